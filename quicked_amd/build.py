@@ -1,0 +1,65 @@
+"""In-tree builds: the gfx950 HIP C-ABI library and the host-side data generator.
+
+Everything is compiled with explicit hipcc / gcc commands into ``quicked_amd/``
+so the ``.so`` files travel with the repository snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HIP_LIB = os.path.join(HERE, "libquicked_hip.so")
+DATAGEN_LIB = os.path.join(HERE, "libqe_datagen.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    subprocess.run(cmd, check=True)
+
+
+def build_datagen(force=False):
+    src = os.path.join(CSRC, "datagen.c")
+    if force or _newer(DATAGEN_LIB, [src]):
+        _run(["gcc", "-O3", "-fPIC", "-shared", "-fopenmp", "-Wall", "-Wextra", src, "-lm", "-o", DATAGEN_LIB])
+    return DATAGEN_LIB
+
+
+def hip_sources():
+    out = []
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".cpp", ".h", ".hpp")):
+            out.append(os.path.join(CSRC, name))
+    out.append(os.path.join(ROOT, "include", "quicked.h"))
+    out.append(os.path.join(ROOT, "include", "quicked_batch.h"))
+    return out
+
+
+def build_hip(force=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs = [s for s in hip_sources() if s.endswith((".hip", ".cpp"))]
+    if force or _newer(HIP_LIB, hip_sources()):
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+        for s in srcs:
+            if s.endswith(".hip"):
+                cmd += ["-x", "hip", s]
+            else:
+                cmd += ["-x", "c++", s]
+        cmd += ["-o", HIP_LIB]
+        _run(cmd)
+    return HIP_LIB
+
+
+def build_all(force=False):
+    build_datagen(force)
+    build_hip(force)

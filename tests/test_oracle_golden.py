@@ -1,0 +1,57 @@
+"""The oracle (oracle/quicked_oracle.c) against the golden vectors captured
+from the compiled reference (tests/golden/make_golden.py).  Runs anywhere."""
+import hashlib
+
+import pytest
+
+import oracle_lib as O
+from quicked_amd import datagen
+
+
+def sha(s):
+    return hashlib.sha256(s.encode()).hexdigest() if s is not None else None
+
+
+def test_kats(golden):
+    for k in golden["kats"]:
+        st, sc, cg = O.oracle_align(k["pattern"].encode(), k["text"].encode(), **k["params"])
+        assert (st, cg) == (k["status"], k["cigar"]), k
+        if st >= 0:
+            assert sc == k["score"], k
+
+
+def test_status_messages():
+    lib = O.oracle()
+    # quicked.c:387-400; tests/CMakeLists.txt:11 greps the EMPTY_SEQUENCE one
+    assert lib.qo_status_msg(O.EMPTY_SEQUENCE) == b"ERROR: Tried to align an empty sequence\n"
+    assert lib.qo_status_msg(O.UNKNOWN_ALGO) == b"ERROR: Unknown algorithm selection\n"
+    assert lib.qo_status_msg(O.WIP) == b"QuickEd finished without errors.\n"
+    assert lib.qo_status_msg(O.OK) == b"QuickEd finished without errors.\n"
+
+
+DATASETS = ["cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len50", "len63", "len64", "len65", "len128",
+            "len130", "len1024", "err35_2kb", "cfg4_100kb_10pct"]
+
+
+@pytest.mark.parametrize("name", DATASETS)
+def test_dataset(golden, name):
+    entry = golden["datasets"][name]
+    batch = datagen.generate(**entry["gen"])
+    pairs = list(batch.pairs())
+    assert [len(p) for p, _ in pairs] == entry["plen"], "generator drifted from the fixture"
+    for label, run in entry["runs"].items():
+        for i, (p, t) in enumerate(pairs):
+            st, sc, cg = O.oracle_align(p, t, **run["params"])
+            assert st == run["status"][i], (name, label, i)
+            assert sc == run["score"][i], (name, label, i)
+            if "cigar_sha256" in run:
+                assert sha(cg) == run["cigar_sha256"][i], (name, label, i)
+                assert O.cigar_is_valid(p, t, cg)
+
+
+def test_exact_distance_agrees_with_golden_quicked(golden):
+    entry = golden["datasets"]["cfg1_1kb_5pct"]
+    batch = datagen.generate(**entry["gen"])
+    lib = O.oracle()
+    for i, (p, t) in enumerate(batch.pairs()):
+        assert lib.qo_exact_distance(p, len(p), t, len(t)) == entry["runs"]["quicked"]["score"][i]

@@ -1,0 +1,60 @@
+"""Oracle vs the compiled reference on fresh random inputs.  Only runs where
+oracle/_ref/libquicked_ref.so exists (built in the container that has
+/root/reference); skipped elsewhere -- the golden-vector tests cover that."""
+import ctypes as C
+
+import pytest
+
+import oracle_lib as O
+from quicked_amd import datagen
+
+pytestmark = pytest.mark.skipif(not O.have_ref(), reason="compiled reference (oracle/_ref) not present")
+
+RUNS = [
+    dict(algo=2, only_score=True, bandwidth=1), dict(algo=2, only_score=True, bandwidth=3),
+    dict(algo=2, only_score=True, bandwidth=15), dict(algo=2, only_score=True, bandwidth=15, force_scalar=True),
+    dict(algo=2, bandwidth=15), dict(algo=3, bandwidth=15),
+    dict(algo=1, only_score=True), dict(algo=1), dict(algo=1, only_score=True, window_size=2),
+    dict(algo=1, window_size=2), dict(algo=1, only_score=True, window_size=2, force_scalar=True),
+    dict(algo=1, only_score=True, window_size=4, overlap_size=2),
+    dict(algo=0), dict(algo=0, force_scalar=True),
+]
+
+
+@pytest.mark.parametrize("gen", [
+    dict(count=40, length=1000, error=0.05, seed=101), dict(count=6, length=10000, error=0.05, seed=102),
+    dict(count=40, length=200, error=0.15, seed=103), dict(count=30, length=70, error=0.2, seed=104),
+    dict(count=20, length=3000, error=0.3, seed=105), dict(count=40, length=1, error=0, seed=106),
+    dict(count=40, length=5, error=2, seed=107),
+])
+def test_random_sets(gen):
+    batch = datagen.generate(**gen)
+    for kw in RUNS:
+        for p, t in batch.pairs():
+            assert O.oracle_align(p, t, **kw) == O.ref_align(p, t, **kw), (gen, kw, len(p), len(t))
+
+
+def test_large_indels_drive_all_stages():
+    batch = datagen.generate(count=12, length=10000, error=0.05, seed=12, indels_num=4, indels_len=800)
+    stages = set()
+    for p, t in batch.pairs():
+        st, sc, cg, tr = O.oracle_align(p, t, trace=True)
+        stages.add(tr["stage"])
+        assert (st, sc, cg) == O.ref_align(p, t)
+        assert (st, sc, cg) == O.ref_align(p, t, force_scalar=True)   # final result is semantics-independent
+    assert {1, 3} <= stages
+
+
+def test_hirschberg_small_splits_are_optimal():
+    """The re-derived join: force many split levels and check optimality."""
+    lib = O.oracle()
+    for gen in (dict(count=20, length=3000, error=0.08, seed=201), dict(count=20, length=2000, error=0.1, seed=202)):
+        for p, t in datagen.generate(**gen).pairs():
+            exact = lib.qo_exact_distance(p, len(p), t, len(t))
+            ops = C.create_string_buffer(len(p) + len(t) + 1)
+            n = C.c_int64()
+            tr = O.QoTrace()
+            st = lib.qo_hirschberg(p, len(p), t, len(t), exact, 1 << 16, ops, C.byref(n), C.byref(tr))
+            assert st == O.OK and tr.hirschberg_splits > 0
+            assert lib.qo_cigar_check(p, len(p), t, len(t), ops, n.value)
+            assert lib.qo_cigar_score(ops, n.value) == exact
