@@ -1,0 +1,68 @@
+/*
+ * quicked_batch.h -- additive batch surface of libquicked_hip.so.
+ *
+ * Not in the reference (its only batch mode is an OpenMP loop over
+ * quicked_align calls, tools/align_benchmark/align_benchmark.c:269-284, fed
+ * from sequence_buffer_t, quicked_utils/include/sequence_buffer.h:30-50).
+ * Per-pair semantics are those of quicked_align() with the aligner's params;
+ * the six reference signatures and both struct layouts are untouched.
+ * Plain pointers and sizes only.
+ */
+#ifndef QUICKED_BATCH_H
+#define QUICKED_BATCH_H
+
+#include "quicked.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* selects the HIP device used by subsequent calls of this thread (default 0) */
+quicked_status_t quicked_set_device(int device);
+
+/* Convenience form: n pairs given as host pointers.  scores_out[n];
+ * cigars_out may be NULL (scores only); otherwise cigars_out[i] is a
+ * NUL-terminated RLE string owned by the aligner until the next batch call or
+ * quicked_free() (NULL for pairs whose status is an error).  status_out may be
+ * NULL.  Returns the first error status, else the common success status. */
+quicked_status_t quicked_align_batch(quicked_aligner_t* aligner, int n,
+                                     const char* const* patterns, const int* pattern_lens,
+                                     const char* const* texts, const int* text_lens,
+                                     int* scores_out, char** cigars_out,
+                                     quicked_status_t* status_out);
+
+/* ---- resident batches: upload once, run many times (what bench.py times) --- */
+typedef struct quicked_batch quicked_batch_t;
+
+/* Pairs stored back to back in two host byte pools (the batch wire format):
+ * pattern i = pattern_pool[pattern_off[i] .. +pattern_len[i]).  Copies the
+ * pools to HBM (H2D) and sizes the device pool; no alignment work. */
+quicked_batch_t* quicked_batch_create(int64_t n,
+                                      const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
+                                      const char* text_pool, const int64_t* text_off, const int32_t* text_len);
+void quicked_batch_destroy(quicked_batch_t* batch);
+
+/* Runs the hot path for every pair with `params` (algo, only_score, ...), from
+ * the ASCII bytes resident in HBM to scores (and CIGAR runs) resident in HBM.
+ * Synchronous w.r.t. the host only if `sync` is non-zero. */
+quicked_status_t quicked_batch_run(quicked_batch_t* batch, const quicked_params_t* params, int sync);
+quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
+
+/* D2H of the results of the last run */
+quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_out, int32_t* status_out);
+/* total bytes of all CIGAR strings incl. terminators, then the strings themselves
+ * (cigar_off[i] = offset of string i in cigar_pool, -1 if none) */
+int64_t quicked_batch_cigar_bytes(quicked_batch_t* batch);
+quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar_pool, int64_t* cigar_off);
+
+/* counters of the last run, for the measurement harness:
+ *   [0] block-advances of score-only BandEd passes   [1] of fills
+ *   [2] WindowEd block steps   [3] traceback steps   [4] CIGAR ops
+ *   [5] last kernel-only time in ns (HIP events on the batch's stream)
+ *   [6] pairs that went past stage 1   [7] pairs that went past stage 2 */
+quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUICKED_BATCH_H */

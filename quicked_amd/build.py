@@ -45,17 +45,12 @@ def hip_sources():
 def build_hip(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    srcs = [s for s in hip_sources() if s.endswith((".hip", ".cpp"))]
+    # one translation unit: qe_driver.hip includes qe_kernels.hip
     if force or _newer(HIP_LIB, hip_sources()):
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-               "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-        for s in srcs:
-            if s.endswith(".hip"):
-                cmd += ["-x", "hip", s]
-            else:
-                cmd += ["-x", "c++", s]
-        cmd += ["-o", HIP_LIB]
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+               os.path.join(CSRC, "qe_driver.hip"), "-o", HIP_LIB]
         _run(cmd)
     return HIP_LIB
 

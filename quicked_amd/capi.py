@@ -1,0 +1,224 @@
+"""ctypes binding of the C-ABI in include/quicked.h + include/quicked_batch.h.
+
+Loads ``quicked_amd/libquicked_hip.so`` (built in-tree by ``build.py``) and
+fails loudly when it is missing: there is no Python or CPU fallback path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build
+
+QUICKED, WINDOWED, BANDED, HIRSCHBERG = 0, 1, 2, 3
+QUICKED_OK, QUICKED_ERROR, QUICKED_FAIL_NON_CONVERGENCE = 0, -1, -2
+QUICKED_UNKNOWN_ALGO, QUICKED_EMPTY_SEQUENCE, QUICKED_UNIMPLEMENTED, QUICKED_WIP = -3, -4, -10, 1
+
+
+class ProfilerCounter(C.Structure):
+    _fields_ = [("total", C.c_uint64), ("samples", C.c_uint64), ("min", C.c_uint64), ("max", C.c_uint64),
+                ("m_oldM", C.c_double), ("m_newM", C.c_double), ("m_oldS", C.c_double), ("m_newS", C.c_double)]
+
+
+class Timespec(C.Structure):
+    _fields_ = [("tv_sec", C.c_long), ("tv_nsec", C.c_long)]
+
+
+class ProfilerTimer(C.Structure):
+    _fields_ = [("begin_timer", Timespec), ("time_ns", ProfilerCounter), ("accumulated", C.c_uint64)]
+
+
+class MMAllocator(C.Structure):
+    _fields_ = [("request_ticker", C.c_uint64), ("segment_size", C.c_uint64), ("segments", C.c_void_p),
+                ("segments_free", C.c_void_p), ("current_segment_idx", C.c_uint64),
+                ("malloc_requests", C.c_void_p), ("malloc_requests_freed", C.c_uint64)]
+
+
+class Params(C.Structure):
+    """quicked_params_t (include/quicked.h; reference quicked/quicked.h:43-54)"""
+    _fields_ = [("algo", C.c_int), ("bandwidth", C.c_uint), ("window_size", C.c_uint), ("overlap_size", C.c_uint),
+                ("hew_threshold", C.c_uint * 2), ("hew_percentage", C.c_uint * 2),
+                ("only_score", C.c_bool), ("force_scalar", C.c_bool), ("external_timer", C.c_bool),
+                ("external_allocator", C.POINTER(MMAllocator))]
+
+
+class Aligner(C.Structure):
+    """quicked_aligner_t (include/quicked.h; reference quicked/quicked.h:56-67)"""
+    _fields_ = [("params", C.POINTER(Params)), ("mm_allocator", C.POINTER(MMAllocator)), ("cigar", C.c_char_p),
+                ("score", C.c_int), ("timer", C.POINTER(ProfilerTimer)),
+                ("timer_windowed_s", C.POINTER(ProfilerTimer)), ("timer_windowed_l", C.POINTER(ProfilerTimer)),
+                ("timer_banded", C.POINTER(ProfilerTimer)), ("timer_align", C.POINTER(ProfilerTimer))]
+
+
+EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params", "quicked_new", "quicked_free",
+           "quicked_align", "quicked_set_device", "quicked_align_batch", "quicked_batch_create",
+           "quicked_batch_destroy", "quicked_batch_run", "quicked_batch_sync", "quicked_batch_scores",
+           "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters"]
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = build.HIP_LIB
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no fallback path")
+    L = C.CDLL(path)
+    L.quicked_check_error.restype = C.c_bool
+    L.quicked_check_error.argtypes = [C.c_int]
+    L.quicked_status_msg.restype = C.c_char_p
+    L.quicked_status_msg.argtypes = [C.c_int]
+    L.quicked_default_params.restype = Params
+    L.quicked_default_params.argtypes = []
+    L.quicked_new.argtypes = [C.POINTER(Aligner), C.POINTER(Params)]
+    L.quicked_free.argtypes = [C.POINTER(Aligner)]
+    L.quicked_align.argtypes = [C.POINTER(Aligner), C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.quicked_set_device.argtypes = [C.c_int]
+    L.quicked_align_batch.argtypes = [C.POINTER(Aligner), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+    L.quicked_batch_create.restype = C.c_void_p
+    L.quicked_batch_create.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.quicked_batch_destroy.argtypes = [C.c_void_p]
+    L.quicked_batch_destroy.restype = None
+    L.quicked_batch_run.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int]
+    L.quicked_batch_sync.argtypes = [C.c_void_p]
+    L.quicked_batch_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.quicked_batch_cigar_bytes.restype = C.c_int64
+    L.quicked_batch_cigar_bytes.argtypes = [C.c_void_p]
+    L.quicked_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.quicked_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
+    _LIB = L
+    return L
+
+
+def make_params(**kw):
+    p = lib().quicked_default_params()
+    for k, v in kw.items():
+        if k in ("hew_threshold", "hew_percentage"):
+            getattr(p, k)[0], getattr(p, k)[1] = v
+        else:
+            setattr(p, k, v)
+    return p
+
+
+class QuickedException(Exception):
+    def __init__(self, status):
+        self.status = status
+        super().__init__(lib().quicked_status_msg(status).decode())
+
+
+class QuickedAligner:
+    """Mirror of the reference's C++/Python binding (bindings/cpp/quicked.hpp:40-66,
+    bindings/python/quicked.cpp:33-45): same method names, same behaviour."""
+
+    def __init__(self):
+        self._lib = lib()
+        self._params = self._lib.quicked_default_params()
+        self._aligner = Aligner()
+        st = self._lib.quicked_new(C.byref(self._aligner), C.byref(self._params))
+        if self._lib.quicked_check_error(st):
+            raise QuickedException(st)
+
+    def __del__(self):
+        try:
+            self._lib.quicked_free(C.byref(self._aligner))
+        except Exception:
+            pass
+
+    def align(self, pattern, text):
+        pattern = pattern.encode() if isinstance(pattern, str) else pattern
+        text = text.encode() if isinstance(text, str) else text
+        st = self._lib.quicked_align(C.byref(self._aligner), pattern, len(pattern), text, len(text))
+        if self._lib.quicked_check_error(st):
+            raise QuickedException(st)
+        return st
+
+    def setAlgorithm(self, algo): self._params.algo = int(algo)
+    def setOnlyScore(self, v): self._params.only_score = bool(v)
+    def setBandwidth(self, v): self._params.bandwidth = int(v)
+    def setWindowSize(self, v): self._params.window_size = int(v)
+    def setOverlapSize(self, v): self._params.overlap_size = int(v)
+    def setForceScalar(self, v): self._params.force_scalar = bool(v)
+
+    def setHEWThreshold(self, v):
+        self._params.hew_threshold[0] = self._params.hew_threshold[1] = int(v)
+
+    def setHEWPercentage(self, v):
+        self._params.hew_percentage[0] = self._params.hew_percentage[1] = int(v)
+
+    def getScore(self): return self._aligner.score
+    def getCigar(self): return self._aligner.cigar.decode() if self._aligner.cigar else "NULL"
+
+    # additive: the batch entry point
+    def alignBatch(self, pairs):
+        n = len(pairs)
+        pats = (C.c_char_p * n)(*[p for p, _ in pairs])
+        txts = (C.c_char_p * n)(*[t for _, t in pairs])
+        pl = (C.c_int * n)(*[len(p) for p, _ in pairs])
+        tl = (C.c_int * n)(*[len(t) for _, t in pairs])
+        scores = (C.c_int * n)(*([-1] * n))
+        status = (C.c_int * n)()
+        cigs = (C.c_char_p * n)()
+        want = not self._params.only_score
+        st = self._lib.quicked_align_batch(C.byref(self._aligner), n, pats, pl, txts, tl, scores,
+                                           cigs if want else None, status)
+        out = [(status[i], scores[i], (cigs[i].decode() if (want and cigs[i]) else None)) for i in range(n)]
+        return st, out
+
+
+class ResidentBatch:
+    """quicked_batch_* : upload once, run many times (what bench.py times)."""
+
+    def __init__(self, batch):
+        self._lib = lib()
+        self.n = len(batch)
+        self._keep = batch
+        self._h = self._lib.quicked_batch_create(
+            self.n, batch.pattern_pool.ctypes.data, batch.pattern_off.ctypes.data, batch.pattern_len.ctypes.data,
+            batch.text_pool.ctypes.data, batch.text_off.ctypes.data, batch.text_len.ctypes.data)
+        if not self._h:
+            raise RuntimeError("quicked_batch_create failed (no GPU / out of memory?)")
+
+    def run(self, params, sync=True):
+        return self._lib.quicked_batch_run(self._h, C.byref(params), 1 if sync else 0)
+
+    def sync(self):
+        return self._lib.quicked_batch_sync(self._h)
+
+    def scores(self):
+        s = np.zeros(self.n, dtype=np.int32)
+        st = np.zeros(self.n, dtype=np.int32)
+        self._lib.quicked_batch_scores(self._h, s.ctypes.data, st.ctypes.data)
+        return s, st
+
+    def cigars(self):
+        nb = self._lib.quicked_batch_cigar_bytes(self._h)
+        pool = np.zeros(max(nb, 1), dtype=np.uint8)
+        off = np.zeros(self.n, dtype=np.int64)
+        self._lib.quicked_batch_cigars(self._h, pool.ctypes.data, off.ctypes.data)
+        raw = pool.tobytes()
+        out = []
+        for o in off:
+            if o < 0:
+                out.append(None)
+            else:
+                e = raw.index(b"\0", o)
+                out.append(raw[o:e].decode())
+        return out
+
+    def counters(self):
+        c = np.zeros(8, dtype=np.int64)
+        self._lib.quicked_batch_counters(self._h, c.ctypes.data)
+        return c
+
+    def close(self):
+        if self._h:
+            self._lib.quicked_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,982 @@
+// qe_driver.hip -- host side of libquicked_hip.so: device pool, batch objects,
+// the bound-and-align driver (run_quicked, quicked.c:163-306) as a staged batch
+// pipeline, and the C-ABI (include/quicked.h, include/quicked_batch.h).
+//
+// Replaces, on this path: quicked/src/quicked.c (drivers), mm_allocator (by a
+// HIP device-pool batch allocator), sequence_buffer (by the pooled batch format).
+// There is no CPU alignment fallback anywhere in this file: every score and
+// every CIGAR comes out of the kernels in qe_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "quicked.h"
+#include "quicked_batch.h"
+#include "qe_types.h"
+#include "qe_kernels.hip"
+
+#define QE_API extern "C" __attribute__((visibility("default")))
+
+namespace qe {
+
+// ---------------------------------------------------------------------------
+// errors: the C-ABI has no exception channel; a HIP failure is fatal for the
+// call and reported as QUICKED_ERROR with the reason on stderr.
+// ---------------------------------------------------------------------------
+struct HipError { hipError_t e; const char* what; int line; };
+#define HIP_CHECK(expr)                                                             \
+    do {                                                                            \
+        hipError_t e__ = (expr);                                                    \
+        if (e__ != hipSuccess) throw qe::HipError{e__, #expr, __LINE__};            \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Device pool: one hipMalloc'd arena per thread and device, carved by a bump
+// pointer from host-side size arithmetic (all scratch sizes are closed-form in
+// plen / tlen / cutoff), reset per batch stage.  Replaces mm_allocator
+// (quicked_utils/src/mm_allocator.c:141-426) on this path.  No device-side
+// malloc, no per-pair hipMalloc.
+// ---------------------------------------------------------------------------
+struct DevicePool {
+    uint8_t* base = nullptr;
+    size_t cap = 0, top = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (base) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(base)); base = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + (1u << 20);
+        HIP_CHECK(hipMalloc((void**)&base, want));
+        cap = want;
+    }
+    void reset() { top = 0; }
+    size_t mark() const { return top; }
+    void release(size_t m) { top = m; }
+    template <typename T> T* take(size_t count) {
+        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (top + bytes > cap) throw HipError{hipErrorOutOfMemory, "device pool exhausted", __LINE__};
+        T* p = (T*)(base + top);
+        top += bytes;
+        return p;
+    }
+    ~DevicePool() { if (base) (void)hipFree(base); }
+};
+
+// sizes a pool request before carving it (two-pass: plan, reserve, carve)
+struct PoolPlan {
+    size_t bytes = 0;
+    template <typename T> void add(size_t count) { bytes += (count * sizeof(T) + 255) & ~(size_t)255; }
+};
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevicePool scratch;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void init() {
+        if (stream) return;
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreate(&ev0));
+        HIP_CHECK(hipEventCreate(&ev1));
+    }
+};
+// the aligner's stage timers (quicked.h:61-66) while one of its calls is running
+struct HostTimers { profiler_timer_t *windowed_s = nullptr, *windowed_l = nullptr, *banded = nullptr, *align = nullptr; };
+static thread_local HostTimers tl_timers;
+static void qe_timer_start(profiler_timer_t* t);
+static void qe_timer_stop(profiler_timer_t* t);
+static thread_local Context* tl_ctx = nullptr;
+static thread_local int tl_device = 0;
+static Context& ctx() {
+    if (!tl_ctx || tl_ctx->device != tl_device) {
+        tl_ctx = new Context();   // lives for the thread; a handful per process
+        tl_ctx->device = tl_device;
+    }
+    tl_ctx->init();
+    return *tl_ctx;
+}
+
+template <typename T>
+static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
+    if (!src.empty()) HIP_CHECK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+template <typename T>
+static void d2h(std::vector<T>& dst, const T* src, size_t n, hipStream_t s) {
+    dst.resize(n);
+    if (n) HIP_CHECK(hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, s));
+}
+
+// ---------------------------------------------------------------------------
+// host mirror of the band geometry (bpm_banded.c:121-135) -- sizes only
+// ---------------------------------------------------------------------------
+struct HGeom { int cutoff, diff, prolog, ebb, ebb_local; };
+static HGeom host_geometry(int m, int n, int cutoff_in) {
+    HGeom g;
+    const int kend = std::abs(n - m) + 1;
+    g.cutoff = std::max(std::max(kend, cutoff_in), 65);
+    g.diff = m - n;
+    const int rel = (g.cutoff - std::abs(g.diff) + 1) / 2;
+    if (g.diff >= 0) { g.prolog = (rel + 63) / 64; g.ebb = (rel + g.diff + 63) / 64 + 1 + g.prolog; }
+    else { g.prolog = (rel - g.diff + 63) / 64; g.ebb = (rel + 63) / 64 + 1 + g.prolog; }
+    g.ebb_local = (g.cutoff + 63) / 64 + 1;
+    return g;
+}
+
+}  // namespace qe
+
+using namespace qe;
+
+// ---------------------------------------------------------------------------
+// A resident batch: ASCII pools + per-pair arrays + planes in one arena that
+// lives as long as the batch; results of the last run.
+// ---------------------------------------------------------------------------
+struct quicked_batch {
+    int64_t n = 0;
+    int device = 0;
+    std::vector<int32_t> p_len, t_len;
+    std::vector<int64_t> p_off, t_off;            // ASCII offsets
+    std::vector<int64_t> plp_off, plt_off;        // plane word offsets
+    std::vector<int32_t> order;                   // task -> pair, sorted by length (ragged batches)
+    // device, persistent
+    uint8_t* arena = nullptr;
+    size_t arena_bytes = 0;
+    uint8_t *d_asc_p = nullptr, *d_asc_t = nullptr;
+    int64_t *d_p_off = nullptr, *d_t_off = nullptr, *d_plp_off = nullptr, *d_plt_off = nullptr;
+    int32_t *d_p_len = nullptr, *d_t_len = nullptr;
+    u64 *d_pl_p = nullptr, *d_pl_t = nullptr, *d_pl_pr = nullptr, *d_pl_tr = nullptr;
+    u32* d_flags = nullptr;
+    int32_t *d_task_pair = nullptr, *d_zero = nullptr;
+    size_t pl_p_words = 0, pl_t_words = 0;
+    bool have_rev = false;
+    // results of the last run, host side, indexed by pair
+    std::vector<int32_t> score, status;
+    std::vector<int64_t> cigar_off;
+    std::vector<char> cigar_pool;
+    bool only_score_run = true;
+    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // results of the last run, device side, indexed by task (what a timed run leaves in HBM)
+    int32_t* d_score = nullptr;
+    bool pending = false;
+    std::string error;
+
+    ~quicked_batch() { if (arena) (void)hipFree(arena); }
+};
+
+namespace qe {
+
+static PairView pair_view(const quicked_batch& B, bool reversed) {
+    PairView v;
+    v.asc_p = B.d_asc_p; v.asc_p_off = B.d_p_off; v.p_len = B.d_p_len;
+    v.asc_t = B.d_asc_t; v.asc_t_off = B.d_t_off; v.t_len = B.d_t_len;
+    v.pl_p = reversed ? B.d_pl_pr : B.d_pl_p; v.pl_p_off = B.d_plp_off;
+    v.pl_t = reversed ? B.d_pl_tr : B.d_pl_t; v.pl_t_off = B.d_plt_off;
+    v.flags = B.d_flags;
+    return v;
+}
+
+static void launch_pack(quicked_batch& B, Context& C, bool reversed) {
+    PackArgs a;
+    a.nseq = (int32_t)B.n;
+    a.reverse = reversed ? 1 : 0;
+    a.flags = reversed ? nullptr : B.d_flags;
+    const int blocks = (int)((B.n + 3) / 4);
+    a.asc = B.d_asc_p; a.asc_off = B.d_p_off; a.len = B.d_p_len;
+    a.planes = reversed ? B.d_pl_pr : B.d_pl_p; a.pl_off = B.d_plp_off;
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, C.stream, a);
+    a.asc = B.d_asc_t; a.asc_off = B.d_t_off; a.len = B.d_t_len;
+    a.planes = reversed ? B.d_pl_tr : B.d_pl_t; a.pl_off = B.d_plt_off;
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, C.stream, a);
+}
+
+// ---------------------------------------------------------------------------
+// One stage = one task list (subset of pairs) laid out as 64-lane groups
+// ---------------------------------------------------------------------------
+struct TaskList {
+    std::vector<int32_t> pair, p0, m, t0, n, cutoff, tfin;   // padded to a multiple of 64, pair = -1 in the padding
+    int ngroups() const { return (int)(pair.size() / 64); }
+    void push(int32_t pr, int32_t p0_, int32_t m_, int32_t t0_, int32_t n_, int32_t cut, int32_t tf) {
+        pair.push_back(pr); p0.push_back(p0_); m.push_back(m_); t0.push_back(t0_); n.push_back(n_);
+        cutoff.push_back(cut); tfin.push_back(tf);
+    }
+    void pad() { while (pair.size() % 64) push(-1, 0, 1, 0, 1, 0, 0); }
+};
+
+struct DevTasks {
+    TaskView v;
+    int32_t *pair, *p0, *m, *t0, *n, *cutoff, *tfin;
+};
+static void plan_tasks(PoolPlan& P, size_t nt) { for (int i = 0; i < 7; ++i) P.add<int32_t>(nt); }
+static DevTasks upload_tasks(const TaskList& L, Context& C) {
+    DevTasks d;
+    const size_t nt = L.pair.size();
+    d.pair = C.scratch.take<int32_t>(nt); d.p0 = C.scratch.take<int32_t>(nt); d.m = C.scratch.take<int32_t>(nt);
+    d.t0 = C.scratch.take<int32_t>(nt); d.n = C.scratch.take<int32_t>(nt); d.cutoff = C.scratch.take<int32_t>(nt);
+    d.tfin = C.scratch.take<int32_t>(nt);
+    h2d(d.pair, L.pair, C.stream); h2d(d.p0, L.p0, C.stream); h2d(d.m, L.m, C.stream); h2d(d.t0, L.t0, C.stream);
+    h2d(d.n, L.n, C.stream); h2d(d.cutoff, L.cutoff, C.stream); h2d(d.tfin, L.tfin, C.stream);
+    d.v.ntasks = (int32_t)nt; d.v.pair = d.pair; d.v.p0 = d.p0; d.v.m = d.m; d.v.t0 = d.t0; d.v.n = d.n;
+    d.v.cutoff = d.cutoff; d.v.tfin = d.tfin;
+    return d;
+}
+
+// per-group workspace geometry of a BandEd launch
+struct BandLayout {
+    std::vector<int64_t> ws_off, mat_off, runs_off;
+    std::vector<int32_t> nslots, nrows, nch, runs_cap;
+    size_t ws_bytes = 0, mat_u4 = 0, runs_u32 = 0;
+};
+static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs) {
+    BandLayout B;
+    const int ng = L.ngroups();
+    B.ws_off.resize(ng); B.mat_off.resize(ng); B.runs_off.resize(ng);
+    B.nslots.resize(ng); B.nrows.resize(ng); B.nch.resize(ng); B.runs_cap.resize(ng);
+    for (int g = 0; g < ng; ++g) {
+        int ns = 3, nr = 4, nch = 2, nmax = 1, cap = 2;
+        for (int l = 0; l < 64; ++l) {
+            const size_t t = (size_t)g * 64 + l;
+            if (L.pair[t] < 0) continue;
+            const HGeom G = host_geometry(L.m[t], L.n[t], L.cutoff[t]);
+            const int nsl = fill ? G.ebb : G.ebb_local;
+            const int nw = (L.m[t] + 63) / 64;
+            ns = std::max(ns, nsl);
+            nr = std::max(nr, nw + nsl + 4);
+            nch = std::max(nch, L.n[t] / 64 + 3);
+            nmax = std::max(nmax, L.n[t]);
+            cap = std::max(cap, L.m[t] + L.n[t] + 2);
+        }
+        B.nslots[g] = ns; B.nrows[g] = nr; B.nch[g] = nch; B.runs_cap[g] = cap;
+        B.ws_off[g] = (int64_t)B.ws_bytes;
+        size_t bytes = (size_t)2 * (ns + 1) * 64 * 8 + (size_t)nr * 64 * 4 + (size_t)2 * nch * 64 * 2;
+        B.ws_bytes += (bytes + 255) & ~(size_t)255;
+        B.mat_off[g] = (int64_t)B.mat_u4;
+        if (fill) B.mat_u4 += (size_t)(nmax + 1) * ns * 64;
+        B.runs_off[g] = (int64_t)B.runs_u32;
+        if (want_runs) B.runs_u32 += (size_t)cap * 64;
+    }
+    return B;
+}
+
+struct DevLayout {
+    uint8_t* ws; int64_t *ws_off, *mat_off, *runs_off; int32_t *nslots, *nrows, *nch, *runs_cap; uint4* mat; u32* runs;
+};
+static void plan_layout(PoolPlan& P, const BandLayout& B) {
+    const size_t ng = B.ws_off.size();
+    P.add<uint8_t>(B.ws_bytes); P.add<uint4>(B.mat_u4); P.add<u32>(B.runs_u32);
+    for (int i = 0; i < 3; ++i) P.add<int64_t>(ng);
+    for (int i = 0; i < 4; ++i) P.add<int32_t>(ng);
+}
+static DevLayout upload_layout(const BandLayout& B, Context& C) {
+    DevLayout d;
+    const size_t ng = B.ws_off.size();
+    d.ws = C.scratch.take<uint8_t>(B.ws_bytes);
+    d.mat = C.scratch.take<uint4>(B.mat_u4);
+    d.runs = C.scratch.take<u32>(B.runs_u32);
+    d.ws_off = C.scratch.take<int64_t>(ng); d.mat_off = C.scratch.take<int64_t>(ng); d.runs_off = C.scratch.take<int64_t>(ng);
+    d.nslots = C.scratch.take<int32_t>(ng); d.nrows = C.scratch.take<int32_t>(ng); d.nch = C.scratch.take<int32_t>(ng);
+    d.runs_cap = C.scratch.take<int32_t>(ng);
+    h2d(d.ws_off, B.ws_off, C.stream); h2d(d.mat_off, B.mat_off, C.stream); h2d(d.runs_off, B.runs_off, C.stream);
+    h2d(d.nslots, B.nslots, C.stream); h2d(d.nrows, B.nrows, C.stream); h2d(d.nch, B.nch, C.stream);
+    h2d(d.runs_cap, B.runs_cap, C.stream);
+    return d;
+}
+
+struct TaskOut {   // device arrays per task
+    int32_t *score, *first, *last, *posv, *hew, *nruns, *nops, *edits, *len;
+    u32 *adv, *steps;
+    int64_t* str_off;
+};
+static void plan_out(PoolPlan& P, size_t nt) { for (int i = 0; i < 11; ++i) P.add<int32_t>(nt); P.add<int64_t>(nt + 1); }
+static TaskOut take_out(Context& C, size_t nt) {
+    TaskOut o;
+    o.score = C.scratch.take<int32_t>(nt); o.first = C.scratch.take<int32_t>(nt); o.last = C.scratch.take<int32_t>(nt);
+    o.posv = C.scratch.take<int32_t>(nt); o.hew = C.scratch.take<int32_t>(nt); o.nruns = C.scratch.take<int32_t>(nt);
+    o.nops = C.scratch.take<int32_t>(nt); o.edits = C.scratch.take<int32_t>(nt); o.len = C.scratch.take<int32_t>(nt);
+    o.adv = C.scratch.take<u32>(nt); o.steps = C.scratch.take<u32>(nt);
+    o.str_off = C.scratch.take<int64_t>(nt + 1);
+    return o;
+}
+
+// ---------------------------------------------------------------------------
+// Stage runners.  Each returns with its kernels enqueued on C.stream.
+// ---------------------------------------------------------------------------
+struct StageResult {
+    std::vector<int32_t> score, hew, first, last, posv, nruns, nops, edits, len;
+    std::vector<u32> adv, steps;
+};
+
+static uint64_t sum_u32(const std::vector<u32>& v) { uint64_t s = 0; for (u32 x : v) s += x; return s; }
+
+// BandEd score-only over a task list (bpm_banded.c:791-964)
+static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
+                             bool fetch, int32_t** d_score_out) {
+    const size_t nt = L.pair.size();
+    const BandLayout lay = band_layout(L, false, false);
+    PoolPlan P; plan_tasks(P, nt); plan_layout(P, lay); plan_out(P, nt);
+    C.scratch.reserve(C.scratch.top + P.bytes);
+    const DevTasks T = upload_tasks(L, C);
+    const DevLayout D = upload_layout(lay, C);
+    const TaskOut O = take_out(C, nt);
+    BandedArgs a;
+    a.P = pair_view(B, reversed); a.T = T.v;
+    a.ws = D.ws; a.g_ws_off = D.ws_off; a.g_nslots = D.nslots; a.g_nrows = D.nrows; a.g_nch = D.nch;
+    a.mat = nullptr; a.g_mat_off = D.mat_off;
+    a.o_score = O.score; a.o_first = O.first; a.o_last = O.last; a.o_posv = O.posv; a.o_adv = O.adv;
+    hipLaunchKernelGGL(k_banded<false>, dim3(L.ngroups()), dim3(64), 0, C.stream, a);
+    if (d_score_out) *d_score_out = O.score;
+    if (fetch && R) {
+        d2h(R->score, O.score, nt, C.stream); d2h(R->adv, O.adv, nt, C.stream);
+        d2h(R->first, O.first, nt, C.stream); d2h(R->last, O.last, nt, C.stream); d2h(R->posv, O.posv, nt, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+    }
+}
+
+// WindowEd over a task list (bpm_windowed.c:563-628)
+struct CigarOut {   // device-side strings of a CIGAR-producing stage
+    char* pool = nullptr; int64_t* str_off = nullptr; int64_t* total = nullptr; int32_t* len = nullptr;
+};
+
+static void format_runs(Context& C, const DevTasks& T, const DevLayout& D, const TaskOut& O, size_t nt, int ngroups,
+                        size_t pool_bytes, char* pool, int64_t* d_total) {
+    FormatArgs f;
+    f.ntasks = (int32_t)nt; f.pair = T.pair; f.runs = D.runs; f.g_runs_off = D.runs_off; f.nruns = O.nruns;
+    f.o_len = O.len; f.str_off = O.str_off; f.pool = pool;
+    hipLaunchKernelGGL(k_format<false>, dim3(ngroups), dim3(64), 0, C.stream, f);
+    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, C.stream, O.len, T.pair, O.str_off, d_total, (int)nt);
+    hipLaunchKernelGGL(k_format<true>, dim3(ngroups), dim3(64), 0, C.stream, f);
+    (void)pool_bytes;
+}
+
+// upper bound of one task's RLE string incl. terminator: every op its own run
+static size_t cigar_bound(int m, int n) { return (size_t)2 * ((size_t)m + (size_t)n) + 12; }
+
+static void fetch_cigars(quicked_batch& B, Context& C, const TaskList& L, const TaskOut& O, const char* pool, size_t nt) {
+    std::vector<int32_t> len; std::vector<int64_t> off;
+    d2h(len, O.len, nt, C.stream); d2h(off, O.str_off, nt, C.stream);
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+    int64_t total = 0;
+    for (size_t t = 0; t < nt; ++t) if (L.pair[t] >= 0) total = std::max<int64_t>(total, off[t] + len[t] + 1);
+    std::vector<char> tmp((size_t)total);
+    if (total) HIP_CHECK(hipMemcpyAsync(tmp.data(), pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+    // append to the batch's pool, indexed by pair
+    for (size_t t = 0; t < nt; ++t) {
+        const int pr = L.pair[t];
+        if (pr < 0) continue;
+        if (len[t] <= 0) { B.cigar_off[pr] = -1; continue; }
+        B.cigar_off[pr] = (int64_t)B.cigar_pool.size();
+        B.cigar_pool.insert(B.cigar_pool.end(), tmp.begin() + off[t], tmp.begin() + off[t] + len[t] + 1);
+    }
+}
+
+static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int W, int O_, int hew_threshold,
+                         bool score_only, bool sse, StageResult* R, bool fetch, bool want_cigar, int32_t** d_score_out) {
+    const size_t nt = L.pair.size();
+    const int ng = L.ngroups();
+    // per group: Pv/Mv [W][64] u64 + history [(64W+3)*W][64] uint4
+    const size_t g_bytes = ((size_t)2 * W * 64 * 8 + (size_t)(64 * W + 3) * W * 64 * 16 + 255) & ~(size_t)255;
+    BandLayout lay;
+    lay.ws_off.resize(ng); lay.mat_off.assign(ng, 0); lay.runs_off.resize(ng);
+    lay.nslots.assign(ng, W); lay.nrows.assign(ng, 0); lay.nch.assign(ng, 0); lay.runs_cap.resize(ng);
+    size_t pool_bytes = 0;
+    for (int g = 0; g < ng; ++g) {
+        int cap = 2;
+        for (int l = 0; l < 64; ++l) {
+            const size_t t = (size_t)g * 64 + l;
+            if (L.pair[t] < 0) continue;
+            cap = std::max(cap, L.m[t] + L.n[t] + 2);
+            if (!score_only) pool_bytes += cigar_bound(L.m[t], L.n[t]);
+        }
+        lay.ws_off[g] = (int64_t)lay.ws_bytes; lay.ws_bytes += g_bytes;
+        lay.runs_cap[g] = cap; lay.runs_off[g] = (int64_t)lay.runs_u32;
+        if (!score_only) lay.runs_u32 += (size_t)cap * 64;
+    }
+    PoolPlan P; plan_tasks(P, nt); plan_layout(P, lay); plan_out(P, nt); P.add<char>(pool_bytes); P.add<int64_t>(1);
+    C.scratch.reserve(C.scratch.top + P.bytes);
+    const DevTasks T = upload_tasks(L, C);
+    const DevLayout D = upload_layout(lay, C);
+    const TaskOut O = take_out(C, nt);
+    char* pool = C.scratch.take<char>(pool_bytes);
+    int64_t* d_total = C.scratch.take<int64_t>(1);
+    WindowArgs a;
+    a.P = pair_view(B, reversed); a.T = T.v;
+    a.W = W; a.O = O_; a.hew_threshold = hew_threshold; a.score_only = score_only ? 1 : 0; a.sse = sse ? 1 : 0; a.reversed = reversed ? 1 : 0;
+    a.ws = D.ws; a.g_ws_off = D.ws_off; a.runs = D.runs; a.g_runs_off = D.runs_off; a.g_runs_cap = D.runs_cap;
+    a.o_score = O.score; a.o_hew = O.hew; a.o_nruns = O.nruns; a.o_nops = O.nops; a.o_edits = O.edits; a.o_steps = O.steps;
+    hipLaunchKernelGGL(k_windowed, dim3(ng), dim3(64), 0, C.stream, a);
+    if (!score_only && want_cigar) format_runs(C, T, D, O, nt, ng, pool_bytes, pool, d_total);
+    if (d_score_out) *d_score_out = O.score;
+    if (fetch && R) {
+        d2h(R->score, O.score, nt, C.stream); d2h(R->hew, O.hew, nt, C.stream); d2h(R->steps, O.steps, nt, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        if (!score_only && want_cigar) fetch_cigars(B, C, L, O, pool, nt);
+    }
+}
+
+// BandEd fill + traceback (+ CIGAR strings) over a task list, sub-batched so the
+// stored matrices fit the pool (bpm_banded.c:199-316, 967-1036; cigar.c:453-488)
+static void run_banded_align(quicked_batch& B, Context& C, const TaskList& L, StageResult* R, bool fetch, bool want_cigar,
+                             int32_t** d_score_out, size_t matrix_budget) {
+    const size_t nt_all = L.pair.size();
+    const int ng_all = L.ngroups();
+    if (R) { R->score.assign(nt_all, -1); R->adv.assign(nt_all, 0); R->steps.assign(nt_all, 0); R->nops.assign(nt_all, 0); }
+    int g0 = 0;
+    while (g0 < ng_all) {
+        // take groups while the matrices fit
+        TaskList S;
+        size_t mat_bytes = 0;
+        int g1 = g0;
+        while (g1 < ng_all) {
+            TaskList one;
+            for (int l = 0; l < 64; ++l) {
+                const size_t t = (size_t)g1 * 64 + l;
+                one.push(L.pair[t], L.p0[t], L.m[t], L.t0[t], L.n[t], L.cutoff[t], L.tfin[t]);
+            }
+            const BandLayout bl = band_layout(one, true, false);
+            if (g1 > g0 && mat_bytes + bl.mat_u4 * 16 > matrix_budget) break;
+            mat_bytes += bl.mat_u4 * 16;
+            for (int l = 0; l < 64; ++l) S.push(one.pair[l], one.p0[l], one.m[l], one.t0[l], one.n[l], one.cutoff[l], one.tfin[l]);
+            ++g1;
+        }
+        const size_t nt = S.pair.size();
+        const int ng = S.ngroups();
+        const size_t mark = C.scratch.mark();
+        const BandLayout lay = band_layout(S, true, true);
+        size_t pool_bytes = 0;
+        if (want_cigar) for (size_t t = 0; t < nt; ++t) if (S.pair[t] >= 0) pool_bytes += cigar_bound(S.m[t], S.n[t]);
+        PoolPlan P; plan_tasks(P, nt); plan_layout(P, lay); plan_out(P, nt); P.add<char>(pool_bytes); P.add<int64_t>(1);
+        C.scratch.reserve(C.scratch.top + P.bytes);
+        const DevTasks T = upload_tasks(S, C);
+        const DevLayout D = upload_layout(lay, C);
+        const TaskOut O = take_out(C, nt);
+        char* pool = C.scratch.take<char>(pool_bytes);
+        int64_t* d_total = C.scratch.take<int64_t>(1);
+        BandedArgs a;
+        a.P = pair_view(B, false); a.T = T.v;
+        a.ws = D.ws; a.g_ws_off = D.ws_off; a.g_nslots = D.nslots; a.g_nrows = D.nrows; a.g_nch = D.nch;
+        a.mat = D.mat; a.g_mat_off = D.mat_off;
+        a.o_score = O.score; a.o_first = O.first; a.o_last = O.last; a.o_posv = O.posv; a.o_adv = O.adv;
+        hipLaunchKernelGGL(k_banded<true>, dim3(ng), dim3(64), 0, C.stream, a);
+        TraceArgs tr;
+        tr.P = a.P; tr.T = T.v;
+        tr.ws = D.ws; tr.g_ws_off = D.ws_off; tr.g_nslots = D.nslots; tr.g_nrows = D.nrows; tr.g_nch = D.nch;
+        tr.mat = D.mat; tr.g_mat_off = D.mat_off;
+        tr.runs = D.runs; tr.g_runs_off = D.runs_off; tr.g_runs_cap = D.runs_cap;
+        tr.o_nruns = O.nruns; tr.o_nops = O.nops; tr.o_edits = O.edits; tr.o_steps = O.steps;
+        hipLaunchKernelGGL(k_traceback, dim3(ng), dim3(64), 0, C.stream, tr);
+        if (want_cigar) format_runs(C, T, D, O, nt, ng, pool_bytes, pool, d_total);
+        if (d_score_out) *d_score_out = O.edits;
+        const bool last_sub = (g1 >= ng_all);
+        if (fetch && R) {
+            std::vector<int32_t> ed, nops; std::vector<u32> adv, steps;
+            d2h(ed, O.edits, nt, C.stream); d2h(adv, O.adv, nt, C.stream); d2h(steps, O.steps, nt, C.stream);
+            d2h(nops, O.nops, nt, C.stream);
+            HIP_CHECK(hipStreamSynchronize(C.stream));
+            for (size_t t = 0; t < nt; ++t) {
+                const size_t dst = (size_t)g0 * 64 + t;
+                R->score[dst] = ed[t]; R->adv[dst] = adv[t]; R->steps[dst] = steps[t]; R->nops[dst] = nops[t];
+            }
+            if (want_cigar) fetch_cigars(B, C, S, O, pool, nt);
+        }
+        if (!last_sub) {
+            HIP_CHECK(hipStreamSynchronize(C.stream));   // the next sub-batch reuses this scratch
+            C.scratch.release(mark);
+        }
+        g0 = g1;
+    }
+}
+
+static int max_cutoff(unsigned bandwidth, int m, int n) {
+    return (int)(((unsigned)std::max(m, n) * bandwidth) / 100u);    // quicked.c:64,131,246 (unsigned arithmetic)
+}
+
+// whole-batch task list in sorted order
+static TaskList all_pairs(const quicked_batch& B, const quicked_params_t& p) {
+    TaskList L;
+    L.pair.reserve((size_t)B.n + 64);
+    for (int64_t i = 0; i < B.n; ++i) {
+        const int pr = B.order[(size_t)i];
+        const int m = B.p_len[pr], n = B.t_len[pr];
+        if (m == 0 || n == 0) continue;                             // QUICKED_EMPTY_SEQUENCE (quicked.c:411-414)
+        L.push(pr, 0, m, 0, n, max_cutoff(p.bandwidth, m, n), n);
+    }
+    L.pad();
+    return L;
+}
+
+static void scatter_scores(quicked_batch& B, const TaskList& L, const std::vector<int32_t>& s, int32_t ok_status) {
+    for (size_t t = 0; t < L.pair.size(); ++t) {
+        const int pr = L.pair[t];
+        if (pr < 0) continue;
+        B.score[pr] = s[t];
+        B.status[pr] = ok_status;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The batch entry point: dispatch on params->algo (quicked_align, quicked.c:405-437)
+// ---------------------------------------------------------------------------
+static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
+    tl_device = B.device;
+    Context& C = ctx();
+    C.scratch.reset();
+    B.only_score_run = p.only_score;
+    B.score.assign((size_t)B.n, -1);
+    B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
+    B.cigar_off.assign((size_t)B.n, -1);
+    B.cigar_pool.clear();
+    for (auto& c : B.counters) c = 0;
+    if ((unsigned)p.algo > (unsigned)HIRSCHBERG) {
+        if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNKNOWN_ALGO);
+        return QUICKED_UNKNOWN_ALGO;
+    }
+    HIP_CHECK(hipEventRecord(C.ev0, C.stream));
+    HIP_CHECK(hipMemsetAsync(B.d_flags, 0, (size_t)B.n * sizeof(u32), C.stream));
+    launch_pack(B, C, false);
+    const bool sse = !p.force_scalar;
+    const bool want_cigar = !p.only_score;
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const size_t matrix_budget = std::max<size_t>((free_b + C.scratch.cap) / 10 * 7, (size_t)1 << 28);
+    quicked_status_t ret = QUICKED_WIP;
+    TaskList L = all_pairs(B, p);
+    if (L.pair.empty()) { HIP_CHECK(hipStreamSynchronize(C.stream)); return QUICKED_EMPTY_SEQUENCE; }
+    StageResult R;
+
+    switch (p.algo) {
+    case BANDED:                                                    // run_banded, quicked.c:58-89
+        if (p.only_score) {
+            run_banded_score(B, C, L, false, &R, fetch, &B.d_score);
+            if (fetch) { scatter_scores(B, L, R.score, QUICKED_WIP); B.counters[0] = (int64_t)sum_u32(R.adv); }
+        } else {
+            run_banded_align(B, C, L, &R, fetch, want_cigar, &B.d_score, matrix_budget);
+            if (fetch) {
+                scatter_scores(B, L, R.score, QUICKED_WIP);
+                B.counters[1] = (int64_t)sum_u32(R.adv); B.counters[3] = (int64_t)sum_u32(R.steps);
+                for (int32_t x : R.nops) B.counters[4] += x;
+            }
+        }
+        break;
+    case WINDOWED:                                                  // run_windowed, quicked.c:91-123
+        run_windowed(B, C, L, false, (int)p.window_size, (int)p.overlap_size, 0, p.only_score, sse, &R, fetch,
+                     want_cigar, &B.d_score);
+        if (fetch) { scatter_scores(B, L, R.score, QUICKED_WIP); B.counters[2] = (int64_t)sum_u32(R.steps); }
+        break;
+    case QUICKED:                                                   // run_quicked, quicked.c:163-306
+    case HIRSCHBERG: {                                              // run_hirschberg, quicked.c:125-161
+        // the bound stages need their results on the host to regroup; the driver is synchronous here
+        std::vector<int32_t> bound(L.pair.size(), 0);
+        if (p.algo == QUICKED) {
+            StageResult S1;
+            qe_timer_start(tl_timers.windowed_s);
+            run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0],
+                         true, sse, &S1, true, false, nullptr);
+            qe_timer_stop(tl_timers.windowed_s);
+            B.counters[2] += (int64_t)sum_u32(S1.steps);
+            bound = S1.score;
+            // stage 2 for the pairs with too many high-error windows (quicked.c:201-202)
+            TaskList L2; std::vector<size_t> idx2;
+            for (size_t t = 0; t < L.pair.size(); ++t) {
+                if (L.pair[t] < 0) continue;
+                const unsigned mx = (unsigned)std::max(L.m[t], L.n[t]);
+                if ((uint64_t)S1.hew[t] * 64u > (uint64_t)(mx * p.hew_percentage[0] / 100u)) {
+                    L2.push(L.pair[t], 0, L.m[t], 0, L.n[t], 0, L.n[t]); idx2.push_back(t);
+                }
+            }
+            B.counters[6] = (int64_t)idx2.size();
+            if (!idx2.empty()) {
+                L2.pad();
+                if (!B.have_rev) { launch_pack(B, C, true); B.have_rev = true; }
+                StageResult F, V;
+                const int W = (int)p.window_size, O = (int)p.overlap_size;
+                qe_timer_start(tl_timers.windowed_l);
+                run_windowed(B, C, L2, false, W, O, (int)p.hew_threshold[1], true, sse, &F, true, false, nullptr);
+                run_windowed(B, C, L2, true, W, O, (int)p.hew_threshold[1], true, sse, &V, true, false, nullptr);
+                qe_timer_stop(tl_timers.windowed_l);
+                B.counters[2] += (int64_t)sum_u32(F.steps) + (int64_t)sum_u32(V.steps);
+                TaskList L3; std::vector<size_t> idx3;
+                for (size_t k = 0; k < idx2.size(); ++k) {
+                    const size_t t = idx2[k];
+                    const int64_t sf = F.score[k], sr = V.score[k];
+                    const int64_t sc = std::min(sf, sr);
+                    const uint64_t hw = (sc >= sr) ? (uint64_t)V.hew[k] : (uint64_t)F.hew[k];   // quicked.c:229-230
+                    bound[t] = (int32_t)sc;
+                    const unsigned mx = (unsigned)std::max(L.m[t], L.n[t]);
+                    if (hw * 64u * (uint64_t)(p.window_size - p.overlap_size) > (uint64_t)(mx * p.hew_percentage[1] / 100u)) {
+                        // stage 3: score-only BandEd, cutoff min(bandwidth%, bound) (quicked.c:246)
+                        const int64_t c0 = std::min<int64_t>((int64_t)(mx * p.bandwidth / 100u), sc);
+                        bound[t] = (int32_t)c0;
+                        L3.push(L.pair[t], 0, L.m[t], 0, L.n[t], (int32_t)c0, L.n[t]); idx3.push_back(t);
+                    }
+                }
+                B.counters[7] = (int64_t)idx3.size();
+                // band doubling (quicked.c:248-278): relaunch on the subset that has not converged
+                while (!idx3.empty()) {
+                    L3.pad();
+                    StageResult S3;
+                    qe_timer_start(tl_timers.banded);
+                    run_banded_score(B, C, L3, false, &S3, true, nullptr);
+                    qe_timer_stop(tl_timers.banded);
+                    B.counters[0] += (int64_t)sum_u32(S3.adv);
+                    TaskList Ln; std::vector<size_t> idxn;
+                    for (size_t k = 0; k < idx3.size(); ++k) {
+                        const size_t t = idx3[k];
+                        const int64_t ns = S3.score[k], sc = L3.cutoff[k];
+                        const int64_t mx = std::max(L.m[t], L.n[t]);
+                        if ((ns > mx / 4 && sc * 3 / 2 < ns) || ns < 0) {
+                            Ln.push(L.pair[t], 0, L.m[t], 0, L.n[t], (int32_t)(sc * 2), L.n[t]); idxn.push_back(t);
+                        } else {
+                            bound[t] = (int32_t)ns;
+                        }
+                    }
+                    L3 = Ln; idx3 = idxn;
+                }
+            }
+        }
+        // align step: bpm_compute_matrix_hirschberg with the bound (quicked.c:283-294) -- leaves only here
+        TaskList LA;
+        bool need_split = false;
+        for (size_t t = 0; t < L.pair.size(); ++t) {
+            if (L.pair[t] < 0) { LA.push(-1, 0, 1, 0, 1, 0, 0); continue; }
+            const int cut = (p.algo == QUICKED) ? bound[t] : L.cutoff[t];
+            const HGeom G = host_geometry(L.m[t], L.n[t], cut);
+            if ((uint64_t)G.ebb * (uint64_t)L.n[t] * 16u > ((uint64_t)1 << 24)) need_split = true;   // bpm_hirschberg.c:63-65
+            LA.push(L.pair[t], 0, L.m[t], 0, L.n[t], cut, L.n[t]);
+        }
+        if (need_split) {
+            // Hirschberg splitting of > 16 MiB alignments is the next row of the scope table;
+            // refuse loudly instead of computing something else.
+            HIP_CHECK(hipStreamSynchronize(C.stream));
+            if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNIMPLEMENTED);
+            return QUICKED_UNIMPLEMENTED;
+        }
+        qe_timer_start(tl_timers.align);
+        run_banded_align(B, C, LA, &R, true, want_cigar, &B.d_score, matrix_budget);
+        qe_timer_stop(tl_timers.align);
+        scatter_scores(B, LA, R.score, p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK);
+        B.counters[1] += (int64_t)sum_u32(R.adv); B.counters[3] += (int64_t)sum_u32(R.steps);
+        for (int32_t x : R.nops) B.counters[4] += x;
+        ret = (p.algo == QUICKED) ? QUICKED_WIP : QUICKED_OK;
+        break;
+    }
+    default: break;
+    }
+    HIP_CHECK(hipEventRecord(C.ev1, C.stream));
+    B.pending = true;
+    if (fetch) {
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, C.ev0, C.ev1));
+        B.counters[5] = (int64_t)(ms * 1e6);
+        B.pending = false;
+    }
+    return ret;
+}
+
+}  // namespace qe
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+static quicked_status_t guard(quicked_batch* B, quicked_status_t (*fn)(quicked_batch*, void*), void* arg) {
+    try { return fn(B, arg); }
+    catch (const HipError& e) {
+        fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+        return QUICKED_ERROR;
+    }
+    catch (const std::bad_alloc&) { fprintf(stderr, "[quicked_hip] out of host memory\n"); return QUICKED_ERROR; }
+}
+
+QE_API quicked_status_t quicked_set_device(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return QUICKED_ERROR;
+    tl_device = device;
+    return QUICKED_OK;
+}
+
+QE_API quicked_batch_t* quicked_batch_create(int64_t n,
+                                             const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
+                                             const char* text_pool, const int64_t* text_off, const int32_t* text_len) {
+    quicked_batch* B = new quicked_batch();
+    try {
+        Context& C = ctx();
+        B->n = n; B->device = C.device;
+        B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
+        // compact the pools (inputs may be sparse in the caller's buffers)
+        B->p_off.resize((size_t)n); B->t_off.resize((size_t)n); B->plp_off.resize((size_t)n); B->plt_off.resize((size_t)n);
+        size_t pb = 0, tb = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            B->p_off[i] = (int64_t)pb; pb += (size_t)pattern_len[i];
+            B->t_off[i] = (int64_t)tb; tb += (size_t)text_len[i];
+            B->plp_off[i] = (int64_t)B->pl_p_words; B->pl_p_words += (size_t)3 * ((size_t)(pattern_len[i] + 63) / 64 + 2);
+            B->plt_off[i] = (int64_t)B->pl_t_words; B->pl_t_words += (size_t)3 * ((size_t)(text_len[i] + 63) / 64 + 2);
+        }
+        B->order.resize((size_t)n);
+        std::iota(B->order.begin(), B->order.end(), 0);
+        std::stable_sort(B->order.begin(), B->order.end(), [&](int a, int b) {
+            const int la = std::max(B->p_len[a], B->t_len[a]), lb = std::max(B->p_len[b], B->t_len[b]);
+            return la > lb;
+        });
+        PoolPlan P;
+        P.add<uint8_t>(pb + 64); P.add<uint8_t>(tb + 64);
+        for (int i = 0; i < 4; ++i) P.add<int64_t>((size_t)n);
+        for (int i = 0; i < 2; ++i) P.add<int32_t>((size_t)n);
+        for (int i = 0; i < 2; ++i) { P.add<u64>(B->pl_p_words + 8); P.add<u64>(B->pl_t_words + 8); }
+        P.add<u32>((size_t)n);
+        B->arena_bytes = P.bytes + 4096;
+        HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
+        DevicePool A; A.base = B->arena; A.cap = B->arena_bytes; A.top = 0;
+        B->d_asc_p = A.take<uint8_t>(pb + 64); B->d_asc_t = A.take<uint8_t>(tb + 64);
+        B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
+        B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
+        B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
+        B->d_pl_p = A.take<u64>(B->pl_p_words + 8); B->d_pl_t = A.take<u64>(B->pl_t_words + 8);
+        B->d_pl_pr = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr = A.take<u64>(B->pl_t_words + 8);
+        B->d_flags = A.take<u32>((size_t)n);
+        A.base = nullptr;   // the batch owns the arena
+        // H2D: gather into pinned-size staging on the host, one copy per pool
+        std::vector<uint8_t> hp(pb + 64, 0), ht(tb + 64, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            if (pattern_len[i]) memcpy(hp.data() + B->p_off[i], pattern_pool + pattern_off[i], (size_t)pattern_len[i]);
+            if (text_len[i]) memcpy(ht.data() + B->t_off[i], text_pool + text_off[i], (size_t)text_len[i]);
+        }
+        HIP_CHECK(hipMemcpyAsync(B->d_asc_p, hp.data(), hp.size(), hipMemcpyHostToDevice, C.stream));
+        HIP_CHECK(hipMemcpyAsync(B->d_asc_t, ht.data(), ht.size(), hipMemcpyHostToDevice, C.stream));
+        h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
+        h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
+        h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        return B;
+    } catch (const HipError& e) {
+        fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+        delete B;
+        return nullptr;
+    }
+}
+
+QE_API void quicked_batch_destroy(quicked_batch_t* batch) {
+    if (!batch) return;
+    (void)hipDeviceSynchronize();
+    delete batch;
+}
+
+QE_API quicked_status_t quicked_batch_run(quicked_batch_t* batch, const quicked_params_t* params, int sync) {
+    struct Arg { const quicked_params_t* p; int sync; } arg{params, sync};
+    return guard(batch, [](quicked_batch* B, void* a) {
+        Arg* x = (Arg*)a;
+        return run_batch(*B, *x->p, x->sync != 0);
+    }, &arg);
+}
+
+QE_API quicked_status_t quicked_batch_sync(quicked_batch_t* batch) {
+    return guard(batch, [](quicked_batch* B, void*) {
+        tl_device = B->device;
+        HIP_CHECK(hipStreamSynchronize(ctx().stream));
+        B->pending = false;
+        return QUICKED_OK;
+    }, nullptr);
+}
+
+QE_API quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_out, int32_t* status_out) {
+    if (batch->score.size() != (size_t)batch->n) return QUICKED_ERROR;
+    if (scores_out) memcpy(scores_out, batch->score.data(), (size_t)batch->n * sizeof(int32_t));
+    if (status_out) memcpy(status_out, batch->status.data(), (size_t)batch->n * sizeof(int32_t));
+    return QUICKED_OK;
+}
+
+QE_API int64_t quicked_batch_cigar_bytes(quicked_batch_t* batch) { return (int64_t)batch->cigar_pool.size(); }
+
+QE_API quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar_pool, int64_t* cigar_off) {
+    if (batch->cigar_off.size() != (size_t)batch->n) return QUICKED_ERROR;
+    if (cigar_pool && !batch->cigar_pool.empty()) memcpy(cigar_pool, batch->cigar_pool.data(), batch->cigar_pool.size());
+    if (cigar_off) memcpy(cigar_off, batch->cigar_off.data(), (size_t)batch->n * sizeof(int64_t));
+    return QUICKED_OK;
+}
+
+QE_API quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]) {
+    memcpy(counters_out, batch->counters, sizeof(batch->counters));
+    return QUICKED_OK;
+}
+
+// ---- the six reference entry points ---------------------------------------
+QE_API bool quicked_check_error(quicked_status_t status) { return status < 0; }    // quicked.c:380
+
+QE_API const char* quicked_status_msg(quicked_status_t status) {                    // quicked.c:382-403
+    switch (status) {
+        case QUICKED_ERROR: return "ERROR: QuickEd has finished with unspecific error\n";
+        case QUICKED_FAIL_NON_CONVERGENCE: return "ERROR: Hirschberg algorithm can not find a middle point of subsequence division!\n";
+        case QUICKED_UNIMPLEMENTED: return "ERROR: The algorithm or parameter combination selected is not implemented\n";
+        case QUICKED_UNKNOWN_ALGO: return "ERROR: Unknown algorithm selection\n";
+        case QUICKED_EMPTY_SEQUENCE: return "ERROR: Tried to align an empty sequence\n";
+        default: return "QuickEd finished without errors.\n";
+    }
+}
+
+QE_API quicked_params_t quicked_default_params(void) {                             // quicked.c:308-321
+    quicked_params_t p;
+    memset(&p, 0, sizeof(p));
+    p.algo = QUICKED;
+    p.bandwidth = 15;
+    p.window_size = 9;
+    p.overlap_size = 1;
+    p.hew_threshold[0] = p.hew_threshold[1] = 40;
+    p.hew_percentage[0] = p.hew_percentage[1] = 15;
+    return p;
+}
+
+// host timers the ABI exposes (profiler_timer.c:53-73, profiler_counter.c:46-66)
+static void qe_timer_reset(profiler_timer_t* t) { memset(t, 0, sizeof(*t)); t->time_ns.min = UINT64_MAX; }
+namespace qe {
+static void qe_timer_start(profiler_timer_t* t) { if (!t) return; t->accumulated = 0; clock_gettime(CLOCK_REALTIME, &t->begin_timer); }
+static void qe_timer_stop(profiler_timer_t* t) {
+    if (!t) return;
+    struct timespec e;
+    clock_gettime(CLOCK_REALTIME, &e);
+    const uint64_t ns = (uint64_t)((e.tv_sec * 1000000000ll + e.tv_nsec) - (t->begin_timer.tv_sec * 1000000000ll + t->begin_timer.tv_nsec));
+    t->accumulated += ns;
+    profiler_counter_t* c = &t->time_ns;
+    const uint64_t amount = t->accumulated;
+    c->total += amount;
+    ++c->samples;
+    if (c->samples == 1) { c->min = amount; c->max = amount; c->m_oldM = (double)amount; c->m_newM = (double)amount; c->m_oldS = 0.0; }
+    else {
+        c->min = std::min(c->min, amount); c->max = std::max(c->max, amount);
+        c->m_newM = c->m_oldM + ((double)amount - c->m_oldM) / (double)c->samples;
+        c->m_newS = c->m_oldS + ((double)amount - c->m_oldM) * ((double)amount - c->m_newM);
+        c->m_oldM = c->m_newM; c->m_oldS = c->m_newS;
+    }
+    t->accumulated = 0;
+}
+}  // namespace qe
+
+// what the library hangs off aligner->mm_allocator when it owns it: the
+// reference keeps its arena there (quicked.c:330-334); here it is the host
+// block that owns the five timers and the last CIGAR strings.
+struct AlignerState {
+    mm_allocator_t shim;                  // first member: a valid mm_allocator_t* for callers that only pass it around
+    profiler_timer_t timers[5];
+    std::vector<char*> batch_cigars;
+    std::vector<char> batch_pool;
+    uint32_t magic;
+};
+static const uint32_t QE_MAGIC = 0x51CEDA11u;
+
+QE_API quicked_status_t quicked_new(quicked_aligner_t* aligner, quicked_params_t* params) {    // quicked.c:323-352
+    aligner->params = params;
+    aligner->score = -1;
+    aligner->cigar = nullptr;
+    AlignerState* st = nullptr;
+    if (params->external_allocator == nullptr) {
+        st = new AlignerState();
+        memset(&st->shim, 0, sizeof(st->shim));
+        st->magic = QE_MAGIC;
+        aligner->mm_allocator = &st->shim;
+    } else {
+        aligner->mm_allocator = params->external_allocator;
+    }
+    if (params->external_timer) {
+        // the caller patches the five pointers after quicked_new (benchmark_edit.c:61-65); NULL until then
+        aligner->timer = aligner->timer_windowed_s = aligner->timer_windowed_l = aligner->timer_banded = aligner->timer_align = nullptr;
+    } else {
+        profiler_timer_t* tm = st ? st->timers : (profiler_timer_t*)calloc(5, sizeof(profiler_timer_t));
+        for (int i = 0; i < 5; ++i) qe_timer_reset(&tm[i]);
+        aligner->timer = &tm[0]; aligner->timer_windowed_s = &tm[1]; aligner->timer_windowed_l = &tm[2];
+        aligner->timer_banded = &tm[3]; aligner->timer_align = &tm[4];
+    }
+    return QUICKED_WIP;
+}
+
+QE_API quicked_status_t quicked_free(quicked_aligner_t* aligner) {                             // quicked.c:354-378
+    if (aligner->cigar != nullptr) { free(aligner->cigar); aligner->cigar = nullptr; }
+    const bool own = aligner->mm_allocator != nullptr && aligner->params->external_allocator == nullptr;
+    if (!aligner->params->external_timer && !own) free(aligner->timer);       // calloc'ed block of five
+    if (own) {
+        AlignerState* st = (AlignerState*)aligner->mm_allocator;
+        if (st->magic == QE_MAGIC) delete st;
+        aligner->mm_allocator = nullptr;
+    }
+    return QUICKED_WIP;
+}
+
+static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const char* const* patterns, const int* plens,
+                                    const char* const* texts, const int* tlens, int* scores_out, char** cigars_out,
+                                    quicked_status_t* status_out, std::vector<char>* pool_keep) {
+    std::vector<int64_t> po((size_t)n), to((size_t)n);
+    std::vector<int32_t> pl((size_t)n), tl((size_t)n);
+    size_t pb = 0, tb = 0;
+    for (int i = 0; i < n; ++i) { po[i] = (int64_t)pb; pb += (size_t)plens[i]; to[i] = (int64_t)tb; tb += (size_t)tlens[i]; pl[i] = plens[i]; tl[i] = tlens[i]; }
+    std::vector<char> pp(pb + 1), tp(tb + 1);
+    for (int i = 0; i < n; ++i) {
+        if (plens[i]) memcpy(pp.data() + po[i], patterns[i], (size_t)plens[i]);
+        if (tlens[i]) memcpy(tp.data() + to[i], texts[i], (size_t)tlens[i]);
+    }
+    quicked_batch_t* B = quicked_batch_create(n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data());
+    if (!B) return QUICKED_ERROR;
+    const quicked_params_t* p = aligner->params;
+    // the five host timers are ticked around the stages they bracket in the reference
+    // (quicked.c:76-78,184-193,204-235,240-275,283-294); a batch is one lap of each.
+    tl_timers.windowed_s = aligner->timer_windowed_s; tl_timers.windowed_l = aligner->timer_windowed_l;
+    tl_timers.banded = aligner->timer_banded; tl_timers.align = aligner->timer_align;
+    qe_timer_start(aligner->timer);
+    quicked_status_t st = quicked_batch_run(B, p, 1);
+    qe_timer_stop(aligner->timer);
+    tl_timers = HostTimers();
+    quicked_status_t first_err = QUICKED_OK;
+    bool any_err = false;
+    for (int i = 0; i < n; ++i) {
+        const quicked_status_t s = (st < 0 && st != QUICKED_EMPTY_SEQUENCE) ? st : (quicked_status_t)B->status[(size_t)i];
+        if (status_out) status_out[i] = s;
+        if (s < 0 && !any_err) { any_err = true; first_err = s; }
+        if (scores_out && s >= 0) scores_out[i] = B->score[(size_t)i];
+    }
+    if (cigars_out) {
+        pool_keep->assign(B->cigar_pool.begin(), B->cigar_pool.end());
+        for (int i = 0; i < n; ++i)
+            cigars_out[i] = (B->cigar_off[(size_t)i] >= 0 && !p->only_score) ? pool_keep->data() + B->cigar_off[(size_t)i] : nullptr;
+    }
+    quicked_batch_destroy(B);
+    if (any_err) return first_err;
+    return st;
+}
+
+QE_API quicked_status_t quicked_align(quicked_aligner_t* aligner, const char* pattern, const int pattern_len,
+                                      const char* text, const int text_len) {                  // quicked.c:405-437
+    if (pattern_len == 0 || text_len == 0) return QUICKED_EMPTY_SEQUENCE;
+    if ((unsigned)aligner->params->algo > (unsigned)HIRSCHBERG) return QUICKED_UNKNOWN_ALGO;
+    int score = -1;
+    char* cg = nullptr;
+    std::vector<char> keep;
+    quicked_status_t one = QUICKED_OK;
+    const quicked_status_t st = align_pairs(aligner, 1, &pattern, &pattern_len, &text, &text_len, &score,
+                                            aligner->params->only_score ? nullptr : &cg, &one, &keep);
+    if (st < 0) return st;
+    aligner->score = score;
+    if (!aligner->params->only_score && cg) {
+        // a previous align's string stays valid until quicked_free in the reference (arena leak, quicked.c:48-50);
+        // here the previous one is released when it is replaced.
+        if (aligner->cigar) free(aligner->cigar);
+        aligner->cigar = strdup(cg);
+    }
+    return st;
+}
+
+QE_API quicked_status_t quicked_align_batch(quicked_aligner_t* aligner, int n,
+                                            const char* const* patterns, const int* pattern_lens,
+                                            const char* const* texts, const int* text_lens,
+                                            int* scores_out, char** cigars_out, quicked_status_t* status_out) {
+    if (n <= 0) return QUICKED_OK;
+    if ((unsigned)aligner->params->algo > (unsigned)HIRSCHBERG) {
+        if (status_out) for (int i = 0; i < n; ++i) status_out[i] = QUICKED_UNKNOWN_ALGO;
+        return QUICKED_UNKNOWN_ALGO;
+    }
+    const bool own = aligner->mm_allocator != nullptr && aligner->params->external_allocator == nullptr &&
+                     ((AlignerState*)aligner->mm_allocator)->magic == QE_MAGIC;
+    static thread_local std::vector<char> tl_keep;     // strings of the last batch when the aligner cannot own them
+    std::vector<char>* keep = own ? &((AlignerState*)aligner->mm_allocator)->batch_pool : &tl_keep;
+    return align_pairs(aligner, n, patterns, pattern_lens, texts, text_lens, scores_out, cigars_out, status_out, keep);
+}

@@ -1,0 +1,708 @@
+// qe_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the QuickEd hot path.
+//
+// Execution model (DESIGN.md "Kernels"): ONE LANE PER ALIGNMENT, 64 alignments
+// per wavefront, no cross-lane traffic.  The reference walks a text column at a
+// time over all band blocks and carries one PHout/MHout bit from block to block
+// (bpm_banded.c:232-262).  Here a lane instead walks ONE 64-row block over a
+// whole 64-column chunk with the block's Pv/Mv in VGPRs, reading the 64 carry-in
+// bits of the block above from a 64-bit "carry word" and producing the 64
+// carry-out bits for the block below as another one.  The dependency graph is
+// the same (block i, column c needs block i-1, column c and block i, column
+// c-1), only the traversal order differs, so every value is bit-identical to
+// the reference's; band bookkeeping then runs per lane exactly as the
+// reference's does every 64 columns (bpm_banded.c:889-922 / 264-301).
+//
+// The 64-column inner loop is pure 32-bit integer VALU on registers (~43 ops
+// per 64 DP cells); global memory is touched once per (block, chunk): 16 B of
+// state + 24 B of pattern planes in, 20 B out, all as [row][lane] rows.
+//
+// No MFMA (bit manipulation, not a contraction), no LDS (nothing is shared
+// between lanes), no CUDA-compat paths.
+#include <hip/hip_runtime.h>
+#include "qe_types.h"
+
+namespace qe {
+
+#define QE_ONES (~(u64)0)
+
+__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
+__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
+__device__ __forceinline__ u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Myers/Hyyro block step (bpm_commons.h:49-68) without the carry extraction:
+// returns the pre-shift horizontal deltas so the caller can pick any row's bit.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void block_step(u64 Eq, u64& P, u64& M, u32 PHin, u32 MHin, u64& Ph_raw, u64& Mh_raw) {
+    const u64 Xv = Eq | M;
+    const u64 Eqc = Eq | (u64)MHin;
+    const u64 Xh = (((Eqc & P) + P) ^ P) | Eqc;
+    u64 Ph = M | ~(Xh | P);
+    u64 Mh = P & Xh;
+    Ph_raw = Ph;
+    Mh_raw = Mh;
+    Ph = (Ph << 1) | (u64)PHin;
+    Mh = (Mh << 1) | (u64)MHin;
+    P = Mh | ~(Xv | Ph);
+    M = Ph & Xv;
+}
+
+// ---------------------------------------------------------------------------
+// 64 columns of one block, fast form: every lane runs all 64 columns, bases are
+// pure ACGT, exported row is bit 63.  Fully unrolled; c is a literal.
+//   a,b     pattern code planes of this block      T0,T1  text code planes of this chunk
+//   hinP/M  carry-in words (bit c = column c)      houtP/M carry-out words
+//   st      column c's {Pv,Mv} goes to st + c*stride (c < 63) / st_last (c == 63)
+// ---------------------------------------------------------------------------
+template <bool STORE>
+__device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0, u64 T1,
+                                           u64 hinP, u64 hinM, u64& houtP, u64& houtM,
+                                           bool act, uint4* st, int64_t st_stride, uint4* st_last) {
+    const u32 alo = lo32(a), ahi = hi32(a), blo = lo32(b), bhi = hi32(b);
+    u32 oP[2] = {0, 0}, oM[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        const int h = c >> 5, s = c & 31;
+        const u32 t0 = h ? hi32(T0) : lo32(T0), t1 = h ? hi32(T1) : lo32(T1);
+        const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0, s, 1);    // 0 / ~0: text code bit 0
+        const u32 m1 = (u32)__builtin_amdgcn_sbfe((int)t1, s, 1);
+        const u32 elo = ~(alo ^ m0) & ~(blo ^ m1);                   // Eq: both code bits equal
+        const u32 ehi = ~(ahi ^ m0) & ~(bhi ^ m1);
+        const u32 PHin = __builtin_amdgcn_ubfe(h ? hi32(hinP) : lo32(hinP), s, 1);
+        const u32 MHin = __builtin_amdgcn_ubfe(h ? hi32(hinM) : lo32(hinM), s, 1);
+        u64 Ph, Mh;
+        block_step(mk64(elo, ehi), P, M, PHin, MHin, Ph, Mh);
+        oP[h] |= (hi32(Ph) >> 31) << s;
+        oM[h] |= (hi32(Mh) >> 31) << s;
+        if (STORE) {
+            if (act) {
+                uint4* q = (c == 63) ? st_last : st + (int64_t)c * st_stride;
+                *q = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));
+            }
+        }
+    }
+    houtP = mk64(oP[0], oP[1]);
+    houtM = mk64(oM[0], oM[1]);
+}
+
+// ---------------------------------------------------------------------------
+// General form: per-lane column count, non-ACGT symbols (N matches N,
+// dna_text.c:41-46 + bpm_banded.c:69-75), and a separate "score row" lvl for
+// the last pattern block (level_mask, bpm_banded.c:88-102).  sP/sM collect bit
+// lvl of every column's horizontal delta, houtP/M bit 63.
+// ---------------------------------------------------------------------------
+template <bool STORE>
+__device__ __forceinline__ void run64_general(u64& P, u64& M, u64 a, u64 b, u64 nn, u64 T0, u64 T1, u64 TN,
+                                           u64 hinP, u64 hinM, u64& houtP, u64& houtM, u64& sP, u64& sM,
+                                           int lvl, int ncols, uint4* st, int64_t st_stride, uint4* st_last) {
+    u64 oP = 0, oM = 0, qP = 0, qM = 0;
+    for (int c = 0; c < 64; ++c) {
+        if (c < ncols) {
+            const u64 m0 = (u64)0 - ((T0 >> c) & 1);
+            const u64 m1 = (u64)0 - ((T1 >> c) & 1);
+            const u64 acgt = ~(a ^ m0) & ~(b ^ m1) & ~nn;
+            const u64 Eq = ((TN >> c) & 1) ? nn : acgt;
+            u64 Ph, Mh;
+            block_step(Eq, P, M, (u32)((hinP >> c) & 1), (u32)((hinM >> c) & 1), Ph, Mh);
+            oP |= (Ph >> 63) << c;
+            oM |= (Mh >> 63) << c;
+            qP |= ((Ph >> lvl) & 1) << c;
+            qM |= ((Mh >> lvl) & 1) << c;
+            if (STORE) {
+                uint4* q = (c == 63) ? st_last : st + (int64_t)c * st_stride;
+                *q = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));
+            }
+        }
+    }
+    houtP = oP; houtM = oM; sP = qP; sM = qM;
+}
+
+// planes of 64 bases starting at bit offset `bit` of a sequence (funnel shift
+// over two rows; sequences are padded with two zero rows)
+__device__ __forceinline__ void load_planes(const u64* __restrict__ base, int bit, u64& a, u64& b, u64& nn) {
+    const int w = bit >> 6, sh = bit & 63;
+    const u64* q = base + 3 * (int64_t)w;
+    u64 a0 = q[0], b0 = q[1], n0 = q[2];
+    if (sh) {
+        const u64 a1 = q[3], b1 = q[4], n1 = q[5];
+        a0 = (a0 >> sh) | (a1 << (64 - sh));
+        b0 = (b0 >> sh) | (b1 << (64 - sh));
+        n0 = (n0 >> sh) | (n1 << (64 - sh));
+    }
+    a = a0; b = b0; nn = n0;
+}
+
+// base code (0..3, 4 = not ACGT) at position `pos` of a packed sequence
+__device__ __forceinline__ int plane_code(const u64* __restrict__ base, int pos) {
+    const u64* q = base + 3 * (int64_t)(pos >> 6);
+    const int s = pos & 63;
+    if ((q[2] >> s) & 1) return 4;
+    return (int)(((q[0] >> s) & 1) | (((q[1] >> s) & 1) << 1));
+}
+
+// ===========================================================================
+// pack: ASCII -> planes.  One wave per sequence; lane l reads byte 64 r + l
+// (one coalesced 64-byte row per load) and three ballots ARE the three plane
+// words of row r.  Lane r % 64 keeps row r; every 64 rows the wave stores 64
+// rows x 24 B = one contiguous 1.5 KB block.
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_pack(PackArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= A.nseq) return;
+    const int len = A.len[seq];
+    const uint8_t* __restrict__ src = A.asc + A.asc_off[seq];
+    u64* __restrict__ dst = A.planes + A.pl_off[seq];
+    const int nw = (len + 63) >> 6;
+    u32 fl = 0;
+    u64 ka = 0, kb = 0, kn = 0;
+    for (int r = 0; r < nw + 2; ++r) {
+        const int pos = r * 64 + lane;
+        u32 ch = 'A';
+        const bool in = pos < len;
+        if (in) ch = A.reverse ? src[len - 1 - pos] : src[pos];
+        const u32 up = ch & 0xDFu;                            // case-insensitive (dna_text.c:44-45)
+        const bool acgt = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+        // A=0x41 C=0x43 G=0x47 T=0x54: bits 1,2 give 0,1,3,2 -- any injective 2-bit code works
+        const u64 wa = __ballot(in && acgt && ((ch >> 1) & 1));
+        const u64 wb = __ballot(in && acgt && ((ch >> 2) & 1));
+        const u64 wn = __ballot(in && !acgt);
+        if (in && !acgt) fl |= FLAG_HAS_N;
+        if (in && !(acgt && ch == up) && ch != 'N') fl |= FLAG_NONCANON;   // lower case or IUPAC: raw != encoded compare
+        if (lane == (r & 63)) { ka = wa; kb = wb; kn = wn; }
+        if ((r & 63) == 63 || r == nw + 1) {
+            const int row = (r & ~63) + lane;
+            if (row <= r) {
+                u64* q = dst + 3 * (int64_t)row;
+                q[0] = ka; q[1] = kb; q[2] = kn;
+            }
+        }
+    }
+    if (A.flags && __any(fl != 0)) {
+        u32 f = fl;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
+        if (lane == 0) atomicOr(&A.flags[seq], f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// band geometry (bpm_banded.c:121-135)
+// ---------------------------------------------------------------------------
+struct Geom { int cutoff, diff, prolog, ebb, fin; };
+__device__ __forceinline__ Geom band_geometry(int m, int n, int cutoff_in) {
+    Geom g;
+    const int kend = abs(n - m) + 1;
+    g.cutoff = max(max(kend, cutoff_in), 65);
+    g.diff = m - n;
+    const int rel = (g.cutoff - abs(g.diff) + 1) / 2;
+    if (g.diff >= 0) {
+        g.prolog = (rel + 63) / 64;
+        g.ebb = (rel + g.diff + 63) / 64 + 1 + g.prolog;
+    } else {
+        g.prolog = (rel - g.diff + 63) / 64;
+        g.ebb = (rel + 63) / 64 + 1 + g.prolog;
+    }
+    g.fin = g.prolog * 64 + g.diff;
+    return g;
+}
+
+struct GroupWs {
+    u64* Pv; u64* Mv; int32_t* S; int16_t* cf; int16_t* cl;
+};
+__device__ __forceinline__ GroupWs group_ws(uint8_t* ws, int64_t off, int ns, int nrows, int nch) {
+    GroupWs w;
+    uint8_t* p = ws + off;
+    w.Pv = (u64*)p;              p += (int64_t)(ns + 1) * 64 * 8;
+    w.Mv = (u64*)p;              p += (int64_t)(ns + 1) * 64 * 8;
+    w.S = (int32_t*)p;           p += (int64_t)nrows * 64 * 4;
+    w.cf = (int16_t*)p;          p += (int64_t)nch * 64 * 2;
+    w.cl = (int16_t*)p;
+    return w;
+}
+
+// ===========================================================================
+// BandEd: score-only (FILL = false, bpm_banded.c:791-964) or full-matrix fill
+// (FILL = true, bpm_banded.c:199-316).  One lane per task.
+// ===========================================================================
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
+    const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
+    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    const bool valid = pair >= 0;
+    int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0, tfin = 0;
+    const u64* pp = A.P.pl_p;
+    const u64* tp = A.P.pl_t;
+    u32 fl = 0;
+    if (valid) {
+        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
+        cut_in = A.T.cutoff[t];
+        tfin = FILL ? n : A.T.tfin[t];
+        pp = A.P.pl_p + A.P.pl_p_off[pair];
+        tp = A.P.pl_t + A.P.pl_t_off[pair];
+        fl = A.P.flags[pair];
+    }
+    const bool hasN = (fl & FLAG_HAS_N) != 0;
+    const Geom G = band_geometry(m, n, cut_in);
+    const int nw = (m + 63) >> 6;
+    // the score-only kernels use their own narrower band (bpm_banded.c:801-803)
+    const int nsl = FILL ? G.ebb : ((G.cutoff + 63) >> 6) + 1;
+    const int stop_row = FILL ? nw - 1 : nw;                       // bpm_banded.c:295 / 917
+    const int lvl_last = (m - 1) & 63;                             // level_mask of the last block
+    int first = G.prolog, last = nsl - 1, pos_v = -G.prolog, pos_h = 0;
+    int max_row_init = nsl - 1;
+    u32 adv = 0;
+
+    const int gns = A.g_nslots[g], gnr = A.g_nrows[g], gnch = A.g_nch[g];
+    const GroupWs W = group_ws(A.ws, A.g_ws_off[g], gns, gnr, gnch);
+    u64* const Pv = W.Pv + 64 + lane;        // slot s lives at Pv[s * 64]; slot -1 is addressable
+    u64* const Mv = W.Mv + 64 + lane;
+    int32_t* const S = W.S + lane;           // scores[] indexed by absolute block row (bpm_banded.c:180-197)
+    uint4* const mat = FILL ? A.mat + A.g_mat_off[g] + lane : nullptr;
+    const int64_t col_stride = (int64_t)gns * 64;                  // uint4 units between columns
+
+    // bpm_reset_search (bpm_banded.c:180-197)
+    for (int s = 0; s < gns; ++s) {
+        if (valid && s < nsl) {
+            Pv[(int64_t)s * 64] = QE_ONES;
+            Mv[(int64_t)s * 64] = 0;
+            S[(int64_t)s * 64] = 64 * (s + 1);
+            if (FILL) mat[(int64_t)s * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+        }
+    }
+    if (FILL && valid) { W.cf[lane] = (int16_t)first; W.cl[lane] = (int16_t)last; }
+
+    const int nfull = tfin >> 6, tail = tfin & 63;
+    const int my_chunks = valid ? nfull + (tail ? 1 : 0) : 0;
+    const int wave_chunks = wave_max(my_chunks);
+
+    for (int k = 0; k < wave_chunks; ++k) {
+        const int ncols = (k < nfull) ? 64 : ((k == nfull) ? tail : 0);
+        const bool on = valid && ncols > 0;
+        u64 T0 = 0, T1 = 0, TN = 0;
+        if (on) load_planes(tp, t0 + 64 * k, T0, T1, TN);
+        const int rhi = min(last, nw - 1 - pos_v);                 // rows >= nw are never computed (A.7(2))
+        const int i0 = wave_min(on ? first : 0x7fffffff);
+        const int i1 = wave_max(on ? rhi : -0x7fffffff);
+        u64 hinP = QE_ONES, hinM = 0;
+        for (int i = i0; i <= i1; ++i) {
+            const bool act = on && i >= first && i <= rhi;
+            const int r = i + pos_v;
+            u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
+            int sc = 0;
+            if (act) {
+                P = Pv[(int64_t)i * 64];
+                M = Mv[(int64_t)i * 64];
+                sc = S[(int64_t)r * 64];
+                load_planes(pp, p0 + 64 * r, a, b, nn);
+            }
+            if (i == first) { hinP = QE_ONES; hinM = 0; }          // PHin = 1 into the band's top block
+            const bool lastblk = (r == nw - 1);
+            uint4* st = nullptr; uint4* st_last = nullptr;
+            if (FILL) {
+                // column c of this chunk is stored as matrix column 64k + c + 1; the chunk's last
+                // column is stored under the NEXT chunk's slot numbering (bpm_banded.c:279-287)
+                st = mat + (int64_t)(64 * k + 1) * col_stride + (int64_t)i * 64;
+                st_last = mat + (int64_t)(64 * k + 64) * col_stride + (int64_t)(i - 1) * 64;
+                if (i == 0) st_last = st + 63 * col_stride;        // slot -1 does not exist; dropped row, never read
+            }
+            u64 houtP, houtM, sP, sM;
+            const bool slow = act && (ncols != 64 || hasN || lastblk);
+            if (!__any(slow)) {
+                run64_fast<FILL>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, col_stride, st_last);
+                sP = houtP; sM = houtM;
+            } else {
+                run64_general<FILL>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
+                                    lastblk ? lvl_last : 63, act ? ncols : 0, st, col_stride,
+                                    (ncols == 64) ? st_last : st + 63 * col_stride);
+            }
+            if (act) {
+                sc += __popcll(sP) - __popcll(sM);
+                S[(int64_t)r * 64] = sc;
+                // in-place band shift: slot i of this chunk is slot i-1 of the next (bpm_banded.c:903-909)
+                const int64_t dst = (ncols == 64) ? (int64_t)(i - 1) * 64 : (int64_t)i * 64;
+                Pv[dst] = P;
+                Mv[dst] = M;
+                adv += (u32)ncols;
+            }
+            hinP = houtP; hinM = houtM;
+        }
+        if (on && ncols == 64) {
+            // every-64-columns bookkeeping (bpm_banded.c:889-922 / 264-301)
+            const bool c1 = (first + 2 < last) && (G.fin > 64 * (first + 1));
+            bool cut_lo = false;
+            if (c1) cut_lo = S[(int64_t)(first + pos_v + 1) * 64] + (G.fin - 64 * (first + 1)) > G.cutoff;
+            if (cut_lo && pos_h >= G.prolog) first++;
+            else if (!cut_lo && pos_h < G.prolog) first--;
+            Pv[(int64_t)last * 64] = QE_ONES;
+            Mv[(int64_t)last * 64] = 0;
+            if (FILL) mat[(int64_t)(64 * k + 64) * col_stride + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+            const int pos = last + pos_v;
+            S[(int64_t)(pos + 1) * 64] = S[(int64_t)pos * 64] + 64;
+            max_row_init = max(max_row_init, pos + 1);
+            const bool c2 = (first + 2 < last) && (64 * (last - 1) > G.fin);
+            bool cut_hi = false;
+            if (c2) cut_hi = S[(int64_t)(last + pos_v - 1) * 64] + (64 * (last - 1) - G.fin) > G.cutoff;
+            if (cut_hi || (pos_v + last >= stop_row)) last--;
+            pos_v++;
+            pos_h++;
+            if (FILL) { W.cf[(int64_t)pos_h * 64 + lane] = (int16_t)first; W.cl[(int64_t)pos_h * 64 + lane] = (int16_t)last; }
+        }
+    }
+    if (valid) {
+        // final score read-out (bpm_banded.c:952-961); -1: band never reached the last block (A.7(3))
+        const int row = nw - 1;
+        int score = -1;
+        if (row <= max_row_init) {
+            score = S[(int64_t)row * 64];
+            if (m & 63) score -= 64 - (m & 63);
+        }
+        A.o_score[t] = score;
+        A.o_first[t] = first;
+        A.o_last[t] = last;
+        A.o_posv[t] = pos_v;
+        A.o_adv[t] = adv;                                     // block-advances (one per block per column)
+    }
+}
+
+template __global__ void k_banded<false>(BandedArgs);
+template __global__ void k_banded<true>(BandedArgs);
+
+// ---------------------------------------------------------------------------
+// RLE emitter shared by the tracebacks: ops arrive back to front
+// ---------------------------------------------------------------------------
+struct RunSink {
+    u32* runs; int cap; int nruns; int cur_op; int cur_len; int nops; int edits;
+    __device__ __forceinline__ void init(u32* r, int c) { runs = r; cap = c; nruns = 0; cur_op = -1; cur_len = 0; nops = 0; edits = 0; }
+    __device__ __forceinline__ void push(int op) {
+        if (op == cur_op) { ++cur_len; }
+        else {
+            if (cur_len > 0 && nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
+            if (cur_len > 0) ++nruns;
+            cur_op = op; cur_len = 1;
+        }
+        ++nops;
+        edits += (op != (int)OP_M);
+    }
+    __device__ __forceinline__ void push_n(int op, int count) {
+        if (count <= 0) return;
+        if (op == cur_op) { cur_len += count; }
+        else {
+            if (cur_len > 0 && nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
+            if (cur_len > 0) ++nruns;
+            cur_op = op; cur_len = count;
+        }
+        nops += count;
+        edits += (op != (int)OP_M) ? count : 0;
+    }
+    __device__ __forceinline__ void flush() {
+        if (cur_len > 0) {
+            if (nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
+            ++nruns;
+            cur_len = 0;
+        }
+    }
+};
+
+// raw-byte equality of text[h] and pattern[v] (bpm_banded.c:1012): encoded
+// equality is the same thing for upper-case ACGTN input; other input compares bytes
+struct EqTest {
+    const u64* pp; const u64* tp; const uint8_t* ap; const uint8_t* at; bool raw;
+    int rp = -1, rt = -1;     // >= 0: the planes hold the reversed strings, ASCII index = r - i
+    __device__ __forceinline__ bool eq(int v, int h) const {
+        if (raw) return ap[rp >= 0 ? rp - v : v] == at[rt >= 0 ? rt - h : h];
+        return plane_code(pp, v) == plane_code(tp, h);
+    }
+};
+
+// ===========================================================================
+// BandEd traceback (bpm_banded.c:967-1036): priority D -> I -> M/X.  One lane
+// per task walks its own path through the [col][slot][lane] matrix.  Cells
+// outside the stored band read as P = 0, M = 0 (see oracle header).
+// ===========================================================================
+__global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
+    const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
+    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    if (pair < 0) return;
+    const int m = A.T.m[t], n = A.T.n[t], p0 = A.T.p0[t], t0 = A.T.t0[t];
+    const Geom G = band_geometry(m, n, A.T.cutoff[t]);
+    const int gns = A.g_nslots[g];
+    const GroupWs W = group_ws(const_cast<uint8_t*>(A.ws), A.g_ws_off[g], gns, A.g_nrows[g], A.g_nch[g]);
+    const int16_t* cf = W.cf + lane;
+    const int16_t* cl = W.cl + lane;
+    const uint4* mat = A.mat + A.g_mat_off[g] + lane;
+    const int64_t col_stride = (int64_t)gns * 64;
+    EqTest E;
+    E.pp = A.P.pl_p + A.P.pl_p_off[pair] ; E.tp = A.P.pl_t + A.P.pl_t_off[pair];
+    E.ap = A.P.asc_p + A.P.asc_p_off[pair]; E.at = A.P.asc_t + A.P.asc_t_off[pair];
+    E.raw = (A.P.flags[pair] & FLAG_NONCANON) != 0;
+    RunSink R;
+    R.init(A.runs + A.g_runs_off[g] + lane, A.g_runs_cap[g]);
+    int h = n - 1, v = m - 1;
+    u32 steps = 0;
+    while (v >= 0 && h >= 0) {
+        const int bh = h >> 6, bhr = (h + 1) >> 6;
+        const int ev = v - 64 * (bh - G.prolog), evr = v - 64 * (bhr - G.prolog);
+        u32 pbit = 0, mbit = 0;
+        {   // Pv at column h + 1
+            const int col = h + 1, ck = col >> 6;
+            const int lo = cf[(int64_t)ck * 64];
+            const int hi = (col & 63) ? cl[(int64_t)ck * 64] : cl[(int64_t)(ck - 1) * 64];
+            const int slot = evr >> 6;
+            if (evr >= 0 && slot >= lo && slot <= hi) {
+                const uint4 q = mat[(int64_t)col * col_stride + (int64_t)slot * 64];
+                const int bit = evr & 63;
+                pbit = ((bit < 32 ? q.x : q.y) >> (bit & 31)) & 1;
+            }
+        }
+        if (!pbit) {   // Mv at column h
+            const int col = h, ck = col >> 6;
+            int lo, hi;
+            if (col == 0) { lo = 0; hi = G.ebb - 1; }
+            else { lo = cf[(int64_t)ck * 64]; hi = (col & 63) ? cl[(int64_t)ck * 64] : cl[(int64_t)(ck - 1) * 64]; }
+            const int slot = ev >> 6;
+            if (ev >= 0 && slot >= lo && slot <= hi) {
+                const uint4 q = mat[(int64_t)col * col_stride + (int64_t)slot * 64];
+                const int bit = ev & 63;
+                mbit = ((bit < 32 ? q.z : q.w) >> (bit & 31)) & 1;
+            }
+        }
+        if (pbit) { R.push(OP_D); --v; }
+        else if (mbit) { R.push(OP_I); --h; }
+        else { R.push(E.eq(p0 + v, t0 + h) ? OP_M : OP_X); --h; --v; }
+        ++steps;
+    }
+    R.push_n(OP_I, h + 1);
+    R.push_n(OP_D, v + 1);
+    R.flush();
+    A.o_nruns[t] = R.nruns;
+    A.o_nops[t] = R.nops;
+    A.o_edits[t] = R.edits;
+    A.o_steps[t] = steps;
+}
+
+// ===========================================================================
+// WindowEd chain (bpm_windowed.c:563-628): windows of W x W blocks anchored at
+// the current traceback position, filled (202-280; SSE semantics 283-445 when
+// sse && W == 2), traced back inside the non-overlap region (448-561).
+// ===========================================================================
+__global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
+    const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
+    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    const bool valid = pair >= 0;
+    const int W = A.W, O = A.O;
+    int m = 0, n = 0, p0 = 0, t0 = 0;
+    const u64* pp = A.P.pl_p; const u64* tp = A.P.pl_t;
+    u32 fl = 0;
+    EqTest E; E.pp = pp; E.tp = tp; E.ap = nullptr; E.at = nullptr; E.raw = false;
+    if (valid) {
+        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
+        pp = A.P.pl_p + A.P.pl_p_off[pair]; tp = A.P.pl_t + A.P.pl_t_off[pair];
+        fl = A.P.flags[pair];
+        E.pp = pp; E.tp = tp;
+        E.ap = A.P.asc_p + A.P.asc_p_off[pair]; E.at = A.P.asc_t + A.P.asc_t_off[pair];
+        E.raw = (fl & FLAG_NONCANON) != 0;
+        if (A.reversed) { E.rp = A.P.p_len[pair] - 1; E.rt = A.P.t_len[pair] - 1; }
+    }
+    const bool hasN = (fl & FLAG_HAS_N) != 0;
+    const bool sse = A.sse && W == 2;                               // bpm_windowed.c:577
+    uint8_t* wsb = A.ws + A.g_ws_off[g];
+    u64* const Pv = (u64*)wsb + lane;                               // [W][64]
+    u64* const Mv = (u64*)wsb + (int64_t)W * 64 + lane;
+    uint4* const hist = (uint4*)(wsb + (int64_t)2 * W * 64 * 8) + lane;   // [(col * W + blk)][64]
+    const int64_t hcol = (int64_t)W * 64;                           // uint4 units between history columns
+    RunSink R;
+    R.init(A.score_only ? nullptr : A.runs + A.g_runs_off[g] + lane, A.score_only ? 0 : A.g_runs_cap[g]);
+    int pos_v = m - 1, pos_h = n - 1;
+    int score = 0, hew = 0;
+    u32 steps = 0;
+
+    while (__any(valid && pos_v >= 0 && pos_h >= 0)) {
+        const bool on = valid && pos_v >= 0 && pos_h >= 0;
+        const int v_fi = pos_v, h_fi = pos_h;
+        const int v0 = max(v_fi - 64 * W + 1, 0), h0 = max(h_fi - 64 * W + 1, 0);
+        const int steps_v = on ? (v_fi - v0) / 64 + 1 : 0;
+        const int steps_h = h_fi - h0;
+        const int ncols_total = on ? steps_h + 1 : 0;
+        const u64 ph_first = (v0 == 0) ? QE_ONES : 0;               // D[0][c] = c only on the real first row
+        // left boundary: Pv = ~0 on the real first column, else free start (bpm_windowed.c:226-230)
+        if (on) {
+            for (int i = 0; i < W; ++i) {
+                const u64 pinit = (h0 == 0) ? QE_ONES : 0;
+                Pv[(int64_t)i * 64] = pinit;
+                Mv[(int64_t)i * 64] = 0;
+                hist[(int64_t)i * 64] = make_uint4(lo32(pinit), hi32(pinit), 0u, 0u);
+            }
+        }
+        const int nchunk = wave_max((ncols_total + 63) >> 6);
+        const int nblk = wave_max(steps_v);
+        for (int j = 0; j < nchunk; ++j) {
+            const int ncols = min(max(ncols_total - 64 * j, 0), 64);
+            u64 T0 = 0, T1 = 0, TN = 0;
+            if (ncols > 0) load_planes(tp, t0 + h0 + 64 * j, T0, T1, TN);
+            u64 hinP, hinM = 0;
+            if (sse) hinP = (j == 0) ? (0x5555555555555556ull | (ph_first & 1)) : 0x5555555555555555ull;
+            else hinP = ph_first;
+            for (int i = 0; i < nblk; ++i) {
+                const bool act = ncols > 0 && i < steps_v;
+                u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
+                if (act) {
+                    P = Pv[(int64_t)i * 64];
+                    M = Mv[(int64_t)i * 64];
+                    load_planes(pp, p0 + v0 + 64 * i, a, b, nn);    // bit-unaligned window rows (237-244)
+                }
+                uint4* st = hist + (int64_t)(64 * j + 1) * hcol + (int64_t)i * 64;
+                u64 houtP, houtM, sP, sM;
+                const bool slow = act && (ncols != 64 || hasN);
+                if (!__any(slow)) {
+                    run64_fast<true>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, hcol, st + 63 * hcol);
+                } else {
+                    run64_general<true>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
+                                        63, act ? ncols : 0, st, hcol, st + 63 * hcol);
+                }
+                if (act) { Pv[(int64_t)i * 64] = P; Mv[(int64_t)i * 64] = M; steps += (u32)ncols; }
+                hinP = houtP; hinM = houtM;
+            }
+        }
+        if (sse && on && steps_v == 2 && (steps_h & 1)) {
+            // the SSE kernel runs block 0 one column past the window and redoes block 1's last
+            // column with the carries of that extra column (bpm_windowed.c:428-444)
+            u64 a, b, nn, P = Pv[0], M = Mv[0];
+            load_planes(pp, p0 + v0, a, b, nn);
+            const int tc = (h_fi + 1 < n) ? plane_code(tp, t0 + h_fi + 1) : 4;      // text[tlen] reads as N (A.7(4))
+            u64 Eq = (tc == 4) ? nn : (~(a ^ ((u64)0 - (u64)(tc & 1))) & ~(b ^ ((u64)0 - (u64)((tc >> 1) & 1))) & ~nn);
+            u64 Ph, Mh;
+            block_step(Eq, P, M, 1u, 0u, Ph, Mh);                   // column steps_h + 1 is even: PHin = 1
+            const u32 cP = (u32)(Ph >> 63), cM = (u32)(Mh >> 63);
+            load_planes(pp, p0 + v0 + 64, a, b, nn);
+            const uint4 q = hist[(int64_t)steps_h * hcol + 64];
+            P = mk64(q.x, q.y); M = mk64(q.z, q.w);
+            const int tl = plane_code(tp, t0 + h_fi);
+            Eq = (tl == 4) ? nn : (~(a ^ ((u64)0 - (u64)(tl & 1))) & ~(b ^ ((u64)0 - (u64)((tl >> 1) & 1))) & ~nn);
+            block_step(Eq, P, M, cP, cM, Ph, Mh);
+            hist[(int64_t)(steps_h + 1) * hcol + 64] = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));
+        }
+        // in-window traceback (bpm_windowed.c:448-561)
+        if (on) {
+            int h = pos_h, v = pos_v;
+            const int h_min = max(pos_h - 64 * W + 1, 0), h_ov = max(pos_h - 64 * (W - O) + 1, 0);
+            const int v_min = max(pos_v - 64 * W + 1, 0), v_ov = max(pos_v - 64 * (W - O) + 1, 0);
+            int wscore = 0;
+            while (v >= v_ov && h >= h_ov) {
+                const int blk = ((v - v_min) >> 6) & 0xff;
+                const int bit = (v - v_min) & 63;                   // A.7(1)
+                const int64_t idx = (int64_t)(h - h_min + 1) * hcol + (int64_t)blk * 64;
+                const uint4 qp = hist[idx];
+                const uint4 qm = hist[idx - hcol];
+                const u32 pb = ((bit < 32 ? qp.x : qp.y) >> (bit & 31)) & 1;
+                const u32 mb = ((bit < 32 ? qm.z : qm.w) >> (bit & 31)) & 1;
+                const bool eq = E.eq(p0 + v, t0 + h);
+                if (A.score_only) {                                 // D -> I -> match -> X (527-549)
+                    if (pb) { ++wscore; --v; }
+                    else if (mb) { ++wscore; --h; }
+                    else { wscore += eq ? 0 : 1; --h; --v; }
+                } else {                                            // match -> D -> I -> X (476-495)
+                    if (eq) { R.push(OP_M); --h; --v; }
+                    else if (pb) { R.push(OP_D); --v; }
+                    else if (mb) { R.push(OP_I); --h; }
+                    else { R.push(OP_X); --h; --v; }
+                }
+            }
+            if (A.score_only) {
+                if (wscore > (W - O) * 64 * A.hew_threshold / 100) ++hew;
+                score += wscore;
+            }
+            pos_h = h; pos_v = v;
+        }
+    }
+    if (valid) {
+        if (A.score_only) {
+            if (pos_h >= 0) score += pos_h + 1;
+            if (pos_v >= 0) score += pos_v + 1;
+            A.o_score[t] = score;
+            A.o_hew[t] = hew;
+        } else {
+            R.push_n(OP_I, pos_h + 1);
+            R.push_n(OP_D, pos_v + 1);
+            R.flush();
+            A.o_nruns[t] = R.nruns;
+            A.o_nops[t] = R.nops;
+            A.o_edits[t] = R.edits;
+            A.o_score[t] = R.edits;
+            A.o_hew[t] = 0;
+        }
+        A.o_steps[t] = steps;
+    }
+}
+
+// ===========================================================================
+// CIGAR formatting (cigar_sprint, cigar.c:453-488): runs are stored back to
+// front, the string goes front to back: "<len><op>" per run.
+// ===========================================================================
+__device__ __forceinline__ int dec_digits(u32 x) {
+    int d = 1;
+    while (x >= 10) { x /= 10; ++d; }
+    return d;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_format(FormatArgs A) {
+    const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
+    if (t >= A.ntasks || A.pair[t] < 0) return;
+    const u32* runs = A.runs + A.g_runs_off[g] + lane;
+    const int nr = A.nruns[t];
+    if (!WRITE) {
+        int len = 0;
+        for (int i = 0; i < nr; ++i) len += dec_digits(runs[(int64_t)i * 64] >> 2) + 1;
+        A.o_len[t] = len;
+    } else {
+        char* out = A.pool + A.str_off[t];
+        for (int i = nr - 1; i >= 0; --i) {
+            const u32 r = runs[(int64_t)i * 64];
+            u32 len = r >> 2;
+            const int d = dec_digits(len);
+            for (int k = d - 1; k >= 0; --k) { out[k] = (char)('0' + len % 10); len /= 10; }
+            out[d] = (char)(0x4449584Du >> (8 * (r & 3)));   // "MXID"
+            out += d + 1;
+        }
+        *out = '\0';
+    }
+}
+template __global__ void k_format<false>(FormatArgs);
+template __global__ void k_format<true>(FormatArgs);
+
+// exclusive scan of (len + 1) over tasks -> string offsets; single block
+__global__ __launch_bounds__(1024) void k_scan_offsets(const int32_t* len, const int32_t* pair, int64_t* off, int64_t* total, int n) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int64_t s = 0;
+    for (int i = lo; i < hi; ++i) s += (pair[i] >= 0) ? (int64_t)len[i] + 1 : 0;
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t acc = 0;
+        for (int i = 0; i < 1024; ++i) { const int64_t v = part[i]; part[i] = acc; acc += v; }
+        *total = acc;
+    }
+    __syncthreads();
+    int64_t acc = part[tid];
+    for (int i = lo; i < hi; ++i) {
+        off[i] = acc;
+        acc += (pair[i] >= 0) ? (int64_t)len[i] + 1 : 0;
+    }
+}
+
+}  // namespace qe

@@ -1,0 +1,97 @@
+// qe_types.h -- argument blocks shared by the host driver and the gfx950 kernels.
+//
+// Data model (DESIGN.md "Data layout in HBM"):
+//   pair    one (pattern, text) of the batch; owns ASCII bytes and bit-planes.
+//   planes  per pair and per sequence, 3 x u64 per 64 bases, interleaved
+//           [row][plane]: plane 0/1 = the two bits of the base code, plane 2 =
+//           "not ACGT" (the reference's code 4, dna_text.c:41-46).  Two zero
+//           rows of padding follow every sequence (funnel-shift over-read).
+//   task    one unit of kernel work = a sub-rectangle of a pair:
+//           pattern[p0, p0+m) x text[t0, t0+n) with a cutoff.  Whole-pair
+//           alignments are tasks with p0 = t0 = 0; Hirschberg children are not.
+//   group   64 consecutive tasks = one wavefront; lane l of group g owns task
+//           64 g + l for the whole kernel (one lane per alignment, no cross-lane
+//           traffic; all per-task state is addressed [..][lane] so that every
+//           global access of a wave is one contiguous 256/512/1024-byte row).
+#pragma once
+#include <stdint.h>
+
+namespace qe {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+enum : u32 { FLAG_HAS_N = 1u, FLAG_NONCANON = 2u };
+enum : u32 { OP_M = 0, OP_X = 1, OP_I = 2, OP_D = 3 };
+
+struct PairView {
+    const uint8_t* asc_p;  const int64_t* asc_p_off;  const int32_t* p_len;
+    const uint8_t* asc_t;  const int64_t* asc_t_off;  const int32_t* t_len;
+    const u64* pl_p;  const int64_t* pl_p_off;     // forward planes, word offsets
+    const u64* pl_t;  const int64_t* pl_t_off;
+    const u32* flags;
+};
+
+struct TaskView {
+    int32_t ntasks;
+    const int32_t* pair;     // -1 = empty slot
+    const int32_t* p0;  const int32_t* m;
+    const int32_t* t0;  const int32_t* n;
+    const int32_t* cutoff;   // cutoff_in of banded_matrix_allocate
+    const int32_t* tfin;     // text_finish_pos (score-only passes)
+};
+
+// pack: ASCII -> planes (+ flags).  reverse != 0 packs the reversed string.
+struct PackArgs {
+    int32_t nseq;
+    const uint8_t* asc;  const int64_t* asc_off;  const int32_t* len;
+    u64* planes;  const int64_t* pl_off;
+    u32* flags;          // OR-ed into (may be null)
+    int32_t reverse;
+};
+
+// BandEd, score-only or fill (bpm_banded.c:791-964 / 199-316)
+struct BandedArgs {
+    PairView P;
+    TaskView T;
+    // per-group workspace: Pv[(ns+1)][64] u64 | Mv[(ns+1)][64] u64 | S[nrows][64] i32 | cf[nch][64] i16 | cl[nch][64] i16
+    uint8_t* ws;  const int64_t* g_ws_off;  const int32_t* g_nslots;  const int32_t* g_nrows;  const int32_t* g_nch;
+    // fill only: {Pv,Mv} of every column, [(col * g_nslots + slot)][64] x 16 B
+    uint4* mat;  const int64_t* g_mat_off;
+    // outputs per task
+    int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;
+};
+
+// BandEd traceback over a filled matrix (bpm_banded.c:967-1036) -> RLE runs, back to front
+struct TraceArgs {
+    PairView P;
+    TaskView T;
+    const uint8_t* ws;  const int64_t* g_ws_off;  const int32_t* g_nslots;  const int32_t* g_nrows;  const int32_t* g_nch;
+    const uint4* mat;  const int64_t* g_mat_off;
+    u32* runs;  const int64_t* g_runs_off;  const int32_t* g_runs_cap;   // [idx][64] u32 = len << 2 | op
+    int32_t* o_nruns;  int32_t* o_nops;  int32_t* o_edits;  u32* o_steps;
+};
+
+// WindowEd chain (bpm_windowed.c:563-628)
+struct WindowArgs {
+    PairView P;
+    TaskView T;
+    int32_t W, O, hew_threshold, score_only, sse, reversed;
+    // per-group workspace: Pv[W][64] u64 | Mv[W][64] u64 ; history {Pv,Mv}[(64W+3)*W][64] x 16 B
+    uint8_t* ws;  const int64_t* g_ws_off;
+    u32* runs;  const int64_t* g_runs_off;  const int32_t* g_runs_cap;
+    int32_t* o_score;  int32_t* o_hew;  int32_t* o_nruns;  int32_t* o_nops;  int32_t* o_edits;  u32* o_steps;
+};
+
+// RLE runs -> "%d%c" strings (cigar.c:453-488)
+struct FormatArgs {
+    int32_t ntasks;
+    const int32_t* pair;
+    const u32* runs;  const int64_t* g_runs_off;
+    const int32_t* nruns;
+    int32_t* o_len;          // pass 1: string length (without terminator)
+    const int64_t* str_off;  // pass 2: where each string starts in pool
+    char* pool;
+};
+
+}  // namespace qe

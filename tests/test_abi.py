@@ -1,0 +1,96 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every
+symbol include/*.h declares, struct layouts match the reference's,
+and the calls that need no GPU behave like the reference's."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from quicked_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(build.HIP_LIB):
+        build.build_hip()
+    return capi.lib()
+
+
+def declared_functions():
+    names = set()
+    for h in ("quicked.h", "quicked_batch.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(quicked_[a-z_]+)\s*\(", src))
+    return names
+
+
+def test_exports_match_headers(lib):
+    decl = declared_functions()
+    assert decl == set(capi.EXPORTS)
+    for name in decl:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match_reference():
+    # x86-64 SysV layout probed on the reference
+    assert C.sizeof(capi.Params) == 48
+    assert [getattr(capi.Params, f).offset for f in ("algo", "bandwidth", "window_size", "overlap_size", "hew_threshold",
+                                                      "hew_percentage", "only_score", "force_scalar", "external_timer",
+                                                      "external_allocator")] == [0, 4, 8, 12, 16, 24, 32, 33, 34, 40]
+    assert C.sizeof(capi.Aligner) == 72
+    assert [getattr(capi.Aligner, f).offset for f in ("params", "mm_allocator", "cigar", "score", "timer",
+                                                       "timer_windowed_s", "timer_windowed_l", "timer_banded",
+                                                       "timer_align")] == [0, 8, 16, 24, 32, 40, 48, 56, 64]
+    assert C.sizeof(capi.ProfilerTimer) == 88
+    assert C.sizeof(capi.MMAllocator) == 56
+
+
+def test_header_compiles_as_c_and_cpp(tmp_path):
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "quicked.h"\n#include "quicked_batch.h"\n'
+                   '_Static_assert(sizeof(quicked_params_t) == 48, "params");\n'
+                   '_Static_assert(sizeof(quicked_aligner_t) == 72, "aligner");\n'
+                   '_Static_assert(sizeof(profiler_timer_t) == 88, "timer");\n'
+                   '_Static_assert(sizeof(mm_allocator_t) == 56, "alloc");\nint main(void){return QUICKED_WIP-1;}\n')
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                    "-o", str(tmp_path / "t.o")], check=True)
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text('#include "quicked.h"\n#include "quicked_batch.h"\nint main(){return 0;}\n')
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(cpp),
+                    "-o", str(tmp_path / "t2.o")], check=True)
+
+
+def test_default_params_and_messages(lib):
+    p = lib.quicked_default_params()      # quicked.c:308-321
+    assert (p.algo, p.bandwidth, p.window_size, p.overlap_size) == (0, 15, 9, 1)
+    assert list(p.hew_threshold) == [40, 40] and list(p.hew_percentage) == [15, 15]
+    assert (p.only_score, p.force_scalar, p.external_timer) == (False, False, False)
+    assert not p.external_allocator
+    assert lib.quicked_status_msg(capi.QUICKED_EMPTY_SEQUENCE) == b"ERROR: Tried to align an empty sequence\n"
+    assert lib.quicked_status_msg(capi.QUICKED_WIP) == b"QuickEd finished without errors.\n"
+    assert lib.quicked_check_error(-4) and not lib.quicked_check_error(1) and not lib.quicked_check_error(0)
+
+
+def test_new_free_and_early_errors_need_no_gpu(lib):
+    p = lib.quicked_default_params()
+    a = capi.Aligner()
+    assert lib.quicked_new(C.byref(a), C.byref(p)) == capi.QUICKED_WIP          # quicked.c:351
+    assert a.score == -1 and a.cigar is None and bool(a.timer) and bool(a.mm_allocator)
+    assert C.addressof(a.params.contents) == C.addressof(p)                       # caller's object, not a copy
+    assert lib.quicked_align(C.byref(a), b"", 0, b"", 0) == capi.QUICKED_EMPTY_SEQUENCE   # quicked.c:411-414
+    assert lib.quicked_align(C.byref(a), b"ACGT", 4, b"", 0) == capi.QUICKED_EMPTY_SEQUENCE
+    p.algo = 7
+    assert lib.quicked_align(C.byref(a), b"ACGT", 4, b"ACGT", 4) == capi.QUICKED_UNKNOWN_ALGO  # quicked.c:432-433
+    assert lib.quicked_free(C.byref(a)) == capi.QUICKED_WIP                       # quicked.c:377
+    # external timers: the five pointers are the caller's to patch (benchmark_edit.c:61-65)
+    p = lib.quicked_default_params()
+    p.external_timer = True
+    a = capi.Aligner()
+    assert lib.quicked_new(C.byref(a), C.byref(p)) == capi.QUICKED_WIP
+    assert not a.timer and not a.timer_align
+    assert lib.quicked_free(C.byref(a)) == capi.QUICKED_WIP

@@ -1,0 +1,159 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the
+oracle on the same seeded inputs and against the golden vectors captured from
+the compiled reference.  Bit-exact: scores, statuses and RLE CIGAR strings."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from quicked_amd import capi, datagen
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(s):
+    return hashlib.sha256(s.encode()).hexdigest() if s is not None else None
+
+
+def gpu_batch(batch, **kw):
+    """-> (scores, statuses, cigars or None, counters) through quicked_batch_*"""
+    rb = capi.ResidentBatch(batch)
+    p = capi.make_params(**kw)
+    st = rb.run(p, sync=True)
+    assert st >= 0 or st == capi.QUICKED_EMPTY_SEQUENCE, st
+    scores, status = rb.scores()
+    cig = None if kw.get("only_score") else rb.cigars()
+    cnt = rb.counters()
+    rb.close()
+    return scores, status, cig, cnt
+
+
+def test_kats_single_pair_abi(golden):
+    """every KAT of the reference's tests/examples through quicked_new/align/free"""
+    import ctypes as C
+    lib = capi.lib()
+    for k in golden["kats"]:
+        p = capi.make_params(**k["params"])
+        a = capi.Aligner()
+        assert lib.quicked_new(C.byref(a), C.byref(p)) == capi.QUICKED_WIP
+        pat, txt = k["pattern"].encode(), k["text"].encode()
+        st = lib.quicked_align(C.byref(a), pat, len(pat), txt, len(txt))
+        assert st == k["status"], k
+        if st >= 0:
+            assert a.score == k["score"], k
+            assert (a.cigar.decode() if a.cigar else None) == k["cigar"], k
+        lib.quicked_free(C.byref(a))
+
+
+def test_binding_mirror_example():
+    """examples/bindings/basic.py of the reference: ACGT vs ACTT -> 1, 2M1X1M"""
+    al = capi.QuickedAligner()
+    al.align("ACGT", "ACTT")
+    assert al.getScore() == 1 and al.getCigar() == "2M1X1M"
+    al.setAlgorithm(capi.BANDED)
+    al.setOnlyScore(True)
+    al.align("ACGT", "ACTT")
+    assert al.getScore() == 1
+    with pytest.raises(capi.QuickedException):
+        al.align("", "")
+
+
+DATASETS = ["cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len50", "len63", "len64", "len65", "len128",
+            "len130", "len1024", "err35_2kb"]
+
+
+@pytest.mark.parametrize("name", DATASETS)
+def test_golden_datasets(golden, name):
+    entry = golden["datasets"][name]
+    batch = datagen.generate(**entry["gen"])
+    pairs = list(batch.pairs())
+    for label, run in entry["runs"].items():
+        scores, status, cig, _ = gpu_batch(batch, **run["params"])
+        assert status.tolist() == run["status"], (name, label)
+        assert scores.tolist() == run["score"], (name, label)
+        if "cigar_sha256" in run:
+            assert [sha(c) for c in cig] == run["cigar_sha256"], (name, label)
+            for (p, t), c in zip(pairs, cig):
+                assert O.cigar_is_valid(p, t, c)
+
+
+RUNS = [
+    dict(algo=2, only_score=True, bandwidth=1), dict(algo=2, only_score=True, bandwidth=4),
+    dict(algo=2, only_score=True, bandwidth=15), dict(algo=2, bandwidth=15), dict(algo=3, bandwidth=15),
+    dict(algo=1, only_score=True), dict(algo=1), dict(algo=1, only_score=True, window_size=2),
+    dict(algo=1, window_size=2), dict(algo=1, only_score=True, window_size=2, force_scalar=True),
+    dict(algo=1, window_size=2, force_scalar=True), dict(algo=1, only_score=True, window_size=4, overlap_size=2),
+    dict(algo=0), dict(algo=0, force_scalar=True), dict(algo=0, only_score=True),
+]
+
+
+@pytest.mark.parametrize("gen", [
+    dict(count=130, length=1000, error=0.05, seed=301), dict(count=70, length=10000, error=0.05, seed=302),
+    dict(count=100, length=200, error=0.15, seed=303), dict(count=100, length=70, error=0.2, seed=304),
+    dict(count=40, length=3000, error=0.3, seed=305), dict(count=70, length=1, error=0, seed=306),
+    dict(count=70, length=5, error=2, seed=307),
+])
+def test_oracle_parity_random(gen):
+    batch = datagen.generate(**gen)
+    pairs = list(batch.pairs())
+    for kw in RUNS:
+        scores, status, cig, _ = gpu_batch(batch, **kw)
+        for i, (p, t) in enumerate(pairs):
+            st, sc, cg = O.oracle_align(p, t, **kw)
+            assert status[i] == st, (gen, kw, i)
+            assert scores[i] == sc, (gen, kw, i)
+            if cig is not None:
+                assert cig[i] == cg, (gen, kw, i)
+
+
+def mixed_batch():
+    """ragged lengths, empty sequences, N / lower-case / IUPAC symbols in one batch"""
+    rng = np.random.default_rng(5)
+    base = datagen.generate(count=48, length=700, error=0.08, seed=41)
+    pairs = []
+    for i, (p, t) in enumerate(base.pairs()):
+        p, t = bytearray(p[: 20 + 14 * i]), bytearray(t[: 25 + 13 * i])
+        if i % 4 == 1:
+            for k in rng.integers(0, len(p), 3): p[k] = ord("N")
+            for k in rng.integers(0, len(t), 3): t[k] = ord("N")
+        if i % 4 == 2:
+            p = bytearray(bytes(p).lower())
+        if i % 4 == 3:
+            for k in rng.integers(0, len(t), 2): t[k] = ord("R")
+            for k in rng.integers(0, len(p), 2): p[k] = ord("n")
+        pairs.append((bytes(p), bytes(t)))
+    pairs[7] = (b"", pairs[7][1])
+    pairs[9] = (pairs[9][0], b"")
+    pairs[11] = (b"", b"")
+    return pairs
+
+
+@pytest.mark.parametrize("kw", [dict(algo=2, only_score=True), dict(algo=2), dict(algo=1, only_score=True),
+                                dict(algo=1), dict(algo=1, window_size=2), dict(algo=0), dict(algo=3)])
+def test_ragged_empty_and_non_acgt(kw):
+    pairs = mixed_batch()
+    al = capi.QuickedAligner()
+    for k, v in kw.items():
+        setattr(al._params, k, v)
+    st, out = al.alignBatch(pairs)
+    for i, (p, t) in enumerate(pairs):
+        est, esc, ecg = O.oracle_align(p, t, **kw)
+        assert out[i][0] == est, (kw, i)
+        if est >= 0:
+            assert out[i][1] == esc, (kw, i, len(p), len(t))
+            assert out[i][2] == ecg, (kw, i)
+
+
+def test_counters_match_oracle_work():
+    """block-advances / window steps / traceback steps are the SURVEY 8(d) work units"""
+    batch = datagen.generate(count=64, length=2000, error=0.05, seed=77)
+    pairs = list(batch.pairs())
+    _, _, _, cnt = gpu_batch(batch, algo=2, only_score=True, bandwidth=15)
+    exp = sum(O.oracle_align(p, t, trace=True, algo=2, only_score=True, bandwidth=15)[3]["score_block_advances"] for p, t in pairs)
+    assert cnt[0] == exp
+    _, _, _, cnt = gpu_batch(batch, algo=0)
+    tr = [O.oracle_align(p, t, trace=True, algo=0)[3] for p, t in pairs]
+    assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
+    assert cnt[2] == sum(x["window_block_steps"] for x in tr)
+    assert cnt[3] == sum(x["traceback_steps"] for x in tr)
