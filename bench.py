@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of the hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic read pairs
+whose ASCII bytes are already resident in HBM: pack -> BandEd score-only kernel
+-> scores in HBM (configs[1] of BASELINE.json: 100 k pairs of 10 kb at 5 %
+error, reference default bandwidth 15 %).  `--workload quicked` runs configs[2]
+(QuickEd bound-and-align + CIGAR) instead.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU (torch.distributed.run), each rank owns its own
+shard of pairs (weak scaling, no data-path collective); RCCL is used only for
+the final reduction of the timings and checksums.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz: 32-bit lane-ops/s
+OPS_PER_BLOCK_COLUMN = 43        # 32-bit VALU ops per 64-row block per column (ISA count)
+
+
+def cpu_baseline(batch, params_kw, budget_s=15.0):
+    """The compiled reference (oracle/_ref, kind "reference") or the oracle
+    restatement (kind "port") on the host cores, one aligner per thread over
+    disjoint pair ranges (the reference's own model, align_benchmark.c:246-284),
+    on a bounded prefix of the same workload."""
+    import concurrent.futures as cf
+    import oracle_lib as O
+    kind = "reference" if O.have_ref() else "port"
+    fn = O.ref_align if kind == "reference" else O.oracle_align
+    cores = os.cpu_count() or 1
+    pairs = []
+    # calibrate on 8 pairs, then size the sample for ~budget_s of wall time
+    probe = [(batch.pattern(i), batch.text(i)) for i in range(min(8, len(batch)))]
+    t0 = time.perf_counter()
+    res_probe = [fn(p, t, **params_kw) for p, t in probe]
+    per = (time.perf_counter() - t0) / len(probe)
+    n = int(min(len(batch), max(cores * 4, budget_s / per * cores * 0.8)))
+    pairs = [(batch.pattern(i), batch.text(i)) for i in range(n)]
+    chunks = [pairs[i::cores] for i in range(cores)]
+
+    def work(ch):
+        return [fn(p, t, **params_kw)[1] for p, t in ch]
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:       # ctypes releases the GIL inside the C call
+        out = list(ex.map(work, chunks))
+    wall = time.perf_counter() - t0
+    scores = np.zeros(n, dtype=np.int64)
+    for c, o in enumerate(out):
+        scores[c::cores] = o
+    return {"value": n / wall, "unit": "alignments/s", "cores": cores, "kind": kind,
+            "sample": f"first {n} pairs of the same workload, {cores} threads, one aligner per thread",
+            "single_thread_value": 1.0 / per}, scores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU per step")
+    ap.add_argument("--length", type=int, default=10000)
+    ap.add_argument("--error", type=float, default=0.05)
+    ap.add_argument("--bandwidth", type=int, default=15)
+    ap.add_argument("--workload", choices=["banded_score", "quicked"], default="banded_score")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0x51CED)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+
+    from quicked_amd import capi, datagen
+    capi.lib().quicked_set_device(local_rank)
+
+    # each rank owns pairs [rank * pairs, (rank + 1) * pairs) of the seeded dataset: independent work units
+    batch = datagen.generate(args.pairs, args.length, args.error, seed=args.seed, first=rank * args.pairs)
+    cells = batch.cells()
+    if args.workload == "banded_score":
+        kw = dict(algo=capi.BANDED, only_score=True, bandwidth=args.bandwidth)
+    else:
+        kw = dict(algo=capi.QUICKED, only_score=False, bandwidth=args.bandwidth)
+    params = capi.make_params(**kw)
+    rb = capi.ResidentBatch(batch)           # H2D happens here, outside the timed region
+
+    for _ in range(max(args.warmup, 0)):
+        rb.run(params, sync=True)
+    rb.kernel_time()                         # drop the warm-up launches
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        rb.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    async_ok = args.workload == "banded_score"
+    for _ in range(args.steps):
+        rb.run(params, sync=not async_ok)
+    rb.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_n = rb.kernel_time()
+
+    # one synchronous run to fetch results + work counters for the report
+    rb.run(params, sync=True)
+    scores, status = rb.scores()
+    counters = rb.counters()
+    rb.kernel_time()
+    checksum = int(scores.astype(np.int64).sum())
+
+    tot_pairs, tot_cells, max_elapsed, tot_checksum = args.pairs, cells, elapsed, checksum
+    if dist is not None:
+        t = torch.tensor([float(args.pairs), float(cells), float(checksum)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        tot_pairs, tot_cells, tot_checksum, max_elapsed = int(t[0].item()), int(t[1].item()), int(t[2].item()), e.item()
+
+    if rank == 0:
+        value = tot_pairs * args.steps / max_elapsed
+        per_launch_bytes = float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64) + 4).sum())
+        kern_s = (kern_ms / 1e3 / kern_n) if kern_n else float("nan")
+        if args.workload == "banded_score":
+            kernel, alg_bytes, work_blocks = "k_banded<false> (BandEd score-only)", per_launch_bytes, int(counters[0])
+        else:
+            # ASCII in + 16 B per stored block-column + 16 B per traceback step + ops out
+            alg_bytes = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
+            kernel, work_blocks = "k_banded<true> (BandEd fill)", int(counters[1])
+        achieved = alg_bytes / kern_s / 1e9
+        valu_tops = work_blocks * OPS_PER_BLOCK_COLUMN / kern_s / 1e12
+        line = {
+            "metric": "alignments/sec + GCUPS, 10kb x 10kb 5%-error pairs",
+            "value": value, "unit": "alignments/s", "gcups": tot_cells * args.steps / max_elapsed / 1e9,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": max_elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {args.pairs} pairs/GPU x {args.length} bp @ {args.error:g} error, "
+                                   f"bandwidth {args.bandwidth} %, seeded generator (SURVEY 8d), ASCII resident in HBM",
+                       "pairs_per_gpu": args.pairs, "length": args.length, "error": args.error,
+                       "bandwidth": args.bandwidth, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
+                         "note": "score-only BandEd is integer-VALU-bound, not HBM-bound (SURVEY 8d); see valu"},
+            "valu": {"achieved": valu_tops, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (32-bit lane ops)",
+                     "frac": valu_tops / VALU_PEAK_TOPS, "block_columns_per_launch": work_blocks,
+                     "ops_per_block_column": OPS_PER_BLOCK_COLUMN},
+            "score_checksum": tot_checksum,
+        }
+        if not args.no_cpu_baseline:
+            base, ref_scores = cpu_baseline(batch, {k: v for k, v in kw.items()})
+            n = len(ref_scores)
+            base["gpu_scores_identical_on_sample"] = bool((scores[:n].astype(np.int64) == ref_scores).all())
+            line["cpu_baseline"] = base
+        print(json.dumps(line))
+    rb.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

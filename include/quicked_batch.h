@@ -62,6 +62,11 @@ quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar_pool, 
  *   [6] pairs that went past stage 1   [7] pairs that went past stage 2 */
 quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]);
 
+/* Sum of the HIP-event durations (ms) of the dominant kernel (BandEd score /
+ * fill) over the runs of this thread since the previous call, and how many
+ * launches that was; synchronises the batch's stream. */
+quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double* ms_sum, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

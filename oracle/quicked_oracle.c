@@ -384,7 +384,7 @@ static void window_fill(win_t* w, const pat_t* pat, const char* text, int64_t tl
         block_step(w->peqw[0 * ALPHA + code], (uint64_t)1 << 63, &P, &M, PHin, 0, &ph0[t], &mh0[t]);
         w->Pv[(t + 1) * W + 0] = P;
         w->Mv[(t + 1) * W + 0] = M;
-        w->block_steps++;
+        if (t <= steps_h) w->block_steps++;         /* work unit = window cells; the extra column is not one */
     }
     if (steps_v > 1) {
         for (int64_t t = 0; t <= steps_h; ++t) {

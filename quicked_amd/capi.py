@@ -53,7 +53,8 @@ class Aligner(C.Structure):
 EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params", "quicked_new", "quicked_free",
            "quicked_align", "quicked_set_device", "quicked_align_batch", "quicked_batch_create",
            "quicked_batch_destroy", "quicked_batch_run", "quicked_batch_sync", "quicked_batch_scores",
-           "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters"]
+           "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters",
+           "quicked_batch_kernel_time"]
 
 _LIB = None
 
@@ -91,6 +92,7 @@ def lib():
     L.quicked_batch_cigar_bytes.argtypes = [C.c_void_p]
     L.quicked_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
+    L.quicked_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _LIB = L
     return L
 
@@ -214,6 +216,12 @@ class ResidentBatch:
         c = np.zeros(8, dtype=np.int64)
         self._lib.quicked_batch_counters(self._h, c.ctypes.data)
         return c
+
+    def kernel_time(self):
+        """-> (sum of dominant-kernel HIP-event ms, launches) since the last call"""
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._lib.quicked_batch_kernel_time(self._h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
 
     def close(self):
         if self._h:

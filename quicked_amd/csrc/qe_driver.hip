@@ -78,6 +78,18 @@ struct Context {
     hipStream_t stream = nullptr;
     DevicePool scratch;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // HIP-event pairs around the dominant kernel of every run since the last collection (bench.py's roofline leg)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+    size_t kev_used = 0;
+    std::pair<hipEvent_t, hipEvent_t>* kernel_events() {
+        if (kev_used >= 4096) return nullptr;
+        if (kev_used == kev.size()) {
+            hipEvent_t a, b;
+            HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+            kev.emplace_back(a, b);
+        }
+        return &kev[kev_used++];
+    }
     void init() {
         if (stream) return;
         HIP_CHECK(hipSetDevice(device));
@@ -327,7 +339,10 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
     a.ws = D.ws; a.g_ws_off = D.ws_off; a.g_nslots = D.nslots; a.g_nrows = D.nrows; a.g_nch = D.nch;
     a.mat = nullptr; a.g_mat_off = D.mat_off;
     a.o_score = O.score; a.o_first = O.first; a.o_last = O.last; a.o_posv = O.posv; a.o_adv = O.adv;
+    auto* ke = C.kernel_events();
+    if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     hipLaunchKernelGGL(k_banded<false>, dim3(L.ngroups()), dim3(64), 0, C.stream, a);
+    if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     if (d_score_out) *d_score_out = O.score;
     if (fetch && R) {
         d2h(R->score, O.score, nt, C.stream); d2h(R->adv, O.adv, nt, C.stream);
@@ -461,7 +476,10 @@ static void run_banded_align(quicked_batch& B, Context& C, const TaskList& L, St
         a.ws = D.ws; a.g_ws_off = D.ws_off; a.g_nslots = D.nslots; a.g_nrows = D.nrows; a.g_nch = D.nch;
         a.mat = D.mat; a.g_mat_off = D.mat_off;
         a.o_score = O.score; a.o_first = O.first; a.o_last = O.last; a.o_posv = O.posv; a.o_adv = O.adv;
+        auto* ke = C.kernel_events();
+        if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
         hipLaunchKernelGGL(k_banded<true>, dim3(ng), dim3(64), 0, C.stream, a);
+        if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
         TraceArgs tr;
         tr.P = a.P; tr.T = T.v;
         tr.ws = D.ws; tr.g_ws_off = D.ws_off; tr.g_nslots = D.nslots; tr.g_nrows = D.nrows; tr.g_nch = D.nch;
@@ -780,6 +798,25 @@ QE_API quicked_status_t quicked_batch_sync(quicked_batch_t* batch) {
         B->pending = false;
         return QUICKED_OK;
     }, nullptr);
+}
+
+QE_API quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double* ms_sum, int64_t* launches) {
+    struct Arg { double* ms; int64_t* n; } arg{ms_sum, launches};
+    return guard(batch, [](quicked_batch* B, void* a) {
+        Arg* x = (Arg*)a;
+        tl_device = B->device;
+        Context& C = ctx();
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        double total = 0;
+        for (size_t i = 0; i < C.kev_used; ++i) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, C.kev[i].first, C.kev[i].second));
+            total += ms;
+        }
+        *x->ms = total; *x->n = (int64_t)C.kev_used;
+        C.kev_used = 0;
+        return QUICKED_OK;
+    }, &arg);
 }
 
 QE_API quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_out, int32_t* status_out) {
