@@ -285,27 +285,19 @@ int64_t qo_banded_align(const char* pattern, int plen, const char* text, int tle
         const int64_t bh = h / W64, bhr = (h + 1) / W64;
         const int64_t ev = v - W64 * (bh - g.prolog);       /* band-relative row at column h   */
         const int64_t evr = v - W64 * (bhr - g.prolog);     /* ... at column h+1               */
+        /* one test decides both reads: block row v/64 must have been computed at column h, i.e. lie
+         * in the stored range of column h+1; otherwise P = 0, M = 0 (reference: uninitialised words) */
         uint64_t pbit = 0, mbit = 0;
-        {   /* Pv at column h+1 */
+        {
             const int64_t col = h + 1;
             const int64_t lo = cfirst[col / W64];
             const int64_t hi = (col % W64 == 0) ? clast[col / W64 - 1] : clast[col / W64];
-            if (evr >= 0) {
+            if (evr >= 0 && ev >= 0) {
                 const int64_t slot = evr / W64;
-                if (slot >= lo && slot <= hi) pbit = (Pm[col * ebb + slot] >> (evr % W64)) & 1;
-            }
-        }
-        {   /* Mv at column h */
-            const int64_t col = h;
-            int64_t lo, hi;
-            if (col == 0) { lo = 0; hi = ebb - 1; }
-            else {
-                lo = cfirst[col / W64];
-                hi = (col % W64 == 0) ? clast[col / W64 - 1] : clast[col / W64];
-            }
-            if (ev >= 0) {
-                const int64_t slot = ev / W64;
-                if (slot >= lo && slot <= hi) mbit = (Mm[col * ebb + slot] >> (ev % W64)) & 1;
+                if (slot >= lo && slot <= hi) {
+                    pbit = (Pm[col * ebb + slot] >> (evr % W64)) & 1;       /* Pv at column h+1 */
+                    mbit = (Mm[h * ebb + ev / W64] >> (ev % W64)) & 1;      /* Mv at column h   */
+                }
             }
         }
         if (pbit) { rev[n++] = 'D'; --v; }

@@ -267,7 +267,7 @@ static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs) {
         size_t bytes = (size_t)2 * (ns + 1) * 64 * 8 + (size_t)nr * 64 * 4 + (size_t)2 * nch * 64 * 2;
         B.ws_bytes += (bytes + 255) & ~(size_t)255;
         B.mat_off[g] = (int64_t)B.mat_u4;
-        if (fill) B.mat_u4 += (size_t)(nmax + 1) * ns * 64;
+        if (fill) B.mat_u4 += ((size_t)(nmax + 8) / 8 + 1) * ns * 512;     // 8-column tiles, see tile_elem()
         B.runs_off[g] = (int64_t)B.runs_u32;
         if (want_runs) B.runs_u32 += (size_t)cap * 64;
     }
@@ -394,7 +394,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
     const size_t nt = L.pair.size();
     const int ng = L.ngroups();
     // per group: Pv/Mv [W][64] u64 + history [(64W+3)*W][64] uint4
-    const size_t g_bytes = ((size_t)2 * W * 64 * 8 + (size_t)(64 * W + 3) * W * 64 * 16 + 255) & ~(size_t)255;
+    const size_t g_bytes = ((size_t)2 * W * 64 * 8 + (size_t)(8 * W + 2) * W * 512 * 16 + 255) & ~(size_t)255;
     BandLayout lay;
     lay.ws_off.resize(ng); lay.mat_off.assign(ng, 0); lay.runs_off.resize(ng);
     lay.nslots.assign(ng, W); lay.nrows.assign(ng, 0); lay.nch.assign(ng, 0); lay.runs_cap.resize(ng);

@@ -29,6 +29,16 @@ __device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
 __device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
 __device__ __forceinline__ u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
+// Stored-column layout of the fill matrix and of the window history: 8 columns of
+// one (slot, lane) are contiguous (one 128-byte line), lanes next to each other:
+//   element(col, slot, lane) = ((col >> 3) * nslots + slot) * 512 + lane * 8 + (col & 7)     [16-byte units]
+// A lane's traceback walks columns one at a time, so 7 of 8 steps stay inside a
+// line it already pulled; the fill's 8 consecutive column stores of a block
+// complete every line they touch.
+__device__ __forceinline__ int64_t tile_elem(int col, int slot, int nslots) {
+    return ((int64_t)(col >> 3) * nslots + slot) * 512 + (col & 7);
+}
+
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
@@ -63,37 +73,52 @@ __device__ __forceinline__ void block_step(u64 Eq, u64& P, u64& M, u32 PHin, u32
 // pure ACGT, exported row is bit 63.  Fully unrolled; c is a literal.
 //   a,b     pattern code planes of this block      T0,T1  text code planes of this chunk
 //   hinP/M  carry-in words (bit c = column c)      houtP/M carry-out words
-//   st      column c's {Pv,Mv} goes to st + c*stride (c < 63) / st_last (c == 63)
+//   st      element of stored column 64k (a multiple of 8) at this slot.  A stored element is
+//           {Pv AFTER the column, Mv BEFORE it}: exactly the two words one traceback step at
+//           that column reads (Pv[h+1], Mv[h]; bpm_banded.c:994-1003).  Chunk column c is stored
+//           column 64k + c + 1 = st + ((c+1) >> 3) * tstride + ((c+1) & 7); c == 63 goes to st_last
 // ---------------------------------------------------------------------------
 template <bool STORE>
 __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0, u64 T1,
                                            u64 hinP, u64 hinM, u64& houtP, u64& houtM,
                                            bool act, uint4* st, int64_t st_stride, uint4* st_last) {
     const u32 alo = lo32(a), ahi = hi32(a), blo = lo32(b), bhi = hi32(b);
-    u32 oP[2] = {0, 0}, oM[2] = {0, 0};
+    u64 oP = 0, oM = 0;
+    // 8 groups of 8 columns: the group loop stays rolled (register pressure, I-cache), the
+    // 8 columns inside are literal so every bit extract is a single v_bfe.
+#pragma unroll 1
+    for (int grp = 0; grp < 8; ++grp) {
+        const u32 t0 = (u32)(T0 >> (8 * grp)), t1 = (u32)(T1 >> (8 * grp));
+        const u32 hp = (u32)(hinP >> (8 * grp)), hm = (u32)(hinM >> (8 * grp));
+        u32 gP = 0, gM = 0;
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        const int h = c >> 5, s = c & 31;
-        const u32 t0 = h ? hi32(T0) : lo32(T0), t1 = h ? hi32(T1) : lo32(T1);
-        const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0, s, 1);    // 0 / ~0: text code bit 0
-        const u32 m1 = (u32)__builtin_amdgcn_sbfe((int)t1, s, 1);
-        const u32 elo = ~(alo ^ m0) & ~(blo ^ m1);                   // Eq: both code bits equal
-        const u32 ehi = ~(ahi ^ m0) & ~(bhi ^ m1);
-        const u32 PHin = __builtin_amdgcn_ubfe(h ? hi32(hinP) : lo32(hinP), s, 1);
-        const u32 MHin = __builtin_amdgcn_ubfe(h ? hi32(hinM) : lo32(hinM), s, 1);
-        u64 Ph, Mh;
-        block_step(mk64(elo, ehi), P, M, PHin, MHin, Ph, Mh);
-        oP[h] |= (hi32(Ph) >> 31) << s;
-        oM[h] |= (hi32(Mh) >> 31) << s;
-        if (STORE) {
-            if (act) {
-                uint4* q = (c == 63) ? st_last : st + (int64_t)c * st_stride;
-                *q = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));
+        for (int j = 0; j < 8; ++j) {
+            const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0, j, 1);    // 0 / ~0: text code bit 0
+            const u32 m1 = (u32)__builtin_amdgcn_sbfe((int)t1, j, 1);
+            const u32 elo = ~(alo ^ m0) & ~(blo ^ m1);                   // Eq: both code bits equal
+            const u32 ehi = ~(ahi ^ m0) & ~(bhi ^ m1);
+            const u32 PHin = __builtin_amdgcn_ubfe(hp, j, 1);
+            const u32 MHin = __builtin_amdgcn_ubfe(hm, j, 1);
+            u64 Ph, Mh;
+            const u64 Min = M;
+            block_step(mk64(elo, ehi), P, M, PHin, MHin, Ph, Mh);
+            gP |= (hi32(Ph) >> 31) << j;
+            gM |= (hi32(Mh) >> 31) << j;
+            if (STORE) {
+                if (act) {
+                    // chunk column c = 8 grp + j is stored column (64k) + c + 1
+                    uint4* q = st + ((j + 1) >> 3) * st_stride + ((j + 1) & 7);
+                    if (j == 7 && grp == 7) q = st_last;
+                    *q = make_uint4(lo32(P), hi32(P), lo32(Min), hi32(Min));   // {Pv after, Mv before} this column
+                }
             }
         }
+        oP |= (u64)gP << (8 * grp);
+        oM |= (u64)gM << (8 * grp);
+        if (STORE) st += st_stride;
     }
-    houtP = mk64(oP[0], oP[1]);
-    houtM = mk64(oM[0], oM[1]);
+    houtP = oP;
+    houtM = oM;
 }
 
 // ---------------------------------------------------------------------------
@@ -105,7 +130,7 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
 template <bool STORE>
 __device__ __forceinline__ void run64_general(u64& P, u64& M, u64 a, u64 b, u64 nn, u64 T0, u64 T1, u64 TN,
                                            u64 hinP, u64 hinM, u64& houtP, u64& houtM, u64& sP, u64& sM,
-                                           int lvl, int ncols, uint4* st, int64_t st_stride, uint4* st_last) {
+                                           int lvl, int ncols, bool st_on, uint4* st, int64_t st_stride, uint4* st_last) {
     u64 oP = 0, oM = 0, qP = 0, qM = 0;
     for (int c = 0; c < 64; ++c) {
         if (c < ncols) {
@@ -114,14 +139,15 @@ __device__ __forceinline__ void run64_general(u64& P, u64& M, u64 a, u64 b, u64 
             const u64 acgt = ~(a ^ m0) & ~(b ^ m1) & ~nn;
             const u64 Eq = ((TN >> c) & 1) ? nn : acgt;
             u64 Ph, Mh;
+            const u64 Min = M;
             block_step(Eq, P, M, (u32)((hinP >> c) & 1), (u32)((hinM >> c) & 1), Ph, Mh);
             oP |= (Ph >> 63) << c;
             oM |= (Mh >> 63) << c;
             qP |= ((Ph >> lvl) & 1) << c;
             qM |= ((Mh >> lvl) & 1) << c;
-            if (STORE) {
-                uint4* q = (c == 63) ? st_last : st + (int64_t)c * st_stride;
-                *q = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));
+            if (STORE && st_on) {
+                uint4* q = (c == 63) ? st_last : st + (int64_t)((c + 1) >> 3) * st_stride + ((c + 1) & 7);
+                *q = make_uint4(lo32(P), hi32(P), lo32(Min), hi32(Min));
             }
         }
     }
@@ -269,8 +295,8 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
     u64* const Pv = W.Pv + 64 + lane;        // slot s lives at Pv[s * 64]; slot -1 is addressable
     u64* const Mv = W.Mv + 64 + lane;
     int32_t* const S = W.S + lane;           // scores[] indexed by absolute block row (bpm_banded.c:180-197)
-    uint4* const mat = FILL ? A.mat + A.g_mat_off[g] + lane : nullptr;
-    const int64_t col_stride = (int64_t)gns * 64;                  // uint4 units between columns
+    uint4* const mat = FILL ? A.mat + A.g_mat_off[g] + lane * 8 : nullptr;   // tiled layout, see tile_elem()
+    const int64_t tstride = (int64_t)gns * 512;                    // uint4 units between 8-column tiles
 
     // bpm_reset_search (bpm_banded.c:180-197)
     for (int s = 0; s < gns; ++s) {
@@ -278,7 +304,7 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
             Pv[(int64_t)s * 64] = QE_ONES;
             Mv[(int64_t)s * 64] = 0;
             S[(int64_t)s * 64] = 64 * (s + 1);
-            if (FILL) mat[(int64_t)s * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+            if (FILL) mat[tile_elem(0, s, gns)] = make_uint4(~0u, ~0u, 0u, 0u);
         }
     }
     if (FILL && valid) { W.cf[lane] = (int16_t)first; W.cl[lane] = (int16_t)last; }
@@ -313,19 +339,18 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
             if (FILL) {
                 // column c of this chunk is stored as matrix column 64k + c + 1; the chunk's last
                 // column is stored under the NEXT chunk's slot numbering (bpm_banded.c:279-287)
-                st = mat + (int64_t)(64 * k + 1) * col_stride + (int64_t)i * 64;
-                st_last = mat + (int64_t)(64 * k + 64) * col_stride + (int64_t)(i - 1) * 64;
-                if (i == 0) st_last = st + 63 * col_stride;        // slot -1 does not exist; dropped row, never read
+                st = mat + tile_elem(64 * k, i, gns);
+                st_last = mat + tile_elem(64 * k + 64, i - 1, gns);
+                if (i == 0) st_last = st + 8 * tstride;            // slot -1 does not exist; dropped row, never read
             }
             u64 houtP, houtM, sP, sM;
             const bool slow = act && (ncols != 64 || hasN || lastblk);
             if (!__any(slow)) {
-                run64_fast<FILL>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, col_stride, st_last);
+                run64_fast<FILL>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, tstride, st_last);
                 sP = houtP; sM = houtM;
             } else {
                 run64_general<FILL>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
-                                    lastblk ? lvl_last : 63, act ? ncols : 0, st, col_stride,
-                                    (ncols == 64) ? st_last : st + 63 * col_stride);
+                                    lastblk ? lvl_last : 63, act ? ncols : 0, true, st, tstride, st_last);
             }
             if (act) {
                 sc += __popcll(sP) - __popcll(sM);
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
             else if (!cut_lo && pos_h < G.prolog) first--;
             Pv[(int64_t)last * 64] = QE_ONES;
             Mv[(int64_t)last * 64] = 0;
-            if (FILL) mat[(int64_t)(64 * k + 64) * col_stride + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+            if (FILL) mat[tile_elem(64 * k + 64, last, gns)] = make_uint4(~0u, ~0u, 0u, 0u);
             const int pos = last + pos_v;
             S[(int64_t)(pos + 1) * 64] = S[(int64_t)pos * 64] + 64;
             max_row_init = max(max_row_init, pos + 1);
@@ -416,13 +441,22 @@ struct RunSink {
 };
 
 // raw-byte equality of text[h] and pattern[v] (bpm_banded.c:1012): encoded
-// equality is the same thing for upper-case ACGTN input; other input compares bytes
+// equality is the same thing for upper-case ACGTN input; other input compares
+// bytes.  The three plane words of the current pattern / text block are cached
+// in registers (a path changes block every ~64 steps).
 struct EqTest {
     const u64* pp; const u64* tp; const uint8_t* ap; const uint8_t* at; bool raw;
     int rp = -1, rt = -1;     // >= 0: the planes hold the reversed strings, ASCII index = r - i
-    __device__ __forceinline__ bool eq(int v, int h) const {
+    int pblk = -1, tblk = -1;
+    u64 pa = 0, pb = 0, pn = 0, ta = 0, tb = 0, tn = 0;
+    __device__ __forceinline__ bool eq(int v, int h) {
         if (raw) return ap[rp >= 0 ? rp - v : v] == at[rt >= 0 ? rt - h : h];
-        return plane_code(pp, v) == plane_code(tp, h);
+        if ((v >> 6) != pblk) { pblk = v >> 6; const u64* q = pp + 3 * (int64_t)pblk; pa = q[0]; pb = q[1]; pn = q[2]; }
+        if ((h >> 6) != tblk) { tblk = h >> 6; const u64* q = tp + 3 * (int64_t)tblk; ta = q[0]; tb = q[1]; tn = q[2]; }
+        const int sv = v & 63, sh = h & 63;
+        const u32 cp = (u32)((pn >> sv) & 1) * 4u | (u32)((pa >> sv) & 1) | ((u32)((pb >> sv) & 1) << 1);
+        const u32 ct = (u32)((tn >> sh) & 1) * 4u | (u32)((ta >> sh) & 1) | ((u32)((tb >> sh) & 1) << 1);
+        return (cp >= 4 && ct >= 4) || cp == ct;
     }
 };
 
@@ -441,8 +475,7 @@ __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
     const GroupWs W = group_ws(const_cast<uint8_t*>(A.ws), A.g_ws_off[g], gns, A.g_nrows[g], A.g_nch[g]);
     const int16_t* cf = W.cf + lane;
     const int16_t* cl = W.cl + lane;
-    const uint4* mat = A.mat + A.g_mat_off[g] + lane;
-    const int64_t col_stride = (int64_t)gns * 64;
+    const uint4* mat = A.mat + A.g_mat_off[g] + lane * 8;
     EqTest E;
     E.pp = A.P.pl_p + A.P.pl_p_off[pair] ; E.tp = A.P.pl_t + A.P.pl_t_off[pair];
     E.ap = A.P.asc_p + A.P.asc_p_off[pair]; E.at = A.P.asc_t + A.P.asc_t_off[pair];
@@ -451,37 +484,46 @@ __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
     R.init(A.runs + A.g_runs_off[g] + lane, A.g_runs_cap[g]);
     int h = n - 1, v = m - 1;
     u32 steps = 0;
+    // stored slot range of column h + 1: chunk K = h >> 6 needs cf[K], cf[K+1], cl[K]
+    int K = -2, cf_a = 0, cf_b = 0, cl_b = 0;
+    constexpr int LOOK = 8;       // the path is mostly diagonal: fetch the next LOOK diagonal cells at once
     while (v >= 0 && h >= 0) {
-        const int bh = h >> 6, bhr = (h + 1) >> 6;
-        const int ev = v - 64 * (bh - G.prolog), evr = v - 64 * (bhr - G.prolog);
-        u32 pbit = 0, mbit = 0;
-        {   // Pv at column h + 1
-            const int col = h + 1, ck = col >> 6;
-            const int lo = cf[(int64_t)ck * 64];
-            const int hi = (col & 63) ? cl[(int64_t)ck * 64] : cl[(int64_t)(ck - 1) * 64];
-            const int slot = evr >> 6;
-            if (evr >= 0 && slot >= lo && slot <= hi) {
-                const uint4 q = mat[(int64_t)col * col_stride + (int64_t)slot * 64];
-                const int bit = evr & 63;
-                pbit = ((bit < 32 ? q.x : q.y) >> (bit & 31)) & 1;
+        uint4 Q[LOOK];
+#pragma unroll
+        for (int j = 0; j < LOOK; ++j) {
+            const int hj = max(h - j, 0), vj = max(v - j, 0);
+            const int evr = vj - 64 * (((hj + 1) >> 6) - G.prolog);
+            const int sp = min(max(evr >> 6, 0), gns - 1);
+            Q[j] = mat[tile_elem(hj + 1, sp, gns)];
+        }
+        bool go = true;
+#pragma unroll
+        for (int j = 0; j < LOOK; ++j) {
+            if (go && v >= 0 && h >= 0) {
+                if ((h >> 6) != K) {
+                    K = h >> 6;
+                    cf_a = cf[(int64_t)(K + 1) * 64]; cf_b = cf[(int64_t)K * 64];
+                    cl_b = cl[(int64_t)K * 64];
+                }
+                // one stored element answers both tests: {Pv[h+1], Mv[h]} of block row v / 64; rows the
+                // fill did not compute at column h read as P = 0, M = 0
+                const int evr = v - 64 * (((h + 1) >> 6) - G.prolog);
+                u32 pbit = 0, mbit = 0;
+                {
+                    const bool edge = ((h + 1) & 63) == 0;
+                    const int lo = edge ? cf_a : cf_b, hi = cl_b, slot = evr >> 6;
+                    if (evr >= 0 && slot >= lo && slot <= hi) {
+                        const int bit = v & 63;
+                        pbit = (u32)((mk64(Q[j].x, Q[j].y) >> bit) & 1);
+                        mbit = (u32)((mk64(Q[j].z, Q[j].w) >> bit) & 1);
+                    }
+                }
+                if (pbit) { R.push(OP_D); --v; go = false; }
+                else if (mbit) { R.push(OP_I); --h; go = false; }
+                else { R.push(E.eq(p0 + v, t0 + h) ? OP_M : OP_X); --h; --v; }
+                ++steps;
             }
         }
-        if (!pbit) {   // Mv at column h
-            const int col = h, ck = col >> 6;
-            int lo, hi;
-            if (col == 0) { lo = 0; hi = G.ebb - 1; }
-            else { lo = cf[(int64_t)ck * 64]; hi = (col & 63) ? cl[(int64_t)ck * 64] : cl[(int64_t)(ck - 1) * 64]; }
-            const int slot = ev >> 6;
-            if (ev >= 0 && slot >= lo && slot <= hi) {
-                const uint4 q = mat[(int64_t)col * col_stride + (int64_t)slot * 64];
-                const int bit = ev & 63;
-                mbit = ((bit < 32 ? q.z : q.w) >> (bit & 31)) & 1;
-            }
-        }
-        if (pbit) { R.push(OP_D); --v; }
-        else if (mbit) { R.push(OP_I); --h; }
-        else { R.push(E.eq(p0 + v, t0 + h) ? OP_M : OP_X); --h; --v; }
-        ++steps;
     }
     R.push_n(OP_I, h + 1);
     R.push_n(OP_D, v + 1);
@@ -520,8 +562,8 @@ __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
     uint8_t* wsb = A.ws + A.g_ws_off[g];
     u64* const Pv = (u64*)wsb + lane;                               // [W][64]
     u64* const Mv = (u64*)wsb + (int64_t)W * 64 + lane;
-    uint4* const hist = (uint4*)(wsb + (int64_t)2 * W * 64 * 8) + lane;   // [(col * W + blk)][64]
-    const int64_t hcol = (int64_t)W * 64;                           // uint4 units between history columns
+    uint4* const hist = (uint4*)(wsb + (int64_t)2 * W * 64 * 8) + lane * 8;   // tiled like the fill matrix, nslots = W
+    const int64_t tstride = (int64_t)W * 512;
     RunSink R;
     R.init(A.score_only ? nullptr : A.runs + A.g_runs_off[g] + lane, A.score_only ? 0 : A.g_runs_cap[g]);
     int pos_v = m - 1, pos_h = n - 1;
@@ -542,9 +584,13 @@ __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
                 const u64 pinit = (h0 == 0) ? QE_ONES : 0;
                 Pv[(int64_t)i * 64] = pinit;
                 Mv[(int64_t)i * 64] = 0;
-                hist[(int64_t)i * 64] = make_uint4(lo32(pinit), hi32(pinit), 0u, 0u);
+                hist[tile_elem(0, i, W)] = make_uint4(lo32(pinit), hi32(pinit), 0u, 0u);
             }
         }
+        // the in-window traceback only visits rows >= v_ov and columns >= h_ov (448-561):
+        // store the history of exactly those blocks / 64-column chunks
+        const int blk_min = (max(v_fi - 64 * (W - O) + 1, 0) - v0) >> 6;
+        const int col_min = max(h_fi - 64 * (W - O) + 1, 0) - h0 + 1;
         const int nchunk = wave_max((ncols_total + 63) >> 6);
         const int nblk = wave_max(steps_v);
         for (int j = 0; j < nchunk; ++j) {
@@ -562,14 +608,15 @@ __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
                     M = Mv[(int64_t)i * 64];
                     load_planes(pp, p0 + v0 + 64 * i, a, b, nn);    // bit-unaligned window rows (237-244)
                 }
-                uint4* st = hist + (int64_t)(64 * j + 1) * hcol + (int64_t)i * 64;
+                uint4* st = hist + tile_elem(64 * j, i, W);
                 u64 houtP, houtM, sP, sM;
                 const bool slow = act && (ncols != 64 || hasN);
+                const bool keep = act && i >= blk_min && 64 * j + 64 >= col_min;
                 if (!__any(slow)) {
-                    run64_fast<true>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, hcol, st + 63 * hcol);
+                    run64_fast<true>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, keep, st, tstride, st + 8 * tstride);
                 } else {
                     run64_general<true>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
-                                        63, act ? ncols : 0, st, hcol, st + 63 * hcol);
+                                        63, act ? ncols : 0, keep, st, tstride, st + 8 * tstride);
                 }
                 if (act) { Pv[(int64_t)i * 64] = P; Mv[(int64_t)i * 64] = M; steps += (u32)ncols; }
                 hinP = houtP; hinM = houtM;
@@ -586,12 +633,12 @@ __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
             block_step(Eq, P, M, 1u, 0u, Ph, Mh);                   // column steps_h + 1 is even: PHin = 1
             const u32 cP = (u32)(Ph >> 63), cM = (u32)(Mh >> 63);
             load_planes(pp, p0 + v0 + 64, a, b, nn);
-            const uint4 q = hist[(int64_t)steps_h * hcol + 64];
-            P = mk64(q.x, q.y); M = mk64(q.z, q.w);
+            const uint4 q = hist[tile_elem(steps_h, 1, W)], q1 = hist[tile_elem(steps_h + 1, 1, W)];
+            P = mk64(q.x, q.y); M = mk64(q1.z, q1.w);            // state before column steps_h: {Pv after the previous, Mv before this}
             const int tl = plane_code(tp, t0 + h_fi);
             Eq = (tl == 4) ? nn : (~(a ^ ((u64)0 - (u64)(tl & 1))) & ~(b ^ ((u64)0 - (u64)((tl >> 1) & 1))) & ~nn);
             block_step(Eq, P, M, cP, cM, Ph, Mh);
-            hist[(int64_t)(steps_h + 1) * hcol + 64] = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));
+            hist[tile_elem(steps_h + 1, 1, W)] = make_uint4(lo32(P), hi32(P), q1.z, q1.w);
         }
         // in-window traceback (bpm_windowed.c:448-561)
         if (on) {
@@ -599,24 +646,33 @@ __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
             const int h_min = max(pos_h - 64 * W + 1, 0), h_ov = max(pos_h - 64 * (W - O) + 1, 0);
             const int v_min = max(pos_v - 64 * W + 1, 0), v_ov = max(pos_v - 64 * (W - O) + 1, 0);
             int wscore = 0;
+            constexpr int LOOK = 8;      // mostly-diagonal path: fetch the next LOOK diagonal cells at once
             while (v >= v_ov && h >= h_ov) {
-                const int blk = ((v - v_min) >> 6) & 0xff;
-                const int bit = (v - v_min) & 63;                   // A.7(1)
-                const int64_t idx = (int64_t)(h - h_min + 1) * hcol + (int64_t)blk * 64;
-                const uint4 qp = hist[idx];
-                const uint4 qm = hist[idx - hcol];
-                const u32 pb = ((bit < 32 ? qp.x : qp.y) >> (bit & 31)) & 1;
-                const u32 mb = ((bit < 32 ? qm.z : qm.w) >> (bit & 31)) & 1;
-                const bool eq = E.eq(p0 + v, t0 + h);
-                if (A.score_only) {                                 // D -> I -> match -> X (527-549)
-                    if (pb) { ++wscore; --v; }
-                    else if (mb) { ++wscore; --h; }
-                    else { wscore += eq ? 0 : 1; --h; --v; }
-                } else {                                            // match -> D -> I -> X (476-495)
-                    if (eq) { R.push(OP_M); --h; --v; }
-                    else if (pb) { R.push(OP_D); --v; }
-                    else if (mb) { R.push(OP_I); --h; }
-                    else { R.push(OP_X); --h; --v; }
+                uint4 Q[LOOK];
+#pragma unroll
+                for (int j = 0; j < LOOK; ++j) {
+                    const int hj = max(h - j, h_min), vj = max(v - j, v_min);
+                    Q[j] = hist[tile_elem(hj - h_min + 1, ((vj - v_min) >> 6) & 0xff, W)];
+                }
+                bool go = true;
+#pragma unroll
+                for (int j = 0; j < LOOK; ++j) {
+                    if (go && v >= v_ov && h >= h_ov) {
+                        const int bit = (v - v_min) & 63;                   // A.7(1)
+                        const u32 pb = (u32)((mk64(Q[j].x, Q[j].y) >> bit) & 1);
+                        const u32 mb = (u32)((mk64(Q[j].z, Q[j].w) >> bit) & 1);
+                        const bool eq = E.eq(p0 + v, t0 + h);
+                        if (A.score_only) {                                 // D -> I -> match -> X (527-549)
+                            if (pb) { ++wscore; --v; go = false; }
+                            else if (mb) { ++wscore; --h; go = false; }
+                            else { wscore += eq ? 0 : 1; --h; --v; }
+                        } else {                                            // match -> D -> I -> X (476-495)
+                            if (eq) { R.push(OP_M); --h; --v; }
+                            else if (pb) { R.push(OP_D); --v; go = false; }
+                            else if (mb) { R.push(OP_I); --h; go = false; }
+                            else { R.push(OP_X); --h; --v; }
+                        }
+                    }
                 }
             }
             if (A.score_only) {
