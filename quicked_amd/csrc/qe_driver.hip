@@ -539,7 +539,15 @@ static void scatter_scores(quicked_batch& B, const TaskList& L, const std::vecto
 // ---------------------------------------------------------------------------
 // The batch entry point: dispatch on params->algo (quicked_align, quicked.c:405-437)
 // ---------------------------------------------------------------------------
+static double now_ms() {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static bool trace_on() { static int v = -1; if (v < 0) v = getenv("QE_TRACE") ? 1 : 0; return v == 1; }
+#define QE_TRACE_POINT(name) do { if (trace_on()) { double t__ = now_ms(); fprintf(stderr, "[qe] %-22s +%.3f ms\n", name, t__ - tr_last); tr_last = t__; } } while (0)
+
 static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
+    double tr_last = now_ms();
     tl_device = B.device;
     Context& C = ctx();
     C.scratch.reset();
@@ -562,7 +570,9 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const size_t matrix_budget = std::max<size_t>((free_b + C.scratch.cap) / 10 * 7, (size_t)1 << 28);
     quicked_status_t ret = QUICKED_WIP;
+    QE_TRACE_POINT("setup+pack launch");
     TaskList L = all_pairs(B, p);
+    QE_TRACE_POINT("task list");
     if (L.pair.empty()) { HIP_CHECK(hipStreamSynchronize(C.stream)); return QUICKED_EMPTY_SEQUENCE; }
     StageResult R;
 
@@ -595,6 +605,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0],
                          true, sse, &S1, true, false, nullptr);
             qe_timer_stop(tl_timers.windowed_s);
+            QE_TRACE_POINT("stage 1 windowed");
             B.counters[2] += (int64_t)sum_u32(S1.steps);
             bound = S1.score;
             // stage 2 for the pairs with too many high-error windows (quicked.c:201-202)
@@ -656,6 +667,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
                 }
             }
         }
+        QE_TRACE_POINT("stage 2/3 decisions");
         // align step: bpm_compute_matrix_hirschberg with the bound (quicked.c:283-294) -- leaves only here
         TaskList LA;
         bool need_split = false;
@@ -673,12 +685,16 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNIMPLEMENTED);
             return QUICKED_UNIMPLEMENTED;
         }
+        QE_TRACE_POINT("align task list");
         qe_timer_start(tl_timers.align);
-        run_banded_align(B, C, LA, &R, true, want_cigar, &B.d_score, matrix_budget);
+        run_banded_align(B, C, LA, &R, fetch, want_cigar, &B.d_score, matrix_budget);
         qe_timer_stop(tl_timers.align);
-        scatter_scores(B, LA, R.score, p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK);
-        B.counters[1] += (int64_t)sum_u32(R.adv); B.counters[3] += (int64_t)sum_u32(R.steps);
-        for (int32_t x : R.nops) B.counters[4] += x;
+        QE_TRACE_POINT("align launch(+fetch)");
+        if (fetch) {
+            scatter_scores(B, LA, R.score, p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK);
+            B.counters[1] += (int64_t)sum_u32(R.adv); B.counters[3] += (int64_t)sum_u32(R.steps);
+            for (int32_t x : R.nops) B.counters[4] += x;
+        }
         ret = (p.algo == QUICKED) ? QUICKED_WIP : QUICKED_OK;
         break;
     }
