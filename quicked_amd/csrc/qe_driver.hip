@@ -45,26 +45,55 @@ struct HipError { hipError_t e; const char* what; int line; };
 // malloc, no per-pair hipMalloc.
 // ---------------------------------------------------------------------------
 struct DevicePool {
-    uint8_t* base = nullptr;
-    size_t cap = 0, top = 0;
-    void reserve(size_t bytes) {
-        if (bytes <= cap) return;
-        if (base) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(base)); base = nullptr; cap = 0; }
-        const size_t want = bytes + bytes / 8 + (1u << 20);
-        HIP_CHECK(hipMalloc((void**)&base, want));
-        cap = want;
+    // Chunks keep every pointer handed out during a run valid: when a run needs more than
+    // the arena holds, another chunk is hipMalloc'ed; reset() (start of the next run) folds
+    // the chunks into one arena of the combined size, so steady-state runs never allocate.
+    struct Chunk { uint8_t* base; size_t cap; };
+    std::vector<Chunk> chunks;
+    size_t cur = 0, top = 0, cap = 0;            // cap = total bytes over all chunks
+    void add_chunk(size_t bytes) {
+        Chunk c; c.cap = bytes; c.base = nullptr;
+        HIP_CHECK(hipMalloc((void**)&c.base, bytes));
+        chunks.push_back(c);
+        cap += bytes;
     }
-    void reset() { top = 0; }
-    size_t mark() const { return top; }
-    void release(size_t m) { top = m; }
+    void reset() {
+        if (chunks.size() > 1) {
+            HIP_CHECK(hipDeviceSynchronize());
+            const size_t total = cap;
+            for (auto& c : chunks) HIP_CHECK(hipFree(c.base));
+            chunks.clear(); cap = 0;
+            add_chunk(total);
+        }
+        cur = 0; top = 0;
+    }
+    struct Mark { size_t cur, top; };
+    Mark mark() const { return Mark{cur, top}; }
+    void release(Mark m) { cur = m.cur; top = m.top; }
     template <typename T> T* take(size_t count) {
         const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
-        if (top + bytes > cap) throw HipError{hipErrorOutOfMemory, "device pool exhausted", __LINE__};
-        T* p = (T*)(base + top);
+        if (chunks.empty()) add_chunk(std::max(bytes, (size_t)1 << 26));
+        while (chunks[cur].cap - top < bytes) {
+            if (cur + 1 == chunks.size())
+                add_chunk(std::max(bytes + ((size_t)1 << 20), std::min(std::max(cap / 4, (size_t)1 << 26), (size_t)1 << 32)));
+            ++cur; top = 0;
+        }
+        T* p = (T*)(chunks[cur].base + top);
         top += bytes;
         return p;
     }
-    ~DevicePool() { if (base) (void)hipFree(base); }
+    size_t used_hint() const { return cap; }
+    ~DevicePool() { for (auto& c : chunks) if (c.base) (void)hipFree(c.base); }
+};
+
+// carves a fixed arena (a batch's persistent buffers)
+struct ArenaCarver {
+    uint8_t* base; size_t top;
+    template <typename T> T* take(size_t count) {
+        T* p = (T*)(base + top);
+        top += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
 };
 
 // sizes a pool request before carving it (two-pass: plan, reserve, carve)
@@ -324,188 +353,356 @@ struct StageResult {
 
 static uint64_t sum_u32(const std::vector<u32>& v) { uint64_t s = 0; for (u32 x : v) s += x; return s; }
 
-// BandEd score-only over a task list (bpm_banded.c:791-964)
-static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
-                             bool fetch, int32_t** d_score_out) {
-    const size_t nt = L.pair.size();
+// BandEd score-only over a task list (bpm_banded.c:791-964); the launch's device state stays
+// addressable (Hirschberg reads the stopped bands)
+struct ScoreLaunch { DevTasks T; DevLayout D; TaskOut O; size_t nt = 0; };
+
+static BandState band_state(const ScoreLaunch& S) {
+    BandState b;
+    b.ws = S.D.ws; b.g_ws_off = S.D.ws_off; b.g_nslots = S.D.nslots; b.g_nrows = S.D.nrows; b.g_nch = S.D.nch;
+    b.first = S.O.first; b.last = S.O.last; b.posv = S.O.posv; b.maxrow = S.O.len;   // O.len doubles as maxrow here
+    return b;
+}
+
+static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, bool timed) {
+    ScoreLaunch S;
+    S.nt = L.pair.size();
     const BandLayout lay = band_layout(L, false, false);
-    PoolPlan P; plan_tasks(P, nt); plan_layout(P, lay); plan_out(P, nt);
-    C.scratch.reserve(C.scratch.top + P.bytes);
-    const DevTasks T = upload_tasks(L, C);
-    const DevLayout D = upload_layout(lay, C);
-    const TaskOut O = take_out(C, nt);
+    S.T = upload_tasks(L, C);
+    S.D = upload_layout(lay, C);
+    S.O = take_out(C, S.nt);
     BandedArgs a;
-    a.P = pair_view(B, reversed); a.T = T.v;
-    a.ws = D.ws; a.g_ws_off = D.ws_off; a.g_nslots = D.nslots; a.g_nrows = D.nrows; a.g_nch = D.nch;
-    a.mat = nullptr; a.g_mat_off = D.mat_off;
-    a.o_score = O.score; a.o_first = O.first; a.o_last = O.last; a.o_posv = O.posv; a.o_adv = O.adv;
-    auto* ke = C.kernel_events();
+    a.P = pair_view(B, reversed); a.T = S.T.v;
+    a.ws = S.D.ws; a.g_ws_off = S.D.ws_off; a.g_nslots = S.D.nslots; a.g_nrows = S.D.nrows; a.g_nch = S.D.nch;
+    a.mat = nullptr; a.g_mat_off = S.D.mat_off;
+    a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
+    a.o_maxrow = S.O.len;
+    auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     hipLaunchKernelGGL(k_banded<false>, dim3(L.ngroups()), dim3(64), 0, C.stream, a);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
-    if (d_score_out) *d_score_out = O.score;
+    return S;
+}
+
+static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
+                             bool fetch, int32_t** d_score_out) {
+    const ScoreLaunch S = launch_banded_score(B, C, L, reversed, true);
+    if (d_score_out) *d_score_out = S.O.score;
     if (fetch && R) {
-        d2h(R->score, O.score, nt, C.stream); d2h(R->adv, O.adv, nt, C.stream);
-        d2h(R->first, O.first, nt, C.stream); d2h(R->last, O.last, nt, C.stream); d2h(R->posv, O.posv, nt, C.stream);
+        d2h(R->score, S.O.score, S.nt, C.stream); d2h(R->adv, S.O.adv, S.nt, C.stream);
         HIP_CHECK(hipStreamSynchronize(C.stream));
     }
 }
 
-// WindowEd over a task list (bpm_windowed.c:563-628)
-struct CigarOut {   // device-side strings of a CIGAR-producing stage
-    char* pool = nullptr; int64_t* str_off = nullptr; int64_t* total = nullptr; int32_t* len = nullptr;
-};
-
-static void format_runs(Context& C, const DevTasks& T, const DevLayout& D, const TaskOut& O, size_t nt, int ngroups,
-                        size_t pool_bytes, char* pool, int64_t* d_total) {
-    FormatArgs f;
-    f.ntasks = (int32_t)nt; f.pair = T.pair; f.runs = D.runs; f.g_runs_off = D.runs_off; f.nruns = O.nruns;
-    f.o_len = O.len; f.str_off = O.str_off; f.pool = pool;
-    hipLaunchKernelGGL(k_format<false>, dim3(ngroups), dim3(64), 0, C.stream, f);
-    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, C.stream, O.len, T.pair, O.str_off, d_total, (int)nt);
-    hipLaunchKernelGGL(k_format<true>, dim3(ngroups), dim3(64), 0, C.stream, f);
-    (void)pool_bytes;
-}
-
-// upper bound of one task's RLE string incl. terminator: every op its own run
+// upper bound of one pair's RLE string incl. terminator: every op its own run
 static size_t cigar_bound(int m, int n) { return (size_t)2 * ((size_t)m + (size_t)n) + 12; }
 
-static void fetch_cigars(quicked_batch& B, Context& C, const TaskList& L, const TaskOut& O, const char* pool, size_t nt) {
-    std::vector<int32_t> len; std::vector<int64_t> off;
-    d2h(len, O.len, nt, C.stream); d2h(off, O.str_off, nt, C.stream);
+// ---------------------------------------------------------------------------
+// CIGAR assembly: per list entry ("root" = one pair's alignment) an ordered list of segments
+// ---------------------------------------------------------------------------
+struct SegList {
+    std::vector<int64_t> off;                 // [nroots + 1]
+    std::vector<int32_t> kind, a, b;
+    std::vector<int32_t> root_pair;           // pair index of every root
+    std::vector<size_t> bound;                // string bound of every root
+};
+
+struct AlignOut {                             // device, per root
+    int32_t *len = nullptr, *edits = nullptr, *nops = nullptr;
+    int64_t *str_off = nullptr, *total = nullptr;
+    char* pool = nullptr;
+    size_t nroots = 0;
+};
+
+static AlignOut format_segments(Context& C, const SegList& SL, const u32* runs, const int64_t* g_runs_off,
+                                const int32_t* nruns, bool want_strings) {
+    AlignOut A;
+    A.nroots = SL.root_pair.size();
+    const size_t nr = A.nroots, nseg = SL.kind.size();
+    int64_t* d_off = C.scratch.take<int64_t>(nr + 1);
+    int32_t* d_kind = C.scratch.take<int32_t>(nseg + 1); int32_t* d_a = C.scratch.take<int32_t>(nseg + 1);
+    int32_t* d_b = C.scratch.take<int32_t>(nseg + 1);
+    int32_t* d_rootpair = C.scratch.take<int32_t>(nr + 1);
+    h2d(d_off, SL.off, C.stream); h2d(d_kind, SL.kind, C.stream); h2d(d_a, SL.a, C.stream); h2d(d_b, SL.b, C.stream);
+    h2d(d_rootpair, SL.root_pair, C.stream);
+    A.len = C.scratch.take<int32_t>(nr + 1); A.edits = C.scratch.take<int32_t>(nr + 1); A.nops = C.scratch.take<int32_t>(nr + 1);
+    A.str_off = C.scratch.take<int64_t>(nr + 1); A.total = C.scratch.take<int64_t>(1);
+    size_t pool_bytes = 0;
+    if (want_strings) for (size_t b : SL.bound) pool_bytes += b;
+    A.pool = C.scratch.take<char>(pool_bytes + 16);
+    SegFormatArgs f;
+    f.npairs = (int32_t)nr; f.seg_off = d_off; f.seg_kind = d_kind; f.seg_a = d_a; f.seg_b = d_b;
+    f.runs = runs; f.g_runs_off = g_runs_off; f.nruns = nruns;
+    f.o_len = A.len; f.o_edits = A.edits; f.o_nops = A.nops; f.str_off = A.str_off; f.pool = A.pool;
+    const int blocks = (int)((nr + 63) / 64);
+    hipLaunchKernelGGL(k_format_segs<false>, dim3(blocks), dim3(64), 0, C.stream, f);
+    if (want_strings) {
+        hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, C.stream, A.len, d_rootpair, A.str_off, A.total, (int)nr);
+        hipLaunchKernelGGL(k_format_segs<true>, dim3(blocks), dim3(64), 0, C.stream, f);
+    }
+    return A;
+}
+
+// D2H of a formatted stage into the batch's host-side result arrays
+static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, const AlignOut& A, bool want_strings,
+                             int32_t ok_status, const std::vector<int32_t>* root_status) {
+    std::vector<int32_t> len, edits, nops; std::vector<int64_t> off;
+    d2h(len, A.len, A.nroots, C.stream); d2h(edits, A.edits, A.nroots, C.stream); d2h(nops, A.nops, A.nroots, C.stream);
+    if (want_strings) d2h(off, A.str_off, A.nroots, C.stream);
     HIP_CHECK(hipStreamSynchronize(C.stream));
     int64_t total = 0;
-    for (size_t t = 0; t < nt; ++t) if (L.pair[t] >= 0) total = std::max<int64_t>(total, off[t] + len[t] + 1);
+    if (want_strings) for (size_t i = 0; i < A.nroots; ++i) total = std::max<int64_t>(total, off[i] + len[i] + 1);
     std::vector<char> tmp((size_t)total);
-    if (total) HIP_CHECK(hipMemcpyAsync(tmp.data(), pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
-    HIP_CHECK(hipStreamSynchronize(C.stream));
-    // append to the batch's pool, indexed by pair
-    for (size_t t = 0; t < nt; ++t) {
-        const int pr = L.pair[t];
-        if (pr < 0) continue;
-        if (len[t] <= 0) { B.cigar_off[pr] = -1; continue; }
-        B.cigar_off[pr] = (int64_t)B.cigar_pool.size();
-        B.cigar_pool.insert(B.cigar_pool.end(), tmp.begin() + off[t], tmp.begin() + off[t] + len[t] + 1);
+    if (total) {
+        HIP_CHECK(hipMemcpyAsync(tmp.data(), A.pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+    }
+    for (size_t i = 0; i < A.nroots; ++i) {
+        const int pr = SL.root_pair[i];
+        B.score[pr] = edits[i];
+        B.status[pr] = root_status ? (*root_status)[i] : ok_status;
+        B.counters[4] += nops[i];
+        if (want_strings && len[i] > 0) {
+            B.cigar_off[pr] = (int64_t)B.cigar_pool.size();
+            B.cigar_pool.insert(B.cigar_pool.end(), tmp.begin() + off[i], tmp.begin() + off[i] + len[i] + 1);
+        }
     }
 }
 
+// WindowEd over a task list (bpm_windowed.c:563-628)
 static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int W, int O_, int hew_threshold,
                          bool score_only, bool sse, StageResult* R, bool fetch, bool want_cigar, int32_t** d_score_out) {
     const size_t nt = L.pair.size();
     const int ng = L.ngroups();
-    // per group: Pv/Mv [W][64] u64 + history [(64W+3)*W][64] uint4
+    // per group: Pv/Mv [W][64] u64 + tiled history of (64W+3) columns x W blocks
     const size_t g_bytes = ((size_t)2 * W * 64 * 8 + (size_t)(8 * W + 2) * W * 512 * 16 + 255) & ~(size_t)255;
     BandLayout lay;
     lay.ws_off.resize(ng); lay.mat_off.assign(ng, 0); lay.runs_off.resize(ng);
     lay.nslots.assign(ng, W); lay.nrows.assign(ng, 0); lay.nch.assign(ng, 0); lay.runs_cap.resize(ng);
-    size_t pool_bytes = 0;
     for (int g = 0; g < ng; ++g) {
         int cap = 2;
         for (int l = 0; l < 64; ++l) {
             const size_t t = (size_t)g * 64 + l;
-            if (L.pair[t] < 0) continue;
-            cap = std::max(cap, L.m[t] + L.n[t] + 2);
-            if (!score_only) pool_bytes += cigar_bound(L.m[t], L.n[t]);
+            if (L.pair[t] >= 0) cap = std::max(cap, L.m[t] + L.n[t] + 2);
         }
         lay.ws_off[g] = (int64_t)lay.ws_bytes; lay.ws_bytes += g_bytes;
         lay.runs_cap[g] = cap; lay.runs_off[g] = (int64_t)lay.runs_u32;
         if (!score_only) lay.runs_u32 += (size_t)cap * 64;
     }
-    PoolPlan P; plan_tasks(P, nt); plan_layout(P, lay); plan_out(P, nt); P.add<char>(pool_bytes); P.add<int64_t>(1);
-    C.scratch.reserve(C.scratch.top + P.bytes);
     const DevTasks T = upload_tasks(L, C);
     const DevLayout D = upload_layout(lay, C);
     const TaskOut O = take_out(C, nt);
-    char* pool = C.scratch.take<char>(pool_bytes);
-    int64_t* d_total = C.scratch.take<int64_t>(1);
     WindowArgs a;
     a.P = pair_view(B, reversed); a.T = T.v;
     a.W = W; a.O = O_; a.hew_threshold = hew_threshold; a.score_only = score_only ? 1 : 0; a.sse = sse ? 1 : 0; a.reversed = reversed ? 1 : 0;
     a.ws = D.ws; a.g_ws_off = D.ws_off; a.runs = D.runs; a.g_runs_off = D.runs_off; a.g_runs_cap = D.runs_cap;
     a.o_score = O.score; a.o_hew = O.hew; a.o_nruns = O.nruns; a.o_nops = O.nops; a.o_edits = O.edits; a.o_steps = O.steps;
     hipLaunchKernelGGL(k_windowed, dim3(ng), dim3(64), 0, C.stream, a);
-    if (!score_only && want_cigar) format_runs(C, T, D, O, nt, ng, pool_bytes, pool, d_total);
     if (d_score_out) *d_score_out = O.score;
+    SegList SL; AlignOut AO;
+    if (!score_only) {
+        SL.off.push_back(0);
+        for (size_t t = 0; t < nt; ++t) {
+            if (L.pair[t] < 0) continue;
+            SL.kind.push_back(0); SL.a.push_back((int32_t)t); SL.b.push_back(0);
+            SL.off.push_back((int64_t)SL.kind.size());
+            SL.root_pair.push_back(L.pair[t]); SL.bound.push_back(cigar_bound(L.m[t], L.n[t]));
+        }
+        AO = format_segments(C, SL, D.runs, D.runs_off, O.nruns, want_cigar);
+        if (d_score_out) *d_score_out = AO.edits;
+    }
     if (fetch && R) {
         d2h(R->score, O.score, nt, C.stream); d2h(R->hew, O.hew, nt, C.stream); d2h(R->steps, O.steps, nt, C.stream);
         HIP_CHECK(hipStreamSynchronize(C.stream));
-        if (!score_only && want_cigar) fetch_cigars(B, C, L, O, pool, nt);
+        if (!score_only) fetch_alignments(B, C, SL, AO, want_cigar, QUICKED_WIP, nullptr);
     }
 }
 
-// BandEd fill + traceback (+ CIGAR strings) over a task list, sub-batched so the
-// stored matrices fit the pool (bpm_banded.c:199-316, 967-1036; cigar.c:453-488)
-static void run_banded_align(quicked_batch& B, Context& C, const TaskList& L, StageResult* R, bool fetch, bool want_cigar,
-                             int32_t** d_score_out, size_t matrix_budget) {
-    const size_t nt_all = L.pair.size();
-    const int ng_all = L.ngroups();
-    if (R) { R->score.assign(nt_all, -1); R->adv.assign(nt_all, 0); R->steps.assign(nt_all, 0); R->nops.assign(nt_all, 0); }
-    int g0 = 0;
-    while (g0 < ng_all) {
-        // take groups while the matrices fit
-        TaskList S;
-        size_t mat_bytes = 0;
-        int g1 = g0;
-        while (g1 < ng_all) {
-            TaskList one;
-            for (int l = 0; l < 64; ++l) {
-                const size_t t = (size_t)g1 * 64 + l;
-                one.push(L.pair[t], L.p0[t], L.m[t], L.t0[t], L.n[t], L.cutoff[t], L.tfin[t]);
-            }
-            const BandLayout bl = band_layout(one, true, false);
-            if (g1 > g0 && mat_bytes + bl.mat_u4 * 16 > matrix_budget) break;
-            mat_bytes += bl.mat_u4 * 16;
-            for (int l = 0; l < 64; ++l) S.push(one.pair[l], one.p0[l], one.m[l], one.t0[l], one.n[l], one.cutoff[l], one.tfin[l]);
-            ++g1;
+// ---------------------------------------------------------------------------
+// The align step (bpm_compute_matrix_hirschberg, bpm_hirschberg.c:33-270) over a list of
+// roots = (pair, cutoff).  The recursion becomes a level-by-level work list: every level is
+// one batch of forward + reverse score-only half passes and one join kernel; the leaves of
+// all levels are then filled and traced back in sub-batches that fit the pool, and every
+// pair's leaves are stitched into one CIGAR in text order.
+// ---------------------------------------------------------------------------
+struct HNode { int32_t pair, p0, m, t0, n, cutoff, left, right, leaf_task; };
+
+struct AlignStats { uint64_t fill_adv = 0, tb_steps = 0, score_adv = 0, splits = 0, leaves = 0; };
+
+static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool fetch, bool want_cigar,
+                      size_t matrix_budget, uint64_t split_bytes, int32_t ok_status, int32_t** d_score_out, AlignStats* stats) {
+    std::vector<HNode> nodes;
+    std::vector<int32_t> root_node, root_status;
+    for (size_t t = 0; t < roots.pair.size(); ++t) {
+        if (roots.pair[t] < 0) continue;
+        root_node.push_back((int32_t)nodes.size());
+        root_status.push_back(ok_status);
+        nodes.push_back(HNode{roots.pair[t], roots.p0[t], roots.m[t], roots.t0[t], roots.n[t], roots.cutoff[t], -1, -1, -1});
+    }
+    std::vector<int32_t> node_root(nodes.size());
+    for (size_t i = 0; i < root_node.size(); ++i) node_root[root_node[i]] = (int32_t)i;
+    // ---- split levels
+    std::vector<int32_t> frontier(root_node);
+    while (true) {
+        std::vector<int32_t> split;
+        for (int32_t id : frontier) {
+            const HNode& nd = nodes[id];
+            if (nd.m == 0 || nd.n == 0) continue;
+            const HGeom G = host_geometry(nd.m, nd.n, nd.cutoff);
+            if ((uint64_t)G.ebb * (uint64_t)nd.n * 16u > split_bytes) split.push_back(id);     // bpm_hirschberg.c:63-65
         }
-        const size_t nt = S.pair.size();
-        const int ng = S.ngroups();
-        const size_t mark = C.scratch.mark();
-        const BandLayout lay = band_layout(S, true, true);
-        size_t pool_bytes = 0;
-        if (want_cigar) for (size_t t = 0; t < nt; ++t) if (S.pair[t] >= 0) pool_bytes += cigar_bound(S.m[t], S.n[t]);
-        PoolPlan P; plan_tasks(P, nt); plan_layout(P, lay); plan_out(P, nt); P.add<char>(pool_bytes); P.add<int64_t>(1);
-        C.scratch.reserve(C.scratch.top + P.bytes);
-        const DevTasks T = upload_tasks(S, C);
-        const DevLayout D = upload_layout(lay, C);
-        const TaskOut O = take_out(C, nt);
-        char* pool = C.scratch.take<char>(pool_bytes);
-        int64_t* d_total = C.scratch.take<int64_t>(1);
+        if (split.empty()) break;
+        const DevicePool::Mark mark = C.scratch.mark();
+        TaskList F, V;
+        std::vector<int32_t> hm, hn1, hn2;
+        for (int32_t id : split) {
+            const HNode& nd = nodes[id];
+            const int n1 = (nd.n + 1) / 2, n2 = nd.n - n1;                                      // bpm_hirschberg.c:68-69
+            // both half passes use the FULL (m, n, cutoff) geometry and stop at their half (85-100)
+            F.push(nd.pair, nd.p0, nd.m, nd.t0, nd.n, nd.cutoff, n1);
+            V.push(nd.pair, B.p_len[nd.pair] - (nd.p0 + nd.m), nd.m, B.t_len[nd.pair] - (nd.t0 + nd.n), nd.n, nd.cutoff, n2);
+            hm.push_back(nd.m); hn1.push_back(n1); hn2.push_back(n2);
+        }
+        F.pad(); V.pad();
+        if (!B.have_rev) { launch_pack(B, C, true); B.have_rev = true; }
+        const ScoreLaunch SF = launch_banded_score(B, C, F, false, false);
+        const ScoreLaunch SV = launch_banded_score(B, C, V, true, false);
+        const size_t ns = split.size();
+        JoinArgs J;
+        J.nnodes = (int32_t)ns;
+        int32_t* dm = C.scratch.take<int32_t>(ns); int32_t* dn1 = C.scratch.take<int32_t>(ns); int32_t* dn2 = C.scratch.take<int32_t>(ns);
+        h2d(dm, hm, C.stream); h2d(dn1, hn1, C.stream); h2d(dn2, hn2, C.stream);
+        J.m = dm; J.n1 = dn1; J.n2 = dn2;
+        J.F = band_state(SF); J.R = band_state(SV);
+        J.o_best = C.scratch.take<int32_t>(ns); J.o_score_l = C.scratch.take<int32_t>(ns);
+        J.o_score_r = C.scratch.take<int32_t>(ns); J.o_ok = C.scratch.take<int32_t>(ns);
+        hipLaunchKernelGGL(k_join, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, C.stream, J);
+        std::vector<int32_t> best, sl, sr, ok; std::vector<u32> advf, advv;
+        d2h(best, J.o_best, ns, C.stream); d2h(sl, J.o_score_l, ns, C.stream); d2h(sr, J.o_score_r, ns, C.stream);
+        d2h(ok, J.o_ok, ns, C.stream); d2h(advf, SF.O.adv, ns, C.stream); d2h(advv, SV.O.adv, ns, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        C.scratch.release(mark);
+        if (stats) { stats->score_adv += sum_u32(advf) + sum_u32(advv); stats->splits += ns; }
+        frontier.clear();
+        for (size_t k = 0; k < ns; ++k) {
+            const int32_t id = split[k];
+            const HNode nd = nodes[id];
+            if (!ok[k]) {                                                                       // bpm_hirschberg.c:116-122
+                root_status[node_root[id]] = QUICKED_FAIL_NON_CONVERGENCE;
+                nodes[id].m = 0; nodes[id].n = 0;                                               // contributes nothing
+                continue;
+            }
+            const int n1 = (nd.n + 1) / 2;
+            const int32_t l = (int32_t)nodes.size(), r = l + 1;
+            nodes.push_back(HNode{nd.pair, nd.p0, best[k], nd.t0, n1, sl[k], -1, -1, -1});
+            nodes.push_back(HNode{nd.pair, nd.p0 + best[k], nd.m - best[k], nd.t0 + n1, nd.n - n1, sr[k], -1, -1, -1});
+            node_root.push_back(node_root[id]); node_root.push_back(node_root[id]);
+            nodes[id].left = l; nodes[id].right = r;
+            frontier.push_back(l); frontier.push_back(r);
+        }
+    }
+    // ---- leaves in text order, per root
+    TaskList LL;
+    SegList SL;
+    SL.off.push_back(0);
+    std::vector<int32_t> stack;
+    for (size_t i = 0; i < root_node.size(); ++i) {
+        stack.clear();
+        stack.push_back(root_node[i]);
+        while (!stack.empty()) {
+            const int32_t id = stack.back(); stack.pop_back();
+            HNode& nd = nodes[id];
+            if (nd.left >= 0) { stack.push_back(nd.right); stack.push_back(nd.left); continue; }
+            if (nd.m == 0 && nd.n == 0) continue;
+            if (nd.m == 0) { SL.kind.push_back(1); SL.a.push_back((int32_t)OP_I); SL.b.push_back(nd.n); continue; }
+            if (nd.n == 0) { SL.kind.push_back(1); SL.a.push_back((int32_t)OP_D); SL.b.push_back(nd.m); continue; }
+            nd.leaf_task = (int32_t)LL.pair.size();
+            LL.push(nd.pair, nd.p0, nd.m, nd.t0, nd.n, nd.cutoff, nd.n);
+            SL.kind.push_back(0); SL.a.push_back(nd.leaf_task); SL.b.push_back(0);
+        }
+        SL.off.push_back((int64_t)SL.kind.size());
+        const HNode& rt = nodes[root_node[i]];
+        SL.root_pair.push_back(rt.pair);
+        SL.bound.push_back(cigar_bound(roots.m.empty() ? rt.m : rt.m, rt.n));
+    }
+    LL.pad();
+    if (stats) stats->leaves += LL.pair.size();
+    // ---- leaves: fill + traceback in sub-batches; runs and per-leaf outputs persist
+    const size_t nt = LL.pair.size();
+    const int ng = LL.ngroups();
+    const BandLayout lay = band_layout(LL, true, true);
+    // partition the groups so that each sub-batch's matrices fit the budget; offsets restart per sub-batch
+    std::vector<int> sub_start{0};
+    std::vector<int64_t> ws_off(ng), mat_off(ng);
+    {
+        size_t ws = 0, mat = 0;
+        for (int g = 0; g < ng; ++g) {
+            const size_t gws = (size_t)((g + 1 < ng ? lay.ws_off[g + 1] : (int64_t)lay.ws_bytes) - lay.ws_off[g]);
+            const size_t gmat = (size_t)((g + 1 < ng ? lay.mat_off[g + 1] : (int64_t)lay.mat_u4) - lay.mat_off[g]);
+            if (g > sub_start.back() && (mat + gmat) * 16 > matrix_budget) { sub_start.push_back(g); ws = 0; mat = 0; }
+            ws_off[g] = (int64_t)ws; mat_off[g] = (int64_t)mat;
+            ws += gws; mat += gmat;
+        }
+        sub_start.push_back(ng);
+    }
+    const DevTasks T = upload_tasks(LL, C);
+    const TaskOut O = take_out(C, nt);
+    int64_t* d_ws_off = C.scratch.take<int64_t>(ng + 1); int64_t* d_mat_off = C.scratch.take<int64_t>(ng + 1);
+    int64_t* d_runs_off = C.scratch.take<int64_t>(ng + 1);
+    int32_t* d_nslots = C.scratch.take<int32_t>(ng + 1); int32_t* d_nrows = C.scratch.take<int32_t>(ng + 1);
+    int32_t* d_nch = C.scratch.take<int32_t>(ng + 1); int32_t* d_runs_cap = C.scratch.take<int32_t>(ng + 1);
+    h2d(d_ws_off, ws_off, C.stream); h2d(d_mat_off, mat_off, C.stream); h2d(d_runs_off, lay.runs_off, C.stream);
+    h2d(d_nslots, lay.nslots, C.stream); h2d(d_nrows, lay.nrows, C.stream); h2d(d_nch, lay.nch, C.stream);
+    h2d(d_runs_cap, lay.runs_cap, C.stream);
+    u32* d_runs = C.scratch.take<u32>(lay.runs_u32 + 64);
+    for (size_t sb = 0; sb + 1 < sub_start.size(); ++sb) {
+        const int g0 = sub_start[sb], g1 = sub_start[sb + 1];
+        if (g1 <= g0) continue;
+        size_t ws_bytes = 0, mat_u4 = 0;
+        for (int g = g0; g < g1; ++g) {
+            ws_bytes = std::max(ws_bytes, (size_t)ws_off[g] + (size_t)((g + 1 < ng ? lay.ws_off[g + 1] : (int64_t)lay.ws_bytes) - lay.ws_off[g]));
+            mat_u4 = std::max(mat_u4, (size_t)mat_off[g] + (size_t)((g + 1 < ng ? lay.mat_off[g + 1] : (int64_t)lay.mat_u4) - lay.mat_off[g]));
+        }
+        const DevicePool::Mark mark = C.scratch.mark();
+        uint8_t* ws = C.scratch.take<uint8_t>(ws_bytes + 256);
+        uint4* mat = C.scratch.take<uint4>(mat_u4 + 16);
+        const size_t o = (size_t)g0 * 64;
         BandedArgs a;
-        a.P = pair_view(B, false); a.T = T.v;
-        a.ws = D.ws; a.g_ws_off = D.ws_off; a.g_nslots = D.nslots; a.g_nrows = D.nrows; a.g_nch = D.nch;
-        a.mat = D.mat; a.g_mat_off = D.mat_off;
-        a.o_score = O.score; a.o_first = O.first; a.o_last = O.last; a.o_posv = O.posv; a.o_adv = O.adv;
+        a.P = pair_view(B, false);
+        a.T = T.v;
+        a.T.ntasks = (int32_t)((size_t)(g1 - g0) * 64);
+        a.T.pair = T.pair + o; a.T.p0 = T.p0 + o; a.T.m = T.m + o; a.T.t0 = T.t0 + o; a.T.n = T.n + o;
+        a.T.cutoff = T.cutoff + o; a.T.tfin = T.tfin + o;
+        a.ws = ws; a.g_ws_off = d_ws_off + g0; a.g_nslots = d_nslots + g0; a.g_nrows = d_nrows + g0; a.g_nch = d_nch + g0;
+        a.mat = mat; a.g_mat_off = d_mat_off + g0;
+        a.o_score = O.score + o; a.o_first = O.first + o; a.o_last = O.last + o; a.o_posv = O.posv + o; a.o_adv = O.adv + o;
+        a.o_maxrow = O.len + o;
         auto* ke = C.kernel_events();
         if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-        hipLaunchKernelGGL(k_banded<true>, dim3(ng), dim3(64), 0, C.stream, a);
+        hipLaunchKernelGGL(k_banded<true>, dim3(g1 - g0), dim3(64), 0, C.stream, a);
         if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
         TraceArgs tr;
-        tr.P = a.P; tr.T = T.v;
-        tr.ws = D.ws; tr.g_ws_off = D.ws_off; tr.g_nslots = D.nslots; tr.g_nrows = D.nrows; tr.g_nch = D.nch;
-        tr.mat = D.mat; tr.g_mat_off = D.mat_off;
-        tr.runs = D.runs; tr.g_runs_off = D.runs_off; tr.g_runs_cap = D.runs_cap;
-        tr.o_nruns = O.nruns; tr.o_nops = O.nops; tr.o_edits = O.edits; tr.o_steps = O.steps;
-        hipLaunchKernelGGL(k_traceback, dim3(ng), dim3(64), 0, C.stream, tr);
-        if (want_cigar) format_runs(C, T, D, O, nt, ng, pool_bytes, pool, d_total);
-        if (d_score_out) *d_score_out = O.edits;
-        const bool last_sub = (g1 >= ng_all);
-        if (fetch && R) {
-            std::vector<int32_t> ed, nops; std::vector<u32> adv, steps;
-            d2h(ed, O.edits, nt, C.stream); d2h(adv, O.adv, nt, C.stream); d2h(steps, O.steps, nt, C.stream);
-            d2h(nops, O.nops, nt, C.stream);
-            HIP_CHECK(hipStreamSynchronize(C.stream));
-            for (size_t t = 0; t < nt; ++t) {
-                const size_t dst = (size_t)g0 * 64 + t;
-                R->score[dst] = ed[t]; R->adv[dst] = adv[t]; R->steps[dst] = steps[t]; R->nops[dst] = nops[t];
-            }
-            if (want_cigar) fetch_cigars(B, C, S, O, pool, nt);
-        }
-        if (!last_sub) {
-            HIP_CHECK(hipStreamSynchronize(C.stream));   // the next sub-batch reuses this scratch
+        tr.P = a.P; tr.T = a.T;
+        tr.ws = ws; tr.g_ws_off = a.g_ws_off; tr.g_nslots = a.g_nslots; tr.g_nrows = a.g_nrows; tr.g_nch = a.g_nch;
+        tr.mat = mat; tr.g_mat_off = a.g_mat_off;
+        tr.runs = d_runs; tr.g_runs_off = d_runs_off + g0; tr.g_runs_cap = d_runs_cap + g0;
+        tr.o_nruns = O.nruns + o; tr.o_nops = O.nops + o; tr.o_edits = O.edits + o; tr.o_steps = O.steps + o;
+        hipLaunchKernelGGL(k_traceback, dim3(g1 - g0), dim3(64), 0, C.stream, tr);
+        if (sb + 2 < sub_start.size()) {
+            HIP_CHECK(hipStreamSynchronize(C.stream));       // the next sub-batch reuses this scratch
             C.scratch.release(mark);
         }
-        g0 = g1;
+    }
+    const AlignOut AO = format_segments(C, SL, d_runs, d_runs_off, O.nruns, want_cigar);
+    if (d_score_out) *d_score_out = AO.edits;
+    if (fetch) {
+        if (stats) {
+            std::vector<u32> adv, steps;
+            d2h(adv, O.adv, nt, C.stream); d2h(steps, O.steps, nt, C.stream);
+            HIP_CHECK(hipStreamSynchronize(C.stream));
+            for (size_t t = 0; t < nt; ++t) if (LL.pair[t] >= 0) { stats->fill_adv += adv[t]; stats->tb_steps += steps[t]; }
+        }
+        fetch_alignments(B, C, SL, AO, want_cigar, ok_status, &root_status);
     }
 }
 
@@ -542,6 +739,11 @@ static void scatter_scores(quicked_batch& B, const TaskList& L, const std::vecto
 static double now_ms() {
     struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+// BUFFER_SIZE_16M of bpm_hirschberg.c:65; QE_SPLIT_BYTES lowers it so tests can force many split levels on small inputs
+static uint64_t split_threshold() {
+    const char* e = getenv("QE_SPLIT_BYTES");
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 24);
 }
 static bool trace_on() { static int v = -1; if (v < 0) v = getenv("QE_TRACE") ? 1 : 0; return v == 1; }
 #define QE_TRACE_POINT(name) do { if (trace_on()) { double t__ = now_ms(); fprintf(stderr, "[qe] %-22s +%.3f ms\n", name, t__ - tr_last); tr_last = t__; } } while (0)
@@ -582,12 +784,9 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             run_banded_score(B, C, L, false, &R, fetch, &B.d_score);
             if (fetch) { scatter_scores(B, L, R.score, QUICKED_WIP); B.counters[0] = (int64_t)sum_u32(R.adv); }
         } else {
-            run_banded_align(B, C, L, &R, fetch, want_cigar, &B.d_score, matrix_budget);
-            if (fetch) {
-                scatter_scores(B, L, R.score, QUICKED_WIP);
-                B.counters[1] = (int64_t)sum_u32(R.adv); B.counters[3] = (int64_t)sum_u32(R.steps);
-                for (int32_t x : R.nops) B.counters[4] += x;
-            }
+            AlignStats AS;          // run_banded never splits: one fill + traceback whatever the size
+            run_align(B, C, L, fetch, want_cigar, matrix_budget, ~(uint64_t)0, QUICKED_WIP, &B.d_score, &AS);
+            B.counters[1] = (int64_t)AS.fill_adv; B.counters[3] = (int64_t)AS.tb_steps;
         }
         break;
     case WINDOWED:                                                  // run_windowed, quicked.c:91-123
@@ -668,33 +867,23 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             }
         }
         QE_TRACE_POINT("stage 2/3 decisions");
-        // align step: bpm_compute_matrix_hirschberg with the bound (quicked.c:283-294) -- leaves only here
+        // align step: bpm_compute_matrix_hirschberg with the bound (quicked.c:283-294)
         TaskList LA;
-        bool need_split = false;
         for (size_t t = 0; t < L.pair.size(); ++t) {
-            if (L.pair[t] < 0) { LA.push(-1, 0, 1, 0, 1, 0, 0); continue; }
-            const int cut = (p.algo == QUICKED) ? bound[t] : L.cutoff[t];
-            const HGeom G = host_geometry(L.m[t], L.n[t], cut);
-            if ((uint64_t)G.ebb * (uint64_t)L.n[t] * 16u > ((uint64_t)1 << 24)) need_split = true;   // bpm_hirschberg.c:63-65
-            LA.push(L.pair[t], 0, L.m[t], 0, L.n[t], cut, L.n[t]);
-        }
-        if (need_split) {
-            // Hirschberg splitting of > 16 MiB alignments is the next row of the scope table;
-            // refuse loudly instead of computing something else.
-            HIP_CHECK(hipStreamSynchronize(C.stream));
-            if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNIMPLEMENTED);
-            return QUICKED_UNIMPLEMENTED;
+            if (L.pair[t] < 0) continue;
+            LA.push(L.pair[t], 0, L.m[t], 0, L.n[t], (p.algo == QUICKED) ? bound[t] : L.cutoff[t], L.n[t]);
         }
         QE_TRACE_POINT("align task list");
         qe_timer_start(tl_timers.align);
-        run_banded_align(B, C, LA, &R, fetch, want_cigar, &B.d_score, matrix_budget);
+        AlignStats AS;
+        // run_quicked ignores the Hirschberg status (quicked.c:290-291, A.7(8)); run_hirschberg returns it (149-160)
+        run_align(B, C, LA, fetch, want_cigar, matrix_budget, split_threshold(), p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK,
+                  &B.d_score, &AS);
         qe_timer_stop(tl_timers.align);
         QE_TRACE_POINT("align launch(+fetch)");
-        if (fetch) {
-            scatter_scores(B, LA, R.score, p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK);
-            B.counters[1] += (int64_t)sum_u32(R.adv); B.counters[3] += (int64_t)sum_u32(R.steps);
-            for (int32_t x : R.nops) B.counters[4] += x;
-        }
+        B.counters[0] += (int64_t)AS.score_adv; B.counters[1] += (int64_t)AS.fill_adv; B.counters[3] += (int64_t)AS.tb_steps;
+        if (fetch && p.algo == QUICKED)
+            for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
         ret = (p.algo == QUICKED) ? QUICKED_WIP : QUICKED_OK;
         break;
     }
@@ -764,7 +953,7 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
         P.add<u32>((size_t)n);
         B->arena_bytes = P.bytes + 4096;
         HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
-        DevicePool A; A.base = B->arena; A.cap = B->arena_bytes; A.top = 0;
+        qe::ArenaCarver A{B->arena, 0};
         B->d_asc_p = A.take<uint8_t>(pb + 64); B->d_asc_t = A.take<uint8_t>(tb + 64);
         B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
         B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
@@ -772,7 +961,6 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
         B->d_pl_p = A.take<u64>(B->pl_p_words + 8); B->d_pl_t = A.take<u64>(B->pl_t_words + 8);
         B->d_pl_pr = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr = A.take<u64>(B->pl_t_words + 8);
         B->d_flags = A.take<u32>((size_t)n);
-        A.base = nullptr;   // the batch owns the arena
         // H2D: gather into pinned-size staging on the host, one copy per pool
         std::vector<uint8_t> hp(pb + 64, 0), ht(tb + 64, 0);
         for (int64_t i = 0; i < n; ++i) {

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
         A.o_first[t] = first;
         A.o_last[t] = last;
         A.o_posv[t] = pos_v;
+        A.o_maxrow[t] = max_row_init;
         A.o_adv[t] = adv;                                     // block-advances (one per block per column)
     }
 }
@@ -737,6 +738,123 @@ __global__ __launch_bounds__(64) void k_format(FormatArgs A) {
 }
 template __global__ void k_format<false>(FormatArgs);
 template __global__ void k_format<true>(FormatArgs);
+
+// ===========================================================================
+// Hirschberg midpoint join.  D[i][column] for pattern prefix length i follows
+// from the stopped band: scores[r] is D at the bottom row of block r (A.8) and
+// rows inside a block from the Pv/Mv vertical deltas.  The split row is the
+// FIRST i minimising D_fwd[i] + D_rev[m - i] over the rows both bands cover;
+// the two summands are the children's exact distances = their cutoffs.
+// ===========================================================================
+struct ColDist {
+    const u64* Pv; const u64* Mv; const int32_t* S;
+    int first, last, posv, maxrow, m, nw, column;
+    int blk = -1, bottom = 0;
+    u64 P = 0, M = 0;
+    __device__ __forceinline__ void init(const BandState& B, int g, int lane, int t, int m_, int column_) {
+        const GroupWs W = group_ws(const_cast<uint8_t*>(B.ws), B.g_ws_off[g], B.g_nslots[g], B.g_nrows[g], B.g_nch[g]);
+        Pv = W.Pv + 64 + lane; Mv = W.Mv + 64 + lane; S = W.S + lane;
+        first = B.first[t]; last = B.last[t]; posv = B.posv[t]; maxrow = B.maxrow[t];
+        m = m_; nw = (m_ + 63) >> 6; column = column_;
+    }
+    __device__ __forceinline__ bool row_ok(int r) const {
+        const int s = r - posv;
+        return s >= first && s <= last && r >= 0 && r < nw && r <= maxrow;
+    }
+    // -1 when prefix length i is not covered by the band
+    __device__ __forceinline__ int get(int i) {
+        if (i == 0) return row_ok(0) ? column : -1;         // exact only on the real first row (PHin = 1 there)
+        const int r = (i - 1) >> 6;
+        if (!row_ok(r)) return -1;
+        if (r != blk) {
+            blk = r;
+            const int s = r - posv;
+            P = Pv[(int64_t)s * 64]; M = Mv[(int64_t)s * 64];
+            const int sc = S[(int64_t)r * 64];
+            const int full = 64 * (r + 1);
+            if (full <= m) bottom = sc;
+            else {                                          // partial last block: scores tracks row m (A.8)
+                bottom = sc - (full - m);
+                const u64 mask = (((u64)1) << (m - 64 * r)) - 1;
+                P &= mask; M &= mask;
+            }
+        }
+        const int k = i - 64 * r;                           // 1..64
+        if (k >= 64) return bottom;
+        return bottom - (__popcll(P >> k) - __popcll(M >> k));
+    }
+};
+
+__global__ __launch_bounds__(64) void k_join(JoinArgs A) {
+    const int g = blockIdx.x, lane = threadIdx.x, j = g * 64 + lane;
+    if (j >= A.nnodes) return;
+    const int m = A.m[j];
+    ColDist F, R;
+    F.init(A.F, g, lane, j, m, A.n1[j]);
+    R.init(A.R, g, lane, j, m, A.n2[j]);
+    int best = -1, best_i = -1, sl = 0, sr = 0;
+    for (int i = 0; i <= m; ++i) {
+        const int df = F.get(i);
+        if (df < 0) continue;
+        const int dr = R.get(m - i);
+        if (dr < 0) continue;
+        const int s = df + dr;
+        if (best < 0 || s < best) { best = s; best_i = i; sl = df; sr = dr; }
+    }
+    A.o_best[j] = best_i;
+    A.o_score_l[j] = sl;
+    A.o_score_r[j] = sr;
+    A.o_ok[j] = best_i >= 0 ? 1 : 0;
+}
+
+// ===========================================================================
+// Segment formatter: one lane per pair walks its segments front to back (a
+// leaf's runs were emitted back to front), merging equal neighbours.
+// ===========================================================================
+struct RunMerger {
+    int op = -1, len = 0, total = 0, edits = 0, nops = 0;
+    char* out = nullptr;
+    template <bool WRITE> __device__ __forceinline__ void emit() {
+        if (len <= 0) return;
+        const int d = dec_digits((u32)len);
+        if (WRITE) {
+            u32 x = (u32)len;
+            for (int k = d - 1; k >= 0; --k) { out[k] = (char)('0' + x % 10); x /= 10; }
+            out[d] = (char)(0x4449584Du >> (8 * (op & 3)));   // "MXID"
+            out += d + 1;
+        }
+        total += d + 1;
+    }
+    template <bool WRITE> __device__ __forceinline__ void push(int o, int n) {
+        if (n <= 0) return;
+        if (o == op) len += n;
+        else { emit<WRITE>(); op = o; len = n; }
+        nops += n;
+        if (o != (int)OP_M) edits += n;
+    }
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_format_segs(SegFormatArgs A) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= A.npairs) return;
+    RunMerger Mg;
+    if (WRITE) Mg.out = A.pool + A.str_off[i];
+    for (int64_t sidx = A.seg_off[i]; sidx < A.seg_off[i + 1]; ++sidx) {
+        if (A.seg_kind[sidx] == 1) { Mg.push<WRITE>(A.seg_a[sidx], A.seg_b[sidx]); continue; }
+        const int t = A.seg_a[sidx];
+        const u32* runs = A.runs + A.g_runs_off[t >> 6] + (t & 63);
+        for (int k = A.nruns[t] - 1; k >= 0; --k) {
+            const u32 r = runs[(int64_t)k * 64];
+            Mg.push<WRITE>((int)(r & 3), (int)(r >> 2));
+        }
+    }
+    Mg.emit<WRITE>();
+    if (WRITE) *Mg.out = '\0';
+    else { A.o_len[i] = Mg.total; A.o_edits[i] = Mg.edits; A.o_nops[i] = Mg.nops; }
+}
+template __global__ void k_format_segs<false>(SegFormatArgs);
+template __global__ void k_format_segs<true>(SegFormatArgs);
 
 // exclusive scan of (len + 1) over tasks -> string offsets; single block
 __global__ __launch_bounds__(1024) void k_scan_offsets(const int32_t* len, const int32_t* pair, int64_t* off, int64_t* total, int n) {

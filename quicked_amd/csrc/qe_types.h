@@ -59,7 +59,7 @@ struct BandedArgs {
     // fill only: {Pv,Mv} of every column, [(col * g_nslots + slot)][64] x 16 B
     uint4* mat;  const int64_t* g_mat_off;
     // outputs per task
-    int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;
+    int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;  int32_t* o_maxrow;
 };
 
 // BandEd traceback over a filled matrix (bpm_banded.c:967-1036) -> RLE runs, back to front
@@ -92,6 +92,33 @@ struct FormatArgs {
     int32_t* o_len;          // pass 1: string length (without terminator)
     const int64_t* str_off;  // pass 2: where each string starts in pool
     char* pool;
+};
+
+// Where a stopped score-only BandEd launch left its band (what the Hirschberg join reads)
+struct BandState {
+    const uint8_t* ws;  const int64_t* g_ws_off;  const int32_t* g_nslots;  const int32_t* g_nrows;  const int32_t* g_nch;
+    const int32_t* first;  const int32_t* last;  const int32_t* posv;  const int32_t* maxrow;
+};
+
+// Hirschberg midpoint join (bpm_hirschberg.c:102-200, re-derived: SURVEY A.5 / A.7(12)); node j of
+// the split list is task j of both the forward and the reverse half-pass launch
+struct JoinArgs {
+    int32_t nnodes;
+    const int32_t* m;  const int32_t* n1;  const int32_t* n2;
+    BandState F, R;
+    int32_t* o_best;  int32_t* o_score_l;  int32_t* o_score_r;  int32_t* o_ok;
+};
+
+// CIGAR of a pair = its segments in order, each either the RLE runs of a leaf alignment
+// (kind 0: a = leaf task index) or a literal run (kind 1: a = op, b = count), merged across
+// segment borders exactly like cigar_sprint over one operations buffer (cigar.c:453-488)
+struct SegFormatArgs {
+    int32_t npairs;
+    const int64_t* seg_off;      // [npairs + 1]
+    const int32_t* seg_kind;  const int32_t* seg_a;  const int32_t* seg_b;
+    const u32* runs;  const int64_t* g_runs_off;  const int32_t* nruns;   // per leaf task
+    int32_t* o_len;  int32_t* o_edits;  int32_t* o_nops;                  // per pair-list entry
+    const int64_t* str_off;  char* pool;
 };
 
 }  // namespace qe

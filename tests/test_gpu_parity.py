@@ -157,3 +157,37 @@ def test_counters_match_oracle_work():
     assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
     assert cnt[2] == sum(x["window_block_steps"] for x in tr)
     assert cnt[3] == sum(x["traceback_steps"] for x in tr)
+
+
+def test_hirschberg_split_100kb_golden(golden):
+    """configs[3] shape: 100 kb / 10 % pairs go through two Hirschberg split levels (bpm_hirschberg.c:63-243)"""
+    entry = golden["datasets"]["cfg4_100kb_10pct"]
+    batch = datagen.generate(**entry["gen"])
+    for label in ("quicked", "hirschberg_bw15", "banded_so_bw15"):
+        run = entry["runs"][label]
+        scores, status, cig, cnt = gpu_batch(batch, **run["params"])
+        assert status.tolist() == run["status"], label
+        assert scores.tolist() == run["score"], label
+        if "cigar_sha256" in run:
+            assert [sha(c) for c in cig] == run["cigar_sha256"], label
+
+
+def test_hirschberg_forced_deep_splits(monkeypatch):
+    """QE_SPLIT_BYTES forces many levels on small inputs; the oracle runs with the same threshold"""
+    import ctypes as C
+    monkeypatch.setenv("QE_SPLIT_BYTES", str(1 << 15))
+    lib = O.oracle()
+    for gen in (dict(count=70, length=3000, error=0.08, seed=401), dict(count=40, length=1500, error=0.2, seed=402)):
+        batch = datagen.generate(**gen)
+        pairs = list(batch.pairs())
+        scores, status, cig, cnt = gpu_batch(batch, algo=0)
+        for i, (p, t) in enumerate(pairs):
+            st, sc, cg, tr = O.oracle_align(p, t, trace=True, algo=0)      # reference threshold: bound + score
+            ops = C.create_string_buffer(len(p) + len(t) + 1)
+            n = C.c_int64()
+            lib.qo_hirschberg(p, len(p), t, len(t), tr["bound"], 1 << 15, ops, C.byref(n), None)
+            buf = C.create_string_buffer(2 * n.value + 16)
+            lib.qo_cigar_rle(ops, n.value, buf)
+            assert scores[i] == sc == lib.qo_exact_distance(p, len(p), t, len(t)), (gen, i)
+            assert cig[i] == buf.value.decode(), (gen, i)
+            assert O.cigar_is_valid(p, t, cig[i])
