@@ -27,7 +27,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz: 32-bit lane-ops/s
-OPS_PER_BLOCK_COLUMN = 43        # 32-bit VALU ops per 64-row block per column (ISA count)
+OPS_PER_BLOCK_COLUMN = 36        # 32-bit VALU ops per 64-row block per column (ISA count of the fused v_bitop3 loop)
 
 
 def cpu_baseline(batch, params_kw, budget_s=15.0):
@@ -147,6 +147,15 @@ def main():
             # ASCII in + 16 B per stored block-column + 16 B per traceback step + ops out
             alg_bytes = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
             kernel, work_blocks = "k_banded<true> (BandEd fill)", int(counters[1])
+        traffic = None
+        try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)["banded_score" if args.workload == "banded_score" else "quicked"]
+            key = "k_banded<false>" if args.workload == "banded_score" else "k_banded<true>"
+            if args.pairs == 100000 and args.length == 10000:
+                traffic = pm[key]["hbm_bytes"]
+        except Exception:
+            traffic = None
         achieved = alg_bytes / kern_s / 1e9
         valu_tops = work_blocks * OPS_PER_BLOCK_COLUMN / kern_s / 1e12
         line = {
@@ -160,7 +169,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "length": args.length, "error": args.error,
                        "bandwidth": args.bandwidth, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
                          "note": "score-only BandEd is integer-VALU-bound, not HBM-bound (SURVEY 8d); see valu"},
             "valu": {"achieved": valu_tops, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (32-bit lane ops)",
