@@ -377,6 +377,7 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     a.mat = nullptr; a.g_mat_off = S.D.mat_off;
     a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
     a.o_maxrow = S.O.len;
+    a.only_if = nullptr;
     auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     hipLaunchKernelGGL(k_banded<false>, dim3(L.ngroups()), dim3(64), 0, C.stream, a);
@@ -384,11 +385,86 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     return S;
 }
 
+// lanes per alignment for the cooperative score-only kernel: enough waves to fill the chip
+// (>= ~4 per SIMD) while every lane keeps >= 2 band slots; QE_COOP_G overrides (0 / 1 = off)
+static int coop_lanes(const TaskList& L) {
+    const char* e = getenv("QE_COOP_G");
+    int min_nsl = 1 << 30;
+    size_t live = 0;
+    for (size_t t = 0; t < L.pair.size(); ++t) {
+        if (L.pair[t] < 0) continue;
+        ++live;
+        min_nsl = std::min(min_nsl, host_geometry(L.m[t], L.n[t], L.cutoff[t]).ebb_local);
+    }
+    if (live == 0) return 1;
+    int G = 1;
+    if (e) G = atoi(e);
+    else while (G < 64 && (live * G) / 64 < 1024) G *= 2;     // one wave per SIMD is enough: the kernel is VALU-issue-bound
+    // the band-height test first + 2 < last must stay decidable G-2 chunks early: keep the band >= 3 G + 4 slots
+    while (G > 1 && min_nsl < 3 * G + 4) G /= 2;
+    return G < 2 ? 1 : G;
+}
+
+// k_banded_coop over the list, then k_banded<false> over the tasks it flagged
+static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int G, bool timed) {
+    ScoreLaunch S;
+    S.nt = L.pair.size();
+    const int NA = 64 / G;
+    const size_t nwaves = S.nt / NA;
+    std::vector<int64_t> w_off(nwaves);
+    std::vector<int32_t> w_ns(nwaves), w_nr(nwaves), w_nch(nwaves);
+    size_t ws_bytes = 0;
+    for (size_t w = 0; w < nwaves; ++w) {
+        int ns = 3, nr = 4, nch = 2;
+        for (int q = 0; q < NA; ++q) {
+            const size_t t = w * NA + q;
+            if (L.pair[t] < 0) continue;
+            const HGeom Gm = host_geometry(L.m[t], L.n[t], L.cutoff[t]);
+            ns = std::max(ns, Gm.ebb_local);
+            nr = std::max(nr, (L.m[t] + 63) / 64 + Gm.ebb_local + 4);
+            nch = std::max(nch, L.n[t] / 64 + 3);
+        }
+        w_ns[w] = ns; w_nr[w] = nr; w_nch[w] = nch;
+        w_off[w] = (int64_t)ws_bytes;
+        const size_t bytes = (size_t)2 * (ns + 1) * NA * 8 + (size_t)2 * nr * NA * 4 + (size_t)2 * nch * NA * 2 + (size_t)2 * NA * 4;
+        ws_bytes += (bytes + 255) & ~(size_t)255;
+    }
+    S.T = upload_tasks(L, C);
+    S.O = take_out(C, S.nt);
+    uint8_t* ws = C.scratch.take<uint8_t>(ws_bytes + 256);
+    int64_t* d_off = C.scratch.take<int64_t>(nwaves); int32_t* d_ns = C.scratch.take<int32_t>(nwaves);
+    int32_t* d_nr = C.scratch.take<int32_t>(nwaves); int32_t* d_nch = C.scratch.take<int32_t>(nwaves);
+    h2d(d_off, w_off, C.stream); h2d(d_ns, w_ns, C.stream); h2d(d_nr, w_nr, C.stream); h2d(d_nch, w_nch, C.stream);
+    CoopArgs a;
+    a.P = pair_view(B, reversed); a.T = S.T.v; a.G = G;
+    a.ws = ws; a.w_ws_off = d_off; a.w_nslots = d_ns; a.w_nrows = d_nr; a.w_nch = d_nch;
+    a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
+    a.o_maxrow = S.O.len; a.o_abort = S.O.hew;
+    HIP_CHECK(hipMemsetAsync(S.O.hew, 0, S.nt * sizeof(int32_t), C.stream));
+    auto* ke = timed ? C.kernel_events() : nullptr;
+    if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
+    hipLaunchKernelGGL(k_banded_coop, dim3((unsigned)nwaves), dim3(64), 0, C.stream, a);
+    // fallback pass: one lane per task, only where a band-edge decision could not be resolved in time
+    const BandLayout lay = band_layout(L, false, false);
+    S.D = upload_layout(lay, C);
+    BandedArgs b;
+    b.P = a.P; b.T = S.T.v;
+    b.ws = S.D.ws; b.g_ws_off = S.D.ws_off; b.g_nslots = S.D.nslots; b.g_nrows = S.D.nrows; b.g_nch = S.D.nch;
+    b.mat = nullptr; b.g_mat_off = S.D.mat_off;
+    b.o_score = S.O.score; b.o_first = S.O.first; b.o_last = S.O.last; b.o_posv = S.O.posv; b.o_adv = S.O.adv;
+    b.o_maxrow = S.O.len; b.only_if = S.O.hew;
+    hipLaunchKernelGGL(k_banded<false>, dim3(L.ngroups()), dim3(64), 0, C.stream, b);
+    if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
+    return S;
+}
+
 static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
                              bool fetch, int32_t** d_score_out) {
-    const ScoreLaunch S = launch_banded_score(B, C, L, reversed, true);
+    const int G = coop_lanes(L);
+    const ScoreLaunch S = (G >= 2) ? launch_banded_coop(B, C, L, reversed, G, true) : launch_banded_score(B, C, L, reversed, true);
     if (d_score_out) *d_score_out = S.O.score;
     if (fetch && R) {
+        if (G >= 2) d2h(R->hew, S.O.hew, S.nt, C.stream);       // abort flags (diagnostics)
         d2h(R->score, S.O.score, S.nt, C.stream); d2h(R->adv, S.O.adv, S.nt, C.stream);
         HIP_CHECK(hipStreamSynchronize(C.stream));
     }
@@ -677,6 +753,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         a.mat = mat; a.g_mat_off = d_mat_off + g0;
         a.o_score = O.score + o; a.o_first = O.first + o; a.o_last = O.last + o; a.o_posv = O.posv + o; a.o_adv = O.adv + o;
         a.o_maxrow = O.len + o;
+        a.only_if = nullptr;
         auto* ke = C.kernel_events();
         if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
         hipLaunchKernelGGL(k_banded<true>, dim3(g1 - g0), dim3(64), 0, C.stream, a);
@@ -782,7 +859,11 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     case BANDED:                                                    // run_banded, quicked.c:58-89
         if (p.only_score) {
             run_banded_score(B, C, L, false, &R, fetch, &B.d_score);
-            if (fetch) { scatter_scores(B, L, R.score, QUICKED_WIP); B.counters[0] = (int64_t)sum_u32(R.adv); }
+            if (fetch) {
+                scatter_scores(B, L, R.score, QUICKED_WIP);
+                B.counters[0] = (int64_t)sum_u32(R.adv);
+                for (int32_t x : R.hew) B.counters[6] += (x != 0);     // tasks the cooperative kernel handed to the fallback pass
+            }
         } else {
             AlignStats AS;          // run_banded never splits: one fill + traceback whatever the size
             run_align(B, C, L, fetch, want_cigar, matrix_budget, ~(uint64_t)0, QUICKED_WIP, &B.d_score, &AS);

@@ -297,8 +297,10 @@ __device__ __forceinline__ GroupWs group_ws(uint8_t* ws, int64_t off, int ns, in
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
     const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
-    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    if (A.only_if != nullptr && pair >= 0 && A.only_if[t] == 0) pair = -1;
     const bool valid = pair >= 0;
+    if (!__any(valid)) return;
     int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0, tfin = 0;
     const u64* pp = A.P.pl_p;
     const u64* tp = A.P.pl_t;
@@ -436,6 +438,245 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
 
 template __global__ void k_banded<false>(BandedArgs);
 template __global__ void k_banded<true>(BandedArgs);
+
+
+// ===========================================================================
+// BandEd score-only, cooperative form: G adjacent lanes share one alignment.
+//
+// Lane g of a group owns the fixed band-slot range [g c, (g+1) c) (c >= 2 slots)
+// and runs ONE CHUNK BEHIND lane g-1: at step s it walks its slots for chunk
+// s - g, so the group is a systolic pipeline over (slot range, chunk) with the
+// same carry-word block walk as k_banded.  What moves between lanes:
+//   * the 64 carry bits out of lane g-1's last slot: one __shfl_up per step;
+//   * band state: slot i's result is stored to slot i-1 (the reference's 64-column
+//     band shift, bpm_banded.c:903-909), so lane g+1's first slot becomes lane g's
+//     last slot through the group's shared workspace -- lane g+1 writes it in
+//     iteration 0 of a step, lane g reads it in a later iteration of that step;
+//   * band-edge decisions (bpm_banded.c:889-922): first/last of every chunk live in
+//     CF[] / CL[] with "known up to" counters; the lane owning slot first+1 decides
+//     the top, the lane owning slot last the bottom.  A lane that starts a chunk
+//     before its `first` is decided assumes "no cut" -- harmless after the prologue,
+//     (the extra slot it computes is dropped), otherwise the task is flagged.
+// Every value is bit-identical to k_banded<false>; a flagged task (o_abort) is
+// simply recomputed by k_banded<false>.
+// ===========================================================================
+__global__ __launch_bounds__(64) void k_banded_coop(CoopArgs A) {
+    const int lane = threadIdx.x, w = blockIdx.x;
+    const int G = A.G, NA = 64 / G;
+    const int q = lane / G, g = lane - q * G;
+    const int t = w * NA + q;
+    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    const bool valid = pair >= 0;
+    int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0, tfin = 0;
+    const u64* pp = A.P.pl_p;
+    const u64* tp = A.P.pl_t;
+    u32 fl = 0;
+    if (valid) {
+        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
+        cut_in = A.T.cutoff[t]; tfin = A.T.tfin[t];
+        pp = A.P.pl_p + A.P.pl_p_off[pair];
+        tp = A.P.pl_t + A.P.pl_t_off[pair];
+        fl = A.P.flags[pair];
+    }
+    const bool hasN = (fl & FLAG_HAS_N) != 0;
+    const Geom GE = band_geometry(m, n, cut_in);
+    const int nw = (m + 63) >> 6;
+    const int nsl = ((GE.cutoff + 63) >> 6) + 1;
+    const int lvl_last = (m - 1) & 63;
+    const int prolog = GE.prolog;
+    // my slots
+    const int cper = max((nsl + G - 1) / G, 2);
+    const int slo = min(g * cper, nsl), shi = min(slo + cper, nsl) - 1;
+
+    const int wns = A.w_nslots[w], wnr = A.w_nrows[w], wnch = A.w_nch[w];
+    uint8_t* base = A.ws + A.w_ws_off[w];
+    u64* const Pv = (u64*)base + NA + q;                                   base += (int64_t)(wns + 1) * NA * 8;
+    u64* const Mv = (u64*)base + NA + q;                                   base += (int64_t)(wns + 1) * NA * 8;
+    // scores[] is double-buffered by chunk parity: a row's value AFTER chunk k lives in S[k & 1].  A lane
+    // that is one chunk ahead may already have advanced a row the deciding lane still needs at chunk k.
+    int32_t* const S0 = (int32_t*)base + q;                                base += (int64_t)2 * wnr * NA * 4;
+    const int64_t Spar = (int64_t)wnr * NA;
+    volatile int16_t* const CF = (volatile int16_t*)base + q;              base += (int64_t)wnch * NA * 2;
+    volatile int16_t* const CL = (volatile int16_t*)base + q;              base += (int64_t)wnch * NA * 2;
+    volatile int32_t* const KF = (volatile int32_t*)base + q;              base += (int64_t)NA * 4;
+    volatile int32_t* const KL = (volatile int32_t*)base + q;
+
+    // bpm_reset_search, each lane its own slots
+    if (valid) {
+        for (int s = slo; s <= shi; ++s) {
+            Pv[(int64_t)s * NA] = QE_ONES;
+            Mv[(int64_t)s * NA] = 0;
+            S0[(int64_t)s * NA] = 64 * (s + 1);
+            S0[Spar + (int64_t)s * NA] = 64 * (s + 1);
+        }
+        if (g == 0) { CF[0] = (int16_t)prolog; CL[0] = (int16_t)(nsl - 1); *KF = 1; *KL = 1; }
+    }
+    const int nfull = tfin >> 6, tail = tfin & 63;
+    const int my_chunks = valid ? nfull + (tail ? 1 : 0) : 0;
+    const int nsteps = wave_max(my_chunks > 0 ? my_chunks + G - 1 : 0);
+    u64 lastP = 0, lastM = 0;          // carry words out of my last processed slot in the previous step
+    u32 adv = 0;
+    int maxrow = nsl - 1, aborted = 0;
+
+    for (int s = 0; s < nsteps; ++s) {
+        const u64 cinP = __shfl_up(lastP, 1), cinM = __shfl_up(lastM, 1);
+        const int k = s - g;
+        const bool on = valid && k >= 0 && k < my_chunks;
+        const int ncols = (k < nfull) ? 64 : tail;
+        const int pos_v = k - prolog;
+        int32_t* const Srd = S0 + (((k - 1) & 1) ? Spar : 0);     // values after chunk k-1
+        int32_t* const Swr = S0 + ((k & 1) ? Spar : 0);           // values after chunk k
+        int fk = 0, lk = -1;
+        if (on) {
+            const int kf = *KF, kl = *KL;
+            if (k < kf) fk = CF[(int64_t)k * NA];
+            else {
+                // `first` of my chunk is not decided yet (the deciding lane runs behind me).  It drops by
+                // at most one slot per undecided chunk: if even that bound stays below my slots I have
+                // nothing to do; one chunk of doubt is resolved by assuming "no cut" (bpm_banded.c:894-901)
+                const int prev = CF[(int64_t)(kf - 1) * NA];
+                const int d = k - (kf - 1);
+                if (shi < prev - d) fk = shi + 1;
+                else if (d == 1) fk = (k - 1 < prolog) ? prev - 1 : prev;
+                else { fk = prev; aborted = 1; }
+            }
+            lk = (k < kl) ? CL[(int64_t)k * NA] : CL[(int64_t)(kl - 1) * NA];   // exact or an upper bound; my range end is the same
+        }
+        const int lo = max(slo, fk), hi = min(min(shi, lk), nw - 1 - pos_v);
+        const int cnt = on ? max(hi - lo + 1, 0) : 0;
+        // my only slot is my last slot: lane g+1 hands it over in iteration 0, take it in iteration 1
+        const int off = (cnt == 1 && lo == shi) ? 1 : 0;
+        const int maxit = wave_max(cnt + off);
+        u64 T0 = 0, T1 = 0, TN = 0;
+        if (cnt > 0) load_planes(tp, t0 + 64 * k, T0, T1, TN);
+        u64 hinP = (lo == fk) ? QE_ONES : cinP, hinM = (lo == fk) ? 0 : cinM;   // PHin = 1 into the band's top block
+        for (int it = 0; it < maxit; ++it) {
+            const int i = lo + it - off;
+            const bool act = cnt > 0 && it >= off && i <= hi;
+            const int r = i + pos_v;
+            u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
+            int sc = 0;
+            if (act) {
+                P = Pv[(int64_t)i * NA];
+                M = Mv[(int64_t)i * NA];
+                sc = Srd[(int64_t)r * NA];
+                load_planes(pp, p0 + 64 * r, a, b, nn);
+            }
+            const bool lastblk = (r == nw - 1);
+            u64 houtP = 0, houtM = 0, sP, sM;
+            const bool slow = act && (ncols != 64 || hasN || lastblk);
+            if (!__any(slow)) {
+                run64_fast<false>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, nullptr, 0, nullptr);
+                sP = houtP; sM = houtM;
+            } else {
+                run64_general<false>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
+                                     lastblk ? lvl_last : 63, act ? ncols : 0, false, nullptr, 0, nullptr);
+            }
+            if (act) {
+                sc += __popcll(sP) - __popcll(sM);
+                Swr[(int64_t)r * NA] = sc;
+                const int64_t dst = (ncols == 64) ? (int64_t)(i - 1) * NA : (int64_t)i * NA;
+                Pv[dst] = P;
+                Mv[dst] = M;
+                adv += (u32)ncols;
+                hinP = houtP; hinM = houtM;
+                lastP = houtP; lastM = houtM;
+            }
+        }
+        // ---- band-edge decisions of every chunk that completed its deciding slot in this step.
+        // Two rounds: a decision made in round 1 can enable the lane above (one chunk ahead) in round 2.
+        const bool full = on && ncols == 64;
+        for (int round = 0; round < 6; ++round) {
+            bool decided = false;
+            if (full) {
+                // top (bpm_banded.c:889-901): decided by the owner of slot first + 1
+                int kf = *KF;
+                if (kf == k + 1) {
+                    const int f = CF[(int64_t)k * NA];
+                    const int dslot = min(f + 1, nsl - 1);
+                    if (dslot >= slo && dslot <= shi) {
+                        const int kl = *KL;
+                        const int lub = CL[(int64_t)(min(k, kl - 1)) * NA];
+                        const int llb = (k < kl) ? lub : lub - (k - (kl - 1));     // last drops by at most one per chunk
+                        bool tall;
+                        if (f + 2 < llb) tall = true;
+                        else if (f + 2 >= lub) tall = false;
+                        else { tall = true; aborted = 1; }
+                        bool cut_lo = false;
+                        if (tall && GE.fin > 64 * (f + 1))
+                            cut_lo = Swr[(int64_t)(f + pos_v + 1) * NA] + (GE.fin - 64 * (f + 1)) > GE.cutoff;
+                        int fnew = f;
+                        if (cut_lo && k >= prolog) fnew = f + 1;
+                        else if (!cut_lo && k < prolog) fnew = f - 1;
+                        CF[(int64_t)(k + 1) * NA] = (int16_t)fnew;
+                        *KF = k + 2;
+                        decided = true;
+                    }
+                }
+                // bottom (bpm_banded.c:903-921): decided by the owner of slot last, once the new first is known
+                kf = *KF;
+                const int kl = *KL;
+                if (kl == k + 1 && kf >= k + 2) {
+                    const int l = CL[(int64_t)k * NA];
+                    if (l >= slo && l <= shi) {
+                        const int fnew = CF[(int64_t)(k + 1) * NA];
+                        Pv[(int64_t)l * NA] = QE_ONES;
+                        Mv[(int64_t)l * NA] = 0;
+                        const int pos = l + pos_v;
+                        Swr[(int64_t)(pos + 1) * NA] = Swr[(int64_t)pos * NA] + 64;
+                        maxrow = max(maxrow, pos + 1);
+                        bool cut_hi = false;
+                        if ((fnew + 2 < l) && (64 * (l - 1) > GE.fin))
+                            cut_hi = Swr[(int64_t)(l + pos_v - 1) * NA] + (64 * (l - 1) - GE.fin) > GE.cutoff;
+                        const int lnew = (cut_hi || (pos_v + l >= nw)) ? l - 1 : l;
+                        CL[(int64_t)(k + 1) * NA] = (int16_t)lnew;
+                        *KL = k + 2;
+                        decided = true;
+                    }
+                }
+            }
+            if (!__any(decided)) break;
+        }
+        // a wrong "no cut" guess before the end of the prologue put the carry chain on the wrong top slot
+        if (on && k >= 1 && k <= prolog && fk <= shi) {
+            const int kf = *KF;
+            if (kf > k && CF[(int64_t)k * NA] != fk) aborted = 1;
+        }
+    }
+    // group reductions: adv (sum), maxrow (max), aborted (or)
+    for (int o = 1; o < G; o <<= 1) {
+        adv += __shfl_xor(adv, o);
+        maxrow = max(maxrow, __shfl_xor(maxrow, o));
+        aborted |= __shfl_xor(aborted, o);
+    }
+    if (valid && g == 0) {
+        if (*KF <= nfull || *KL <= nfull) aborted = 1;          // a decision never got made: recompute
+        const int row = nw - 1;
+        int score = -1;
+        if (row <= maxrow) {
+            // which parity holds the row's latest value: processed in the last chunk (in band), or the
+            // never-processed row created by the last bookkeeping; anything else is recomputed
+            const int flast = CF[(int64_t)nfull * NA], llast = CL[(int64_t)nfull * NA];
+            const int slot = row - (nfull - prolog);
+            int par = -1;
+            if (my_chunks == 0) par = 1;
+            else if (slot >= flast && slot <= llast) par = (my_chunks - 1) & 1;
+            else if (slot == llast + 1 && nfull > 0) par = (nfull - 1) & 1;
+            if (par < 0) aborted = 1;
+            else {
+                score = S0[(par ? Spar : 0) + (int64_t)row * NA];
+                if (m & 63) score -= 64 - (m & 63);
+            }
+        }
+        A.o_score[t] = score;
+        A.o_first[t] = CF[(int64_t)nfull * NA];
+        A.o_last[t] = CL[(int64_t)nfull * NA];
+        A.o_posv[t] = nfull - prolog;
+        A.o_maxrow[t] = maxrow;
+        A.o_adv[t] = adv;
+        A.o_abort[t] = aborted;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // RLE emitter shared by the tracebacks: ops arrive back to front

@@ -60,6 +60,19 @@ struct BandedArgs {
     uint4* mat;  const int64_t* g_mat_off;
     // outputs per task
     int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;  int32_t* o_maxrow;
+    const int32_t* only_if;  // run only tasks whose flag is non-zero (fallback pass after k_banded_coop); may be null
+};
+
+// BandEd score-only, G lanes per alignment (cooperative form of k_banded<false>)
+struct CoopArgs {
+    PairView P;
+    TaskView T;
+    int32_t G;                               // lanes per alignment: 2, 4, ..., 64; a wave owns 64 / G tasks
+    // per-WAVE workspace (A = 64 / G): Pv[(ns+1)][A] u64 | Mv[(ns+1)][A] u64 | S[nrows][A] i32 |
+    //                                  CF[nch][A] i16 | CL[nch][A] i16 | KF[A] i32 | KL[A] i32
+    uint8_t* ws;  const int64_t* w_ws_off;  const int32_t* w_nslots;  const int32_t* w_nrows;  const int32_t* w_nch;
+    int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;  int32_t* o_maxrow;
+    int32_t* o_abort;                        // 1: a band-edge decision could not be resolved in time; rerun with k_banded<false>
 };
 
 // BandEd traceback over a filled matrix (bpm_banded.c:967-1036) -> RLE runs, back to front
