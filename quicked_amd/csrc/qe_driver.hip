@@ -355,10 +355,21 @@ static uint64_t sum_u32(const std::vector<u32>& v) { uint64_t s = 0; for (u32 x 
 
 // BandEd score-only over a task list (bpm_banded.c:791-964); the launch's device state stays
 // addressable (Hirschberg reads the stopped bands)
-struct ScoreLaunch { DevTasks T; DevLayout D; TaskOut O; size_t nt = 0; };
+struct ScoreLaunch {
+    DevTasks T; DevLayout D; TaskOut O; size_t nt = 0;
+    int G = 1;                                                          // >= 2: cooperative launch + fallback pass
+    uint8_t* cws = nullptr; int64_t* c_off = nullptr; int32_t *c_ns = nullptr, *c_nr = nullptr, *c_nch = nullptr;
+};
+static BandState coop_state(const ScoreLaunch& S) {
+    BandState b;
+    b.G = S.G; b.ws = S.cws; b.g_ws_off = S.c_off; b.g_nslots = S.c_ns; b.g_nrows = S.c_nr; b.g_nch = S.c_nch;
+    b.first = S.O.first; b.last = S.O.last; b.posv = S.O.posv; b.maxrow = S.O.len; b.abort = S.O.hew;
+    return b;
+}
 
 static BandState band_state(const ScoreLaunch& S) {
     BandState b;
+    b.G = 1; b.abort = nullptr;
     b.ws = S.D.ws; b.g_ws_off = S.D.ws_off; b.g_nslots = S.D.nslots; b.g_nrows = S.D.nrows; b.g_nch = S.D.nch;
     b.first = S.O.first; b.last = S.O.last; b.posv = S.O.posv; b.maxrow = S.O.len;   // O.len doubles as maxrow here
     return b;
@@ -435,6 +446,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     int64_t* d_off = C.scratch.take<int64_t>(nwaves); int32_t* d_ns = C.scratch.take<int32_t>(nwaves);
     int32_t* d_nr = C.scratch.take<int32_t>(nwaves); int32_t* d_nch = C.scratch.take<int32_t>(nwaves);
     h2d(d_off, w_off, C.stream); h2d(d_ns, w_ns, C.stream); h2d(d_nr, w_nr, C.stream); h2d(d_nch, w_nch, C.stream);
+    S.G = G; S.cws = ws; S.c_off = d_off; S.c_ns = d_ns; S.c_nr = d_nr; S.c_nch = d_nch;
     CoopArgs a;
     a.P = pair_view(B, reversed); a.T = S.T.v; a.G = G;
     a.ws = ws; a.w_ws_off = d_off; a.w_nslots = d_ns; a.w_nrows = d_nr; a.w_nch = d_nch;
@@ -641,15 +653,17 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         }
         F.pad(); V.pad();
         if (!B.have_rev) { launch_pack(B, C, true); B.have_rev = true; }
-        const ScoreLaunch SF = launch_banded_score(B, C, F, false, false);
-        const ScoreLaunch SV = launch_banded_score(B, C, V, true, false);
+        const int Gf = coop_lanes(F);
+        const ScoreLaunch SF = (Gf >= 2) ? launch_banded_coop(B, C, F, false, Gf, false) : launch_banded_score(B, C, F, false, false);
+        const ScoreLaunch SV = (Gf >= 2) ? launch_banded_coop(B, C, V, true, Gf, false) : launch_banded_score(B, C, V, true, false);
         const size_t ns = split.size();
         JoinArgs J;
         J.nnodes = (int32_t)ns;
         int32_t* dm = C.scratch.take<int32_t>(ns); int32_t* dn1 = C.scratch.take<int32_t>(ns); int32_t* dn2 = C.scratch.take<int32_t>(ns);
         h2d(dm, hm, C.stream); h2d(dn1, hn1, C.stream); h2d(dn2, hn2, C.stream);
         J.m = dm; J.n1 = dn1; J.n2 = dn2;
-        J.F = band_state(SF); J.R = band_state(SV);
+        J.Ffb = band_state(SF); J.Rfb = band_state(SV);
+        J.F = (Gf >= 2) ? coop_state(SF) : J.Ffb; J.R = (Gf >= 2) ? coop_state(SV) : J.Rfb;
         J.o_best = C.scratch.take<int32_t>(ns); J.o_score_l = C.scratch.take<int32_t>(ns);
         J.o_score_r = C.scratch.take<int32_t>(ns); J.o_ok = C.scratch.take<int32_t>(ns);
         hipLaunchKernelGGL(k_join, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, C.stream, J);

@@ -1024,9 +1024,25 @@ struct ColDist {
     int first, last, posv, maxrow, m, nw, column;
     int blk = -1, bottom = 0;
     u64 P = 0, M = 0;
-    __device__ __forceinline__ void init(const BandState& B, int g, int lane, int t, int m_, int column_) {
-        const GroupWs W = group_ws(const_cast<uint8_t*>(B.ws), B.g_ws_off[g], B.g_nslots[g], B.g_nrows[g], B.g_nch[g]);
-        Pv = W.Pv + 64 + lane; Mv = W.Mv + 64 + lane; S = W.S + lane;
+    int64_t stride = 64;
+    __device__ __forceinline__ void init(const BandState& B, int t, int m_, int column_) {
+        if (B.G <= 1) {
+            const int g = t >> 6, lane = t & 63;
+            const GroupWs W = group_ws(const_cast<uint8_t*>(B.ws), B.g_ws_off[g], B.g_nslots[g], B.g_nrows[g], B.g_nch[g]);
+            Pv = W.Pv + 64 + lane; Mv = W.Mv + 64 + lane; S = W.S + lane;
+            stride = 64;
+        } else {
+            // k_banded_coop layout: Pv[(ns+1)][NA] | Mv | S[2][nrows][NA]; the row values after the last
+            // processed chunk are in parity (chunks - 1) & 1
+            const int NA = 64 / B.G, w = t / NA, q = t - w * NA;
+            const uint8_t* base = B.ws + B.g_ws_off[w];
+            const int ns = B.g_nslots[w], nr = B.g_nrows[w];
+            Pv = (const u64*)base + NA + q;                      base += (int64_t)(ns + 1) * NA * 8;
+            Mv = (const u64*)base + NA + q;                      base += (int64_t)(ns + 1) * NA * 8;
+            const int chunks = (column_ >> 6) + ((column_ & 63) ? 1 : 0);
+            S = (const int32_t*)base + q + (((chunks - 1) & 1) ? (int64_t)nr * NA : 0);
+            stride = NA;
+        }
         first = B.first[t]; last = B.last[t]; posv = B.posv[t]; maxrow = B.maxrow[t];
         m = m_; nw = (m_ + 63) >> 6; column = column_;
     }
@@ -1042,8 +1058,8 @@ struct ColDist {
         if (r != blk) {
             blk = r;
             const int s = r - posv;
-            P = Pv[(int64_t)s * 64]; M = Mv[(int64_t)s * 64];
-            const int sc = S[(int64_t)r * 64];
+            P = Pv[(int64_t)s * stride]; M = Mv[(int64_t)s * stride];
+            const int sc = S[(int64_t)r * stride];
             const int full = 64 * (r + 1);
             if (full <= m) bottom = sc;
             else {                                          // partial last block: scores tracks row m (A.8)
@@ -1063,8 +1079,8 @@ __global__ __launch_bounds__(64) void k_join(JoinArgs A) {
     if (j >= A.nnodes) return;
     const int m = A.m[j];
     ColDist F, R;
-    F.init(A.F, g, lane, j, m, A.n1[j]);
-    R.init(A.R, g, lane, j, m, A.n2[j]);
+    F.init((A.F.G > 1 && A.F.abort[j]) ? A.Ffb : A.F, j, m, A.n1[j]);
+    R.init((A.R.G > 1 && A.R.abort[j]) ? A.Rfb : A.R, j, m, A.n2[j]);
     int best = -1, best_i = -1, sl = 0, sr = 0;
     for (int i = 0; i <= m; ++i) {
         const int df = F.get(i);

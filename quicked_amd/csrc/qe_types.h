@@ -109,8 +109,10 @@ struct FormatArgs {
 
 // Where a stopped score-only BandEd launch left its band (what the Hirschberg join reads)
 struct BandState {
+    int32_t G;     // 1: k_banded<false> layout (per 64-task group, column = lane); >= 2: k_banded_coop layout (per wave of 64/G tasks)
     const uint8_t* ws;  const int64_t* g_ws_off;  const int32_t* g_nslots;  const int32_t* g_nrows;  const int32_t* g_nch;
     const int32_t* first;  const int32_t* last;  const int32_t* posv;  const int32_t* maxrow;
+    const int32_t* abort;  // coop only: tasks recomputed by the fallback pass live in fb's layout
 };
 
 // Hirschberg midpoint join (bpm_hirschberg.c:102-200, re-derived: SURVEY A.5 / A.7(12)); node j of
@@ -118,7 +120,8 @@ struct BandState {
 struct JoinArgs {
     int32_t nnodes;
     const int32_t* m;  const int32_t* n1;  const int32_t* n2;
-    BandState F, R;
+    BandState F, R;       // cooperative launches (or the only ones when G == 1)
+    BandState Ffb, Rfb;   // their k_banded<false> fallback passes (G == 1 layout); used where abort[j] != 0
     int32_t* o_best;  int32_t* o_score_l;  int32_t* o_score_r;  int32_t* o_ok;
 };
 
