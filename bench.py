@@ -26,43 +26,50 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz: 32-bit lane-ops/s
+# Integer VALU peak for the block-step instruction mix: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU (quad-cycles) on
+# k_banded<false>, i.e. every VALU instruction of this mix holds its SIMD for 4 cycles = 16 lanes/clk/SIMD
+# (profiles/README.md); 256 CU x 4 SIMD x 16 lanes x 2.4 GHz.  A 400 k-pair launch saturates at 35 Tops/s.
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 OPS_PER_BLOCK_COLUMN = 36        # 32-bit VALU ops per 64-row block per column (ISA count of the fused v_bitop3 loop)
 
 
 def cpu_baseline(batch, params_kw, budget_s=15.0):
     """The compiled reference (oracle/_ref, kind "reference") or the oracle
-    restatement (kind "port") on the host cores, one aligner per thread over
-    disjoint pair ranges (the reference's own model, align_benchmark.c:246-284),
-    on a bounded prefix of the same workload."""
-    import concurrent.futures as cf
+    restatement (kind "port") on the host cores: oracle/cpu_bench.c, one aligner
+    per OpenMP thread over disjoint pair ranges (the reference's own model,
+    align_benchmark.c:246-284), on a bounded prefix of the same workload."""
+    import ctypes as C
+    import subprocess
     import oracle_lib as O
+    so = os.path.join(O.ORACLE_DIR, "libcpubench.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", O.ORACLE_DIR, "all"], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(so)
+    lib.cpu_bench_run.restype = C.c_double
+    lib.cpu_bench_run.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p]
     kind = "reference" if O.have_ref() else "port"
-    fn = O.ref_align if kind == "reference" else O.oracle_align
+    ref_so = O.REF_SO.encode() if kind == "reference" else None
     cores = os.cpu_count() or 1
-    pairs = []
-    # calibrate on 8 pairs, then size the sample for ~budget_s of wall time
-    probe = [(batch.pattern(i), batch.text(i)) for i in range(min(8, len(batch)))]
-    t0 = time.perf_counter()
-    res_probe = [fn(p, t, **params_kw) for p, t in probe]
-    per = (time.perf_counter() - t0) / len(probe)
-    n = int(min(len(batch), max(cores * 4, budget_s / per * cores * 0.8)))
-    pairs = [(batch.pattern(i), batch.text(i)) for i in range(n)]
-    chunks = [pairs[i::cores] for i in range(cores)]
 
-    def work(ch):
-        return [fn(p, t, **params_kw)[1] for p, t in ch]
+    def run(n, threads):
+        scores = np.zeros(n, dtype=np.int32)
+        wall = lib.cpu_bench_run(ref_so, n, batch.pattern_pool.ctypes.data, batch.pattern_off.ctypes.data,
+                                 batch.pattern_len.ctypes.data, batch.text_pool.ctypes.data, batch.text_off.ctypes.data,
+                                 batch.text_len.ctypes.data, params_kw["algo"], 1 if params_kw.get("only_score") else 0,
+                                 params_kw.get("bandwidth", 15), threads, scores.ctypes.data)
+        assert wall > 0, "cpu_bench_run failed"
+        return wall, scores
 
-    t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(cores) as ex:       # ctypes releases the GIL inside the C call
-        out = list(ex.map(work, chunks))
-    wall = time.perf_counter() - t0
-    scores = np.zeros(n, dtype=np.int64)
-    for c, o in enumerate(out):
-        scores[c::cores] = o
+    run(min(len(batch), cores), cores)                   # warm the library, the arenas and the page cache
+    n1 = min(len(batch), 64)
+    w1, _ = run(n1, 1)                                   # single-thread calibration
+    per = w1 / n1
+    n = int(min(len(batch), max(cores * 8, budget_s / per * cores)))
+    wall, scores = run(n, cores)
     return {"value": n / wall, "unit": "alignments/s", "cores": cores, "kind": kind,
-            "sample": f"first {n} pairs of the same workload, {cores} threads, one aligner per thread",
-            "single_thread_value": 1.0 / per}, scores
+            "sample": f"first {n} pairs of the same workload, {cores} OpenMP threads, one aligner per thread",
+            "single_thread_value": 1.0 / per}, scores.astype(np.int64)
 
 
 def main():
@@ -84,7 +91,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("QE_FORCE_DIST"):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
