@@ -55,6 +55,20 @@ def build_hip(force=False):
     return HIP_LIB
 
 
+HARNESS = os.path.join(ROOT, "tools", "bin", "align_benchmark")
+
+
+def build_harness(force=False):
+    """tools/align_benchmark.cpp: the reference CLI's interface over the C-ABI batch call."""
+    src = os.path.join(ROOT, "tools", "align_benchmark.cpp")
+    os.makedirs(os.path.dirname(HARNESS), exist_ok=True)
+    if force or _newer(HARNESS, [src, HIP_LIB, os.path.join(ROOT, "include", "quicked_batch.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-I", os.path.join(ROOT, "include"), "-L", HERE, "-lquicked_hip",
+              "-Wl,-rpath," + HERE, "-o", HARNESS])
+    return HARNESS
+
+
 def build_all(force=False):
     build_datagen(force)
     build_hip(force)
+    build_harness(force)

@@ -96,12 +96,6 @@ struct ArenaCarver {
     }
 };
 
-// sizes a pool request before carving it (two-pass: plan, reserve, carve)
-struct PoolPlan {
-    size_t bytes = 0;
-    template <typename T> void add(size_t count) { bytes += (count * sizeof(T) + 255) & ~(size_t)255; }
-};
-
 struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -192,7 +186,6 @@ struct quicked_batch {
     int32_t *d_p_len = nullptr, *d_t_len = nullptr;
     u64 *d_pl_p = nullptr, *d_pl_t = nullptr, *d_pl_pr = nullptr, *d_pl_tr = nullptr;
     u32* d_flags = nullptr;
-    int32_t *d_task_pair = nullptr, *d_zero = nullptr;
     size_t pl_p_words = 0, pl_t_words = 0;
     bool have_rev = false;
     // results of the last run, host side, indexed by pair
@@ -204,7 +197,6 @@ struct quicked_batch {
     // results of the last run, device side, indexed by task (what a timed run leaves in HBM)
     int32_t* d_score = nullptr;
     bool pending = false;
-    std::string error;
 
     ~quicked_batch() { if (arena) (void)hipFree(arena); }
 };
@@ -252,7 +244,6 @@ struct DevTasks {
     TaskView v;
     int32_t *pair, *p0, *m, *t0, *n, *cutoff, *tfin;
 };
-static void plan_tasks(PoolPlan& P, size_t nt) { for (int i = 0; i < 7; ++i) P.add<int32_t>(nt); }
 static DevTasks upload_tasks(const TaskList& L, Context& C) {
     DevTasks d;
     const size_t nt = L.pair.size();
@@ -306,12 +297,6 @@ static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs) {
 struct DevLayout {
     uint8_t* ws; int64_t *ws_off, *mat_off, *runs_off; int32_t *nslots, *nrows, *nch, *runs_cap; uint4* mat; u32* runs;
 };
-static void plan_layout(PoolPlan& P, const BandLayout& B) {
-    const size_t ng = B.ws_off.size();
-    P.add<uint8_t>(B.ws_bytes); P.add<uint4>(B.mat_u4); P.add<u32>(B.runs_u32);
-    for (int i = 0; i < 3; ++i) P.add<int64_t>(ng);
-    for (int i = 0; i < 4; ++i) P.add<int32_t>(ng);
-}
 static DevLayout upload_layout(const BandLayout& B, Context& C) {
     DevLayout d;
     const size_t ng = B.ws_off.size();
@@ -332,7 +317,6 @@ struct TaskOut {   // device arrays per task
     u32 *adv, *steps;
     int64_t* str_off;
 };
-static void plan_out(PoolPlan& P, size_t nt) { for (int i = 0; i < 11; ++i) P.add<int32_t>(nt); P.add<int64_t>(nt + 1); }
 static TaskOut take_out(Context& C, size_t nt) {
     TaskOut o;
     o.score = C.scratch.take<int32_t>(nt); o.first = C.scratch.take<int32_t>(nt); o.last = C.scratch.take<int32_t>(nt);
@@ -1040,13 +1024,9 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
             const int la = std::max(B->p_len[a], B->t_len[a]), lb = std::max(B->p_len[b], B->t_len[b]);
             return la > lb;
         });
-        PoolPlan P;
-        P.add<uint8_t>(pb + 64); P.add<uint8_t>(tb + 64);
-        for (int i = 0; i < 4; ++i) P.add<int64_t>((size_t)n);
-        for (int i = 0; i < 2; ++i) P.add<int32_t>((size_t)n);
-        for (int i = 0; i < 2; ++i) { P.add<u64>(B->pl_p_words + 8); P.add<u64>(B->pl_t_words + 8); }
-        P.add<u32>((size_t)n);
-        B->arena_bytes = P.bytes + 4096;
+        auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+        B->arena_bytes = pad(pb + 64) + pad(tb + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
+                         2 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + pad((size_t)n * 4) + 4096;
         HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
         qe::ArenaCarver A{B->arena, 0};
         B->d_asc_p = A.take<uint8_t>(pb + 64); B->d_asc_t = A.take<uint8_t>(tb + 64);

@@ -986,31 +986,7 @@ __device__ __forceinline__ int dec_digits(u32 x) {
     return d;
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_format(FormatArgs A) {
-    const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
-    if (t >= A.ntasks || A.pair[t] < 0) return;
-    const u32* runs = A.runs + A.g_runs_off[g] + lane;
-    const int nr = A.nruns[t];
-    if (!WRITE) {
-        int len = 0;
-        for (int i = 0; i < nr; ++i) len += dec_digits(runs[(int64_t)i * 64] >> 2) + 1;
-        A.o_len[t] = len;
-    } else {
-        char* out = A.pool + A.str_off[t];
-        for (int i = nr - 1; i >= 0; --i) {
-            const u32 r = runs[(int64_t)i * 64];
-            u32 len = r >> 2;
-            const int d = dec_digits(len);
-            for (int k = d - 1; k >= 0; --k) { out[k] = (char)('0' + len % 10); len /= 10; }
-            out[d] = (char)(0x4449584Du >> (8 * (r & 3)));   // "MXID"
-            out += d + 1;
-        }
-        *out = '\0';
-    }
-}
-template __global__ void k_format<false>(FormatArgs);
-template __global__ void k_format<true>(FormatArgs);
+
 
 // ===========================================================================
 // Hirschberg midpoint join.  D[i][column] for pattern prefix length i follows

@@ -96,17 +96,6 @@ struct WindowArgs {
     int32_t* o_score;  int32_t* o_hew;  int32_t* o_nruns;  int32_t* o_nops;  int32_t* o_edits;  u32* o_steps;
 };
 
-// RLE runs -> "%d%c" strings (cigar.c:453-488)
-struct FormatArgs {
-    int32_t ntasks;
-    const int32_t* pair;
-    const u32* runs;  const int64_t* g_runs_off;
-    const int32_t* nruns;
-    int32_t* o_len;          // pass 1: string length (without terminator)
-    const int64_t* str_off;  // pass 2: where each string starts in pool
-    char* pool;
-};
-
 // Where a stopped score-only BandEd launch left its band (what the Hirschberg join reads)
 struct BandState {
     int32_t G;     // 1: k_banded<false> layout (per 64-task group, column = lane); >= 2: k_banded_coop layout (per wave of 64/G tasks)

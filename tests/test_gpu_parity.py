@@ -191,3 +191,29 @@ def test_hirschberg_forced_deep_splits(monkeypatch):
             assert scores[i] == sc == lib.qo_exact_distance(p, len(p), t, len(t)), (gen, i)
             assert cig[i] == buf.value.decode(), (gen, i)
             assert O.cigar_is_valid(p, t, cig[i])
+
+
+def test_align_benchmark_harness(tmp_path):
+    """tools/align_benchmark: the reference CLI's input / output formats and --check score (SURVEY 8f #1)"""
+    import subprocess
+    from quicked_amd import build
+    exe = build.build_harness()
+    batch = datagen.generate(count=100, length=1500, error=0.06, seed=77)
+    pairs = list(batch.pairs())
+    seq = tmp_path / "in.seq"
+    with open(seq, "wb") as f:
+        for p, t in pairs:
+            f.write(b">" + p + b"\n<" + t + b"\n")
+    for algo, kw in (("quicked", dict(algo=0)), ("edit-banded", dict(algo=2)), ("edit-windowed", dict(algo=1)),
+                     ("edit-banded-hirschberg", dict(algo=3))):
+        out = tmp_path / f"{algo}.out"
+        r = subprocess.run([exe, "-a", algo, "-i", str(seq), "-o", str(out), "-c", "score", "--batch-size", "64"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        lines = out.read_text().splitlines()
+        assert len(lines) == len(pairs)
+        for (p, t), line in zip(pairs, lines):
+            st, sc, cg = O.oracle_align(p, t, **kw)
+            assert line == f"{sc}\t{cg}", algo
+        assert "INACCURATE SCORE" not in r.stderr or algo == "edit-windowed"      # WindowEd is a bound, not exact
+        assert "Alignments.Correct     100/100" in r.stderr
