@@ -225,25 +225,38 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A) {
     const int nw = (len + 63) >> 6;
     u32 fl = 0;
     u64 ka = 0, kb = 0, kn = 0;
-    for (int r = 0; r < nw + 2; ++r) {
-        const int pos = r * 64 + lane;
-        u32 ch = 'A';
-        const bool in = pos < len;
-        if (in) ch = A.reverse ? src[len - 1 - pos] : src[pos];
-        const u32 up = ch & 0xDFu;                            // case-insensitive (dna_text.c:44-45)
-        const bool acgt = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
-        // A=0x41 C=0x43 G=0x47 T=0x54: bits 1,2 give 0,1,3,2 -- any injective 2-bit code works
-        const u64 wa = __ballot(in && acgt && ((ch >> 1) & 1));
-        const u64 wb = __ballot(in && acgt && ((ch >> 2) & 1));
-        const u64 wn = __ballot(in && !acgt);
-        if (in && !acgt) fl |= FLAG_HAS_N;
-        if (in && !(acgt && ch == up) && ch != 'N') fl |= FLAG_NONCANON;   // lower case or IUPAC: raw != encoded compare
-        if (lane == (r & 63)) { ka = wa; kb = wb; kn = wn; }
-        if ((r & 63) == 63 || r == nw + 1) {
-            const int row = (r & ~63) + lane;
-            if (row <= r) {
-                u64* q = dst + 3 * (int64_t)row;
-                q[0] = ka; q[1] = kb; q[2] = kn;
+    const int nrows = nw + 2;
+    constexpr int UNR = 8;     // 8 independent 64-byte row loads in flight per wave (the loop is latency-bound otherwise)
+    for (int r0 = 0; r0 < nrows; r0 += UNR) {
+        u32 chv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int pos = (r0 + u) * 64 + lane;
+            chv[u] = 0;
+            if (pos < len) chv[u] = A.reverse ? src[len - 1 - pos] : src[pos];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int r = r0 + u;
+            if (r < nrows) {
+                const u32 ch = chv[u];
+                const bool in = r * 64 + lane < len;
+                const u32 up = ch & 0xDFu;                            // case-insensitive (dna_text.c:44-45)
+                const bool acgt = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+                // A=0x41 C=0x43 G=0x47 T=0x54: bits 1,2 give 0,1,3,2 -- any injective 2-bit code works
+                const u64 wa = __ballot(in && acgt && ((ch >> 1) & 1));
+                const u64 wb = __ballot(in && acgt && ((ch >> 2) & 1));
+                const u64 wn = __ballot(in && !acgt);
+                if (in && !acgt) fl |= FLAG_HAS_N;
+                if (in && !(acgt && ch == up) && ch != 'N') fl |= FLAG_NONCANON;   // lower case or IUPAC: raw != encoded compare
+                if (lane == (r & 63)) { ka = wa; kb = wb; kn = wn; }
+                if ((r & 63) == 63 || r == nrows - 1) {
+                    const int row = (r & ~63) + lane;
+                    if (row <= r) {
+                        u64* q = dst + 3 * (int64_t)row;
+                        q[0] = ka; q[1] = kb; q[2] = kn;
+                    }
+                }
             }
         }
     }
