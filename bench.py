@@ -111,7 +111,10 @@ def main():
     rb = capi.ResidentBatch(batch)           # H2D happens here, outside the timed region
 
     for _ in range(max(args.warmup, 0)):
-        rb.run(params, sync=True)
+        st = rb.run(params, sync=True)
+        assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
+    if args.warmup <= 0:
+        st = 0
     rb.kernel_time()                         # drop the warm-up launches
 
     def barrier():
@@ -123,15 +126,18 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rb.run(params, sync=False)          # results stay resident in HBM; the driver still syncs where a stage needs host decisions
+        st = rb.run(params, sync=False)     # results stay resident in HBM; the driver still syncs where a stage needs host decisions
+        assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
     rb.sync()
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = rb.kernel_time()
 
     # one synchronous run to fetch results + work counters for the report
-    rb.run(params, sync=True)
+    st = rb.run(params, sync=True)
+    assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
     scores, status = rb.scores()
+    assert (status >= 0).all(), "some pairs failed" 
     counters = rb.counters()
     rb.kernel_time()
     checksum = int(scores.astype(np.int64).sum())
