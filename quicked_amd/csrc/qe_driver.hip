@@ -98,8 +98,15 @@ struct ArenaCarver {
 
 struct Context {
     int device = 0;
-    hipStream_t stream = nullptr;
-    DevicePool scratch;
+    // Two phases of a run use two streams and two pools so that consecutive runs pipeline:
+    //   W: pack + bound stages (WindowEd, band doubling)      A: the BandEd kernels (score / fill / traceback / format)
+    // Run k+1's W phase overlaps run k's A phase (different resources: W is latency / VALU-light, A is
+    // VALU- or HBM-bound); a batch double-buffers its planes for that.
+    hipStream_t stream_w = nullptr, stream_a = nullptr;
+    hipStream_t stream = nullptr;            // where the current phase launches
+    DevicePool pool_w, pool_a;
+    DevicePool* scratch_p = nullptr;         // the current phase's pool
+    hipEvent_t ev_pack = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // HIP-event pairs around the dominant kernel of every run since the last collection (bench.py's roofline leg)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
@@ -113,10 +120,15 @@ struct Context {
         }
         return &kev[kev_used++];
     }
+    void phase_w() { stream = stream_w; scratch_p = &pool_w; }
+    void phase_a() { stream = stream_a; scratch_p = &pool_a; }
     void init() {
         if (stream) return;
         HIP_CHECK(hipSetDevice(device));
-        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&stream_w, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&stream_a, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
+        phase_w();
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
     }
@@ -184,10 +196,14 @@ struct quicked_batch {
     uint8_t *d_asc_p = nullptr, *d_asc_t = nullptr;
     int64_t *d_p_off = nullptr, *d_t_off = nullptr, *d_plp_off = nullptr, *d_plt_off = nullptr;
     int32_t *d_p_len = nullptr, *d_t_len = nullptr;
-    u64 *d_pl_p = nullptr, *d_pl_t = nullptr, *d_pl_pr = nullptr, *d_pl_tr = nullptr;
-    u32* d_flags = nullptr;
+    // planes and flags are double-buffered by run parity (see Context)
+    u64 *d_pl_p[2] = {nullptr, nullptr}, *d_pl_t[2] = {nullptr, nullptr}, *d_pl_pr[2] = {nullptr, nullptr}, *d_pl_tr[2] = {nullptr, nullptr};
+    u32* d_flags[2] = {nullptr, nullptr};
+    int parity = 0;
+    hipEvent_t ev_done[2] = {nullptr, nullptr};    // end of the A phase of the last run that used this parity
+    bool ev_done_set[2] = {false, false};
     size_t pl_p_words = 0, pl_t_words = 0;
-    bool have_rev = false;
+    bool have_rev[2] = {false, false};
     // results of the last run, host side, indexed by pair
     std::vector<int32_t> score, status;
     std::vector<int64_t> cigar_off;
@@ -198,7 +214,10 @@ struct quicked_batch {
     int32_t* d_score = nullptr;
     bool pending = false;
 
-    ~quicked_batch() { if (arena) (void)hipFree(arena); }
+    ~quicked_batch() {
+        if (arena) (void)hipFree(arena);
+        for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
+    }
 };
 
 namespace qe {
@@ -207,9 +226,10 @@ static PairView pair_view(const quicked_batch& B, bool reversed) {
     PairView v;
     v.asc_p = B.d_asc_p; v.asc_p_off = B.d_p_off; v.p_len = B.d_p_len;
     v.asc_t = B.d_asc_t; v.asc_t_off = B.d_t_off; v.t_len = B.d_t_len;
-    v.pl_p = reversed ? B.d_pl_pr : B.d_pl_p; v.pl_p_off = B.d_plp_off;
-    v.pl_t = reversed ? B.d_pl_tr : B.d_pl_t; v.pl_t_off = B.d_plt_off;
-    v.flags = B.d_flags;
+    const int q = B.parity;
+    v.pl_p = reversed ? B.d_pl_pr[q] : B.d_pl_p[q]; v.pl_p_off = B.d_plp_off;
+    v.pl_t = reversed ? B.d_pl_tr[q] : B.d_pl_t[q]; v.pl_t_off = B.d_plt_off;
+    v.flags = B.d_flags[q];
     return v;
 }
 
@@ -217,13 +237,14 @@ static void launch_pack(quicked_batch& B, Context& C, bool reversed) {
     PackArgs a;
     a.nseq = (int32_t)B.n;
     a.reverse = reversed ? 1 : 0;
-    a.flags = reversed ? nullptr : B.d_flags;
+    const int q = B.parity;
+    a.flags = reversed ? nullptr : B.d_flags[q];
     const int blocks = (int)((B.n + 3) / 4);
     a.asc = B.d_asc_p; a.asc_off = B.d_p_off; a.len = B.d_p_len;
-    a.planes = reversed ? B.d_pl_pr : B.d_pl_p; a.pl_off = B.d_plp_off;
+    a.planes = reversed ? B.d_pl_pr[q] : B.d_pl_p[q]; a.pl_off = B.d_plp_off;
     hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, C.stream, a);
     a.asc = B.d_asc_t; a.asc_off = B.d_t_off; a.len = B.d_t_len;
-    a.planes = reversed ? B.d_pl_tr : B.d_pl_t; a.pl_off = B.d_plt_off;
+    a.planes = reversed ? B.d_pl_tr[q] : B.d_pl_t[q]; a.pl_off = B.d_plt_off;
     hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, C.stream, a);
 }
 
@@ -247,9 +268,9 @@ struct DevTasks {
 static DevTasks upload_tasks(const TaskList& L, Context& C) {
     DevTasks d;
     const size_t nt = L.pair.size();
-    d.pair = C.scratch.take<int32_t>(nt); d.p0 = C.scratch.take<int32_t>(nt); d.m = C.scratch.take<int32_t>(nt);
-    d.t0 = C.scratch.take<int32_t>(nt); d.n = C.scratch.take<int32_t>(nt); d.cutoff = C.scratch.take<int32_t>(nt);
-    d.tfin = C.scratch.take<int32_t>(nt);
+    d.pair = C.scratch_p->take<int32_t>(nt); d.p0 = C.scratch_p->take<int32_t>(nt); d.m = C.scratch_p->take<int32_t>(nt);
+    d.t0 = C.scratch_p->take<int32_t>(nt); d.n = C.scratch_p->take<int32_t>(nt); d.cutoff = C.scratch_p->take<int32_t>(nt);
+    d.tfin = C.scratch_p->take<int32_t>(nt);
     h2d(d.pair, L.pair, C.stream); h2d(d.p0, L.p0, C.stream); h2d(d.m, L.m, C.stream); h2d(d.t0, L.t0, C.stream);
     h2d(d.n, L.n, C.stream); h2d(d.cutoff, L.cutoff, C.stream); h2d(d.tfin, L.tfin, C.stream);
     d.v.ntasks = (int32_t)nt; d.v.pair = d.pair; d.v.p0 = d.p0; d.v.m = d.m; d.v.t0 = d.t0; d.v.n = d.n;
@@ -300,12 +321,12 @@ struct DevLayout {
 static DevLayout upload_layout(const BandLayout& B, Context& C) {
     DevLayout d;
     const size_t ng = B.ws_off.size();
-    d.ws = C.scratch.take<uint8_t>(B.ws_bytes);
-    d.mat = C.scratch.take<uint4>(B.mat_u4);
-    d.runs = C.scratch.take<u32>(B.runs_u32);
-    d.ws_off = C.scratch.take<int64_t>(ng); d.mat_off = C.scratch.take<int64_t>(ng); d.runs_off = C.scratch.take<int64_t>(ng);
-    d.nslots = C.scratch.take<int32_t>(ng); d.nrows = C.scratch.take<int32_t>(ng); d.nch = C.scratch.take<int32_t>(ng);
-    d.runs_cap = C.scratch.take<int32_t>(ng);
+    d.ws = C.scratch_p->take<uint8_t>(B.ws_bytes);
+    d.mat = C.scratch_p->take<uint4>(B.mat_u4);
+    d.runs = C.scratch_p->take<u32>(B.runs_u32);
+    d.ws_off = C.scratch_p->take<int64_t>(ng); d.mat_off = C.scratch_p->take<int64_t>(ng); d.runs_off = C.scratch_p->take<int64_t>(ng);
+    d.nslots = C.scratch_p->take<int32_t>(ng); d.nrows = C.scratch_p->take<int32_t>(ng); d.nch = C.scratch_p->take<int32_t>(ng);
+    d.runs_cap = C.scratch_p->take<int32_t>(ng);
     h2d(d.ws_off, B.ws_off, C.stream); h2d(d.mat_off, B.mat_off, C.stream); h2d(d.runs_off, B.runs_off, C.stream);
     h2d(d.nslots, B.nslots, C.stream); h2d(d.nrows, B.nrows, C.stream); h2d(d.nch, B.nch, C.stream);
     h2d(d.runs_cap, B.runs_cap, C.stream);
@@ -319,11 +340,11 @@ struct TaskOut {   // device arrays per task
 };
 static TaskOut take_out(Context& C, size_t nt) {
     TaskOut o;
-    o.score = C.scratch.take<int32_t>(nt); o.first = C.scratch.take<int32_t>(nt); o.last = C.scratch.take<int32_t>(nt);
-    o.posv = C.scratch.take<int32_t>(nt); o.hew = C.scratch.take<int32_t>(nt); o.nruns = C.scratch.take<int32_t>(nt);
-    o.nops = C.scratch.take<int32_t>(nt); o.edits = C.scratch.take<int32_t>(nt); o.len = C.scratch.take<int32_t>(nt);
-    o.adv = C.scratch.take<u32>(nt); o.steps = C.scratch.take<u32>(nt);
-    o.str_off = C.scratch.take<int64_t>(nt + 1);
+    o.score = C.scratch_p->take<int32_t>(nt); o.first = C.scratch_p->take<int32_t>(nt); o.last = C.scratch_p->take<int32_t>(nt);
+    o.posv = C.scratch_p->take<int32_t>(nt); o.hew = C.scratch_p->take<int32_t>(nt); o.nruns = C.scratch_p->take<int32_t>(nt);
+    o.nops = C.scratch_p->take<int32_t>(nt); o.edits = C.scratch_p->take<int32_t>(nt); o.len = C.scratch_p->take<int32_t>(nt);
+    o.adv = C.scratch_p->take<u32>(nt); o.steps = C.scratch_p->take<u32>(nt);
+    o.str_off = C.scratch_p->take<int64_t>(nt + 1);
     return o;
 }
 
@@ -426,9 +447,9 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     }
     S.T = upload_tasks(L, C);
     S.O = take_out(C, S.nt);
-    uint8_t* ws = C.scratch.take<uint8_t>(ws_bytes + 256);
-    int64_t* d_off = C.scratch.take<int64_t>(nwaves); int32_t* d_ns = C.scratch.take<int32_t>(nwaves);
-    int32_t* d_nr = C.scratch.take<int32_t>(nwaves); int32_t* d_nch = C.scratch.take<int32_t>(nwaves);
+    uint8_t* ws = C.scratch_p->take<uint8_t>(ws_bytes + 256);
+    int64_t* d_off = C.scratch_p->take<int64_t>(nwaves); int32_t* d_ns = C.scratch_p->take<int32_t>(nwaves);
+    int32_t* d_nr = C.scratch_p->take<int32_t>(nwaves); int32_t* d_nch = C.scratch_p->take<int32_t>(nwaves);
     h2d(d_off, w_off, C.stream); h2d(d_ns, w_ns, C.stream); h2d(d_nr, w_nr, C.stream); h2d(d_nch, w_nch, C.stream);
     S.G = G; S.cws = ws; S.c_off = d_off; S.c_ns = d_ns; S.c_nr = d_nr; S.c_nch = d_nch;
     CoopArgs a;
@@ -491,17 +512,17 @@ static AlignOut format_segments(Context& C, const SegList& SL, const u32* runs, 
     AlignOut A;
     A.nroots = SL.root_pair.size();
     const size_t nr = A.nroots, nseg = SL.kind.size();
-    int64_t* d_off = C.scratch.take<int64_t>(nr + 1);
-    int32_t* d_kind = C.scratch.take<int32_t>(nseg + 1); int32_t* d_a = C.scratch.take<int32_t>(nseg + 1);
-    int32_t* d_b = C.scratch.take<int32_t>(nseg + 1);
-    int32_t* d_rootpair = C.scratch.take<int32_t>(nr + 1);
+    int64_t* d_off = C.scratch_p->take<int64_t>(nr + 1);
+    int32_t* d_kind = C.scratch_p->take<int32_t>(nseg + 1); int32_t* d_a = C.scratch_p->take<int32_t>(nseg + 1);
+    int32_t* d_b = C.scratch_p->take<int32_t>(nseg + 1);
+    int32_t* d_rootpair = C.scratch_p->take<int32_t>(nr + 1);
     h2d(d_off, SL.off, C.stream); h2d(d_kind, SL.kind, C.stream); h2d(d_a, SL.a, C.stream); h2d(d_b, SL.b, C.stream);
     h2d(d_rootpair, SL.root_pair, C.stream);
-    A.len = C.scratch.take<int32_t>(nr + 1); A.edits = C.scratch.take<int32_t>(nr + 1); A.nops = C.scratch.take<int32_t>(nr + 1);
-    A.str_off = C.scratch.take<int64_t>(nr + 1); A.total = C.scratch.take<int64_t>(1);
+    A.len = C.scratch_p->take<int32_t>(nr + 1); A.edits = C.scratch_p->take<int32_t>(nr + 1); A.nops = C.scratch_p->take<int32_t>(nr + 1);
+    A.str_off = C.scratch_p->take<int64_t>(nr + 1); A.total = C.scratch_p->take<int64_t>(1);
     size_t pool_bytes = 0;
     if (want_strings) for (size_t b : SL.bound) pool_bytes += b;
-    A.pool = C.scratch.take<char>(pool_bytes + 16);
+    A.pool = C.scratch_p->take<char>(pool_bytes + 16);
     SegFormatArgs f;
     f.npairs = (int32_t)nr; f.seg_off = d_off; f.seg_kind = d_kind; f.seg_a = d_a; f.seg_b = d_b;
     f.runs = runs; f.g_runs_off = g_runs_off; f.nruns = nruns;
@@ -624,7 +645,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             if ((uint64_t)G.ebb * (uint64_t)nd.n * 16u > split_bytes) split.push_back(id);     // bpm_hirschberg.c:63-65
         }
         if (split.empty()) break;
-        const DevicePool::Mark mark = C.scratch.mark();
+        const DevicePool::Mark mark = C.scratch_p->mark();
         TaskList F, V;
         std::vector<int32_t> hm, hn1, hn2;
         for (int32_t id : split) {
@@ -636,26 +657,31 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             hm.push_back(nd.m); hn1.push_back(n1); hn2.push_back(n2);
         }
         F.pad(); V.pad();
-        if (!B.have_rev) { launch_pack(B, C, true); B.have_rev = true; }
+        if (!B.have_rev[B.parity]) {
+            hipStream_t cur = C.stream; C.stream = C.stream_w;
+            launch_pack(B, C, true);
+            HIP_CHECK(hipStreamSynchronize(C.stream_w));
+            C.stream = cur; B.have_rev[B.parity] = true;
+        }
         const int Gf = coop_lanes(F);
         const ScoreLaunch SF = (Gf >= 2) ? launch_banded_coop(B, C, F, false, Gf, false) : launch_banded_score(B, C, F, false, false);
         const ScoreLaunch SV = (Gf >= 2) ? launch_banded_coop(B, C, V, true, Gf, false) : launch_banded_score(B, C, V, true, false);
         const size_t ns = split.size();
         JoinArgs J;
         J.nnodes = (int32_t)ns;
-        int32_t* dm = C.scratch.take<int32_t>(ns); int32_t* dn1 = C.scratch.take<int32_t>(ns); int32_t* dn2 = C.scratch.take<int32_t>(ns);
+        int32_t* dm = C.scratch_p->take<int32_t>(ns); int32_t* dn1 = C.scratch_p->take<int32_t>(ns); int32_t* dn2 = C.scratch_p->take<int32_t>(ns);
         h2d(dm, hm, C.stream); h2d(dn1, hn1, C.stream); h2d(dn2, hn2, C.stream);
         J.m = dm; J.n1 = dn1; J.n2 = dn2;
         J.Ffb = band_state(SF); J.Rfb = band_state(SV);
         J.F = (Gf >= 2) ? coop_state(SF) : J.Ffb; J.R = (Gf >= 2) ? coop_state(SV) : J.Rfb;
-        J.o_best = C.scratch.take<int32_t>(ns); J.o_score_l = C.scratch.take<int32_t>(ns);
-        J.o_score_r = C.scratch.take<int32_t>(ns); J.o_ok = C.scratch.take<int32_t>(ns);
+        J.o_best = C.scratch_p->take<int32_t>(ns); J.o_score_l = C.scratch_p->take<int32_t>(ns);
+        J.o_score_r = C.scratch_p->take<int32_t>(ns); J.o_ok = C.scratch_p->take<int32_t>(ns);
         hipLaunchKernelGGL(k_join, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, C.stream, J);
         std::vector<int32_t> best, sl, sr, ok; std::vector<u32> advf, advv;
         d2h(best, J.o_best, ns, C.stream); d2h(sl, J.o_score_l, ns, C.stream); d2h(sr, J.o_score_r, ns, C.stream);
         d2h(ok, J.o_ok, ns, C.stream); d2h(advf, SF.O.adv, ns, C.stream); d2h(advv, SV.O.adv, ns, C.stream);
         HIP_CHECK(hipStreamSynchronize(C.stream));
-        C.scratch.release(mark);
+        C.scratch_p->release(mark);
         if (stats) { stats->score_adv += sum_u32(advf) + sum_u32(advv); stats->splits += ns; }
         frontier.clear();
         for (size_t k = 0; k < ns; ++k) {
@@ -721,14 +747,14 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     }
     const DevTasks T = upload_tasks(LL, C);
     const TaskOut O = take_out(C, nt);
-    int64_t* d_ws_off = C.scratch.take<int64_t>(ng + 1); int64_t* d_mat_off = C.scratch.take<int64_t>(ng + 1);
-    int64_t* d_runs_off = C.scratch.take<int64_t>(ng + 1);
-    int32_t* d_nslots = C.scratch.take<int32_t>(ng + 1); int32_t* d_nrows = C.scratch.take<int32_t>(ng + 1);
-    int32_t* d_nch = C.scratch.take<int32_t>(ng + 1); int32_t* d_runs_cap = C.scratch.take<int32_t>(ng + 1);
+    int64_t* d_ws_off = C.scratch_p->take<int64_t>(ng + 1); int64_t* d_mat_off = C.scratch_p->take<int64_t>(ng + 1);
+    int64_t* d_runs_off = C.scratch_p->take<int64_t>(ng + 1);
+    int32_t* d_nslots = C.scratch_p->take<int32_t>(ng + 1); int32_t* d_nrows = C.scratch_p->take<int32_t>(ng + 1);
+    int32_t* d_nch = C.scratch_p->take<int32_t>(ng + 1); int32_t* d_runs_cap = C.scratch_p->take<int32_t>(ng + 1);
     h2d(d_ws_off, ws_off, C.stream); h2d(d_mat_off, mat_off, C.stream); h2d(d_runs_off, lay.runs_off, C.stream);
     h2d(d_nslots, lay.nslots, C.stream); h2d(d_nrows, lay.nrows, C.stream); h2d(d_nch, lay.nch, C.stream);
     h2d(d_runs_cap, lay.runs_cap, C.stream);
-    u32* d_runs = C.scratch.take<u32>(lay.runs_u32 + 64);
+    u32* d_runs = C.scratch_p->take<u32>(lay.runs_u32 + 64);
     for (size_t sb = 0; sb + 1 < sub_start.size(); ++sb) {
         const int g0 = sub_start[sb], g1 = sub_start[sb + 1];
         if (g1 <= g0) continue;
@@ -737,9 +763,9 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             ws_bytes = std::max(ws_bytes, (size_t)ws_off[g] + (size_t)((g + 1 < ng ? lay.ws_off[g + 1] : (int64_t)lay.ws_bytes) - lay.ws_off[g]));
             mat_u4 = std::max(mat_u4, (size_t)mat_off[g] + (size_t)((g + 1 < ng ? lay.mat_off[g + 1] : (int64_t)lay.mat_u4) - lay.mat_off[g]));
         }
-        const DevicePool::Mark mark = C.scratch.mark();
-        uint8_t* ws = C.scratch.take<uint8_t>(ws_bytes + 256);
-        uint4* mat = C.scratch.take<uint4>(mat_u4 + 16);
+        const DevicePool::Mark mark = C.scratch_p->mark();
+        uint8_t* ws = C.scratch_p->take<uint8_t>(ws_bytes + 256);
+        uint4* mat = C.scratch_p->take<uint4>(mat_u4 + 16);
         const size_t o = (size_t)g0 * 64;
         BandedArgs a;
         a.P = pair_view(B, false);
@@ -765,7 +791,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         hipLaunchKernelGGL(k_traceback, dim3(g1 - g0), dim3(64), 0, C.stream, tr);
         if (sb + 2 < sub_start.size()) {
             HIP_CHECK(hipStreamSynchronize(C.stream));       // the next sub-batch reuses this scratch
-            C.scratch.release(mark);
+            C.scratch_p->release(mark);
         }
     }
     const AlignOut AO = format_segments(C, SL, d_runs, d_runs_off, O.nruns, want_cigar);
@@ -827,7 +853,13 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     double tr_last = now_ms();
     tl_device = B.device;
     Context& C = ctx();
-    C.scratch.reset();
+    B.parity ^= 1;
+    const int par = B.parity;
+    // ---- phase W: pack + bound stages on stream_w with pool_w.  The planes of this parity were last read by
+    // the A phase two runs ago: wait for it on the device, not on the host.
+    C.phase_w();
+    C.pool_w.reset();
+    if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.stream_w, B.ev_done[par], 0));
     B.only_score_run = p.only_score;
     B.score.assign((size_t)B.n, -1);
     B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
@@ -839,22 +871,31 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         return QUICKED_UNKNOWN_ALGO;
     }
     HIP_CHECK(hipEventRecord(C.ev0, C.stream));
-    HIP_CHECK(hipMemsetAsync(B.d_flags, 0, (size_t)B.n * sizeof(u32), C.stream));
+    HIP_CHECK(hipMemsetAsync(B.d_flags[par], 0, (size_t)B.n * sizeof(u32), C.stream));
     launch_pack(B, C, false);
+    HIP_CHECK(hipEventRecord(C.ev_pack, C.stream_w));
+    // phase A starts on the device when the planes are there and (stream order) the previous run's A phase is over;
+    // its pool can be reset now because everything it launches is ordered behind that previous A phase
+    auto enter_a = [&]() {
+        C.phase_a();
+        C.pool_a.reset();
+        HIP_CHECK(hipStreamWaitEvent(C.stream_a, C.ev_pack, 0));
+    };
     const bool sse = !p.force_scalar;
     const bool want_cigar = !p.only_score;
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const size_t matrix_budget = std::max<size_t>((free_b + C.scratch.cap) / 10 * 7, (size_t)1 << 28);
+    const size_t matrix_budget = std::max<size_t>((free_b + C.pool_a.cap) / 10 * 7, (size_t)1 << 28);
     quicked_status_t ret = QUICKED_WIP;
     QE_TRACE_POINT("setup+pack launch");
     TaskList L = all_pairs(B, p);
     QE_TRACE_POINT("task list");
-    if (L.pair.empty()) { HIP_CHECK(hipStreamSynchronize(C.stream)); return QUICKED_EMPTY_SEQUENCE; }
+    if (L.pair.empty()) { HIP_CHECK(hipStreamSynchronize(C.stream_w)); return QUICKED_EMPTY_SEQUENCE; }
     StageResult R;
 
     switch (p.algo) {
     case BANDED:                                                    // run_banded, quicked.c:58-89
+        enter_a();
         if (p.only_score) {
             run_banded_score(B, C, L, false, &R, fetch, &B.d_score);
             if (fetch) {
@@ -869,6 +910,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         }
         break;
     case WINDOWED:                                                  // run_windowed, quicked.c:91-123
+        enter_a();
         run_windowed(B, C, L, false, (int)p.window_size, (int)p.overlap_size, 0, p.only_score, sse, &R, fetch,
                      want_cigar, &B.d_score);
         if (fetch) { scatter_scores(B, L, R.score, QUICKED_WIP); B.counters[2] = (int64_t)sum_u32(R.steps); }
@@ -898,7 +940,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             B.counters[6] = (int64_t)idx2.size();
             if (!idx2.empty()) {
                 L2.pad();
-                if (!B.have_rev) { launch_pack(B, C, true); B.have_rev = true; }
+                if (!B.have_rev[B.parity]) { launch_pack(B, C, true); B.have_rev[B.parity] = true; }
                 StageResult F, V;
                 const int W = (int)p.window_size, O = (int)p.overlap_size;
                 qe_timer_start(tl_timers.windowed_l);
@@ -953,6 +995,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             LA.push(L.pair[t], 0, L.m[t], 0, L.n[t], (p.algo == QUICKED) ? bound[t] : L.cutoff[t], L.n[t]);
         }
         QE_TRACE_POINT("align task list");
+        enter_a();
         qe_timer_start(tl_timers.align);
         AlignStats AS;
         // run_quicked ignores the Hirschberg status (quicked.c:290-291, A.7(8)); run_hirschberg returns it (149-160)
@@ -969,9 +1012,13 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     default: break;
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
+    HIP_CHECK(hipEventRecord(B.ev_done[par], C.stream_a));
+    B.ev_done_set[par] = true;
+    C.phase_w();
     B.pending = true;
     if (fetch) {
-        HIP_CHECK(hipStreamSynchronize(C.stream));
+        HIP_CHECK(hipStreamSynchronize(C.stream_w));
+        HIP_CHECK(hipStreamSynchronize(C.stream_a));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, C.ev0, C.ev1));
         B.counters[5] = (int64_t)(ms * 1e6);
@@ -1026,16 +1073,19 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
         });
         auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
         B->arena_bytes = pad(pb + 64) + pad(tb + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
-                         2 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + pad((size_t)n * 4) + 4096;
+                         4 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + 2 * pad((size_t)n * 4) + 4096;
         HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
         qe::ArenaCarver A{B->arena, 0};
         B->d_asc_p = A.take<uint8_t>(pb + 64); B->d_asc_t = A.take<uint8_t>(tb + 64);
         B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
         B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
         B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
-        B->d_pl_p = A.take<u64>(B->pl_p_words + 8); B->d_pl_t = A.take<u64>(B->pl_t_words + 8);
-        B->d_pl_pr = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr = A.take<u64>(B->pl_t_words + 8);
-        B->d_flags = A.take<u32>((size_t)n);
+        for (int q = 0; q < 2; ++q) {
+            B->d_pl_p[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[q] = A.take<u64>(B->pl_t_words + 8);
+            B->d_pl_pr[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[q] = A.take<u64>(B->pl_t_words + 8);
+            B->d_flags[q] = A.take<u32>((size_t)n);
+            HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
+        }
         // H2D: gather into pinned-size staging on the host, one copy per pool
         std::vector<uint8_t> hp(pb + 64, 0), ht(tb + 64, 0);
         for (int64_t i = 0; i < n; ++i) {
@@ -1073,7 +1123,9 @@ QE_API quicked_status_t quicked_batch_run(quicked_batch_t* batch, const quicked_
 QE_API quicked_status_t quicked_batch_sync(quicked_batch_t* batch) {
     return guard(batch, [](quicked_batch* B, void*) {
         tl_device = B->device;
-        HIP_CHECK(hipStreamSynchronize(ctx().stream));
+        Context& C = ctx();
+        HIP_CHECK(hipStreamSynchronize(C.stream_w));
+        HIP_CHECK(hipStreamSynchronize(C.stream_a));
         B->pending = false;
         return QUICKED_OK;
     }, nullptr);
@@ -1085,7 +1137,8 @@ QE_API quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double
         Arg* x = (Arg*)a;
         tl_device = B->device;
         Context& C = ctx();
-        HIP_CHECK(hipStreamSynchronize(C.stream));
+        HIP_CHECK(hipStreamSynchronize(C.stream_w));
+        HIP_CHECK(hipStreamSynchronize(C.stream_a));
         double total = 0;
         for (size_t i = 0; i < C.kev_used; ++i) {
             float ms = 0;
