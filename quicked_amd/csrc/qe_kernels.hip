@@ -727,23 +727,31 @@ struct RunSink {
     }
 };
 
-// raw-byte equality of text[h] and pattern[v] (bpm_banded.c:1012): encoded
-// equality is the same thing for upper-case ACGTN input; other input compares
-// bytes.  The three plane words of the current pattern / text block are cached
-// in registers (a path changes block every ~64 steps).
+// raw-byte equality of text[h] and pattern[v] (bpm_banded.c:1012): encoded equality is the
+// same thing for upper-case ACGTN input; other input compares bytes.  A path moves mostly along
+// a diagonal, so the test is done 64 cells at a time: the text block's planes are rotated onto
+// the pattern block's bit positions for the current diagonal (v - h) and compared once; a step
+// then reads one bit.  The word is rebuilt when the path changes block or diagonal.
 struct EqTest {
     const u64* pp; const u64* tp; const uint8_t* ap; const uint8_t* at; bool raw;
     int rp = -1, rt = -1;     // >= 0: the planes hold the reversed strings, ASCII index = r - i
-    int pblk = -1, tblk = -1;
-    u64 pa = 0, pb = 0, pn = 0, ta = 0, tb = 0, tn = 0;
+    int kp = -1, kt = -1, kd = 0;
+    u64 eqw = 0;
     __device__ __forceinline__ bool eq(int v, int h) {
         if (raw) return ap[rp >= 0 ? rp - v : v] == at[rt >= 0 ? rt - h : h];
-        if ((v >> 6) != pblk) { pblk = v >> 6; const u64* q = pp + 3 * (int64_t)pblk; pa = q[0]; pb = q[1]; pn = q[2]; }
-        if ((h >> 6) != tblk) { tblk = h >> 6; const u64* q = tp + 3 * (int64_t)tblk; ta = q[0]; tb = q[1]; tn = q[2]; }
-        const int sv = v & 63, sh = h & 63;
-        const u32 cp = (u32)((pn >> sv) & 1) * 4u | (u32)((pa >> sv) & 1) | ((u32)((pb >> sv) & 1) << 1);
-        const u32 ct = (u32)((tn >> sh) & 1) * 4u | (u32)((ta >> sh) & 1) | ((u32)((tb >> sh) & 1) << 1);
-        return (cp >= 4 && ct >= 4) || cp == ct;
+        const int d = (v - h) & 63;
+        if (((v >> 6) != kp) | ((h >> 6) != kt) | (d != kd)) {
+            kp = v >> 6; kt = h >> 6; kd = d;
+            const u64* q = pp + 3 * (int64_t)kp;
+            const u64* r = tp + 3 * (int64_t)kt;
+            const u64 pa = q[0], pb = q[1], pn = q[2];
+            u64 ta = r[0], tb = r[1], tn = r[2];
+            if (d) {   // text bit (h & 63) must land on pattern bit (v & 63): rotate left by d
+                ta = (ta << d) | (ta >> (64 - d)); tb = (tb << d) | (tb >> (64 - d)); tn = (tn << d) | (tn >> (64 - d));
+            }
+            eqw = ~((pa ^ ta) | (pb ^ tb) | (pn ^ tn));       // equal codes <=> all three plane bits equal
+        }
+        return (eqw >> (v & 63)) & 1;
     }
 };
 
@@ -795,19 +803,17 @@ __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
                 // one stored element answers both tests: {Pv[h+1], Mv[h]} of block row v / 64; rows the
                 // fill did not compute at column h read as P = 0, M = 0
                 const int evr = v - 64 * (((h + 1) >> 6) - G.prolog);
-                u32 pbit = 0, mbit = 0;
-                {
-                    const bool edge = ((h + 1) & 63) == 0;
-                    const int lo = edge ? cf_a : cf_b, hi = cl_b, slot = evr >> 6;
-                    if (evr >= 0 && slot >= lo && slot <= hi) {
-                        const int bit = v & 63;
-                        pbit = (u32)((mk64(Q[j].x, Q[j].y) >> bit) & 1);
-                        mbit = (u32)((mk64(Q[j].z, Q[j].w) >> bit) & 1);
-                    }
-                }
-                if (pbit) { R.push(OP_D); --v; go = false; }
-                else if (mbit) { R.push(OP_I); --h; go = false; }
-                else { R.push(E.eq(p0 + v, t0 + h) ? OP_M : OP_X); --h; --v; }
+                const int lo = (((h + 1) & 63) == 0) ? cf_a : cf_b, slot = evr >> 6;
+                const u32 inb = (u32)((evr >= 0) & (slot >= lo) & (slot <= cl_b));
+                const int bit = v & 63;
+                const u32 isD = inb & (u32)((mk64(Q[j].x, Q[j].y) >> bit) & 1);
+                const u32 isI = inb & (u32)((mk64(Q[j].z, Q[j].w) >> bit) & 1) & (isD ^ 1u);
+                const u32 eq = E.eq(p0 + v, t0 + h) ? 1u : 0u;
+                const int op = isD ? (int)OP_D : (isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X));
+                R.push(op);
+                v -= (int)(isI ^ 1u);
+                h -= (int)(isD ^ 1u);
+                go = (isD | isI) == 0;
                 ++steps;
             }
         }
@@ -948,17 +954,18 @@ __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
                         const int bit = (v - v_min) & 63;                   // A.7(1)
                         const u32 pb = (u32)((mk64(Q[j].x, Q[j].y) >> bit) & 1);
                         const u32 mb = (u32)((mk64(Q[j].z, Q[j].w) >> bit) & 1);
-                        const bool eq = E.eq(p0 + v, t0 + h);
+                        const u32 eq = E.eq(p0 + v, t0 + h) ? 1u : 0u;
+                        u32 isD, isI;
                         if (A.score_only) {                                 // D -> I -> match -> X (527-549)
-                            if (pb) { ++wscore; --v; go = false; }
-                            else if (mb) { ++wscore; --h; go = false; }
-                            else { wscore += eq ? 0 : 1; --h; --v; }
+                            isD = pb; isI = mb & (pb ^ 1u);
+                            wscore += (int)(isD | isI | (eq ^ 1u));
                         } else {                                            // match -> D -> I -> X (476-495)
-                            if (eq) { R.push(OP_M); --h; --v; }
-                            else if (pb) { R.push(OP_D); --v; go = false; }
-                            else if (mb) { R.push(OP_I); --h; go = false; }
-                            else { R.push(OP_X); --h; --v; }
+                            isD = pb & (eq ^ 1u); isI = mb & (eq ^ 1u) & (pb ^ 1u);
+                            R.push(isD ? (int)OP_D : (isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X)));
                         }
+                        v -= (int)(isI ^ 1u);
+                        h -= (int)(isD ^ 1u);
+                        go = (isD | isI) == 0;
                     }
                 }
             }
