@@ -217,3 +217,58 @@ def test_align_benchmark_harness(tmp_path):
             assert line == f"{sc}\t{cg}", algo
         assert "INACCURATE SCORE" not in r.stderr or algo == "edit-windowed"      # WindowEd is a bound, not exact
         assert "Alignments.Correct     100/100" in r.stderr
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_randomised_shapes_and_params(seed, monkeypatch):
+    """fuzz: ragged lengths 1..4000, mixed error rates, random algorithm parameters -- every score, status
+    and CIGAR equal to the oracle's"""
+    rng = np.random.default_rng(seed)
+    pairs = []
+    for i in range(96):
+        L = int(rng.choice([1, 2, 7, 63, 64, 65, 127, 128, 129, 500, 1000, 2500, 4000]))
+        e = float(rng.choice([0.0, 0.02, 0.1, 0.3]))
+        b = datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=seed * 1000 + i)
+        p, t = next(b.pairs())
+        if rng.random() < 0.15:
+            t = t[: max(1, len(t) - int(rng.integers(0, max(1, len(t) // 3))))]      # length mismatch
+        if rng.random() < 0.1:
+            p = p.replace(b"A", b"N", 2)
+        pairs.append((p, t))
+    for _ in range(6):
+        algo = int(rng.integers(0, 4))
+        kw = dict(algo=algo, bandwidth=int(rng.choice([1, 3, 10, 15, 40])), only_score=bool(rng.integers(0, 2)),
+                  force_scalar=bool(rng.integers(0, 2)))
+        if algo in (0, 1):
+            W = int(rng.choice([2, 3, 5, 9]))
+            kw.update(window_size=W, overlap_size=int(rng.integers(1, W)))
+        if algo == 0:
+            kw.update(hew_threshold=(int(rng.choice([10, 40])),) * 2, hew_percentage=(int(rng.choice([1, 15])),) * 2)
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            if k in ("hew_threshold", "hew_percentage"):
+                getattr(al._params, k)[0], getattr(al._params, k)[1] = v
+            else:
+                setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            est, esc, ecg = O.oracle_align(p, t, **kw)
+            # CIGAR-producing BandEd / Hirschberg below the true distance is outside the parity domain (DESIGN.md 5)
+            in_domain = not (algo in (2, 3) and not kw["only_score"]) or \
+                O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+            assert out[i][0] == est or not in_domain, (kw, i)
+            if est >= 0 and in_domain:
+                assert out[i][1] == esc, (kw, i, len(p), len(t))
+                assert out[i][2] == ecg, (kw, i)
+
+
+def test_cooperative_kernel_forced(monkeypatch):
+    """QE_COOP_G forces the G-lanes-per-alignment kernel (and its fallback pass) on shapes the host would not pick it for"""
+    batch = datagen.generate(count=300, length=6000, error=0.07, seed=91)
+    pairs = list(batch.pairs())
+    for G in ("2", "8", "32"):
+        monkeypatch.setenv("QE_COOP_G", G)
+        for bw in (8, 15, 40):
+            scores, status, _, cnt = gpu_batch(batch, algo=2, only_score=True, bandwidth=bw)
+            exp = [O.oracle_align(p, t, algo=2, only_score=True, bandwidth=bw)[1] for p, t in pairs]
+            assert scores.tolist() == exp, (G, bw)
