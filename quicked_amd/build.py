@@ -68,7 +68,38 @@ def build_harness(force=False):
     return HARNESS
 
 
+REF = "/root/reference"
+REF_CALLERS = os.path.join(ROOT, "tools", "bin", "ref_callers")
+
+
+def build_ref_callers(force=False):
+    """Drop-in proof: the reference's OWN callers -- tests/quicked_harness.c, examples/*.c and the C++
+    binding with its examples -- compiled unmodified, from where they lie under /root/reference, against
+    the REFERENCE's headers, and linked against libquicked_hip.so instead of libquicked.a.  Only where the
+    reference tree exists; the binaries travel with the snapshot like the in-tree .so files."""
+    if not os.path.isdir(os.path.join(REF, "quicked")):
+        return None
+    os.makedirs(REF_CALLERS, exist_ok=True)
+    inc = ["-I", REF, "-I", os.path.join(REF, "quicked"), "-I", os.path.join(REF, "quicked", "include")]
+    link = ["-L", HERE, "-lquicked_hip", "-Wl,-rpath," + HERE]
+    jobs = [(os.path.join(REF, "tests", "quicked_harness.c"), "quicked_harness", "gcc", [])]
+    for name in sorted(os.listdir(os.path.join(REF, "examples"))):
+        if name.endswith(".c"):
+            jobs.append((os.path.join(REF, "examples", name), "example_" + name[:-2], "gcc", []))
+    cpp_binding = os.path.join(REF, "bindings", "cpp", "quicked.cpp")
+    for name in sorted(os.listdir(os.path.join(REF, "examples", "bindings"))):
+        if name.endswith(".cpp"):
+            jobs.append((os.path.join(REF, "examples", "bindings", name), "binding_" + name[:-4] + "_cpp", "g++",
+                         [cpp_binding, "-I", os.path.join(REF, "bindings", "cpp")]))
+    for src, out, cc, extra in jobs:
+        exe = os.path.join(REF_CALLERS, out)
+        if force or _newer(exe, [src, HIP_LIB]):
+            _run([cc, "-O2", "-w", src] + extra + inc + link + ["-o", exe])
+    return REF_CALLERS
+
+
 def build_all(force=False):
     build_datagen(force)
     build_hip(force)
     build_harness(force)
+    build_ref_callers(force)

@@ -272,3 +272,27 @@ def test_cooperative_kernel_forced(monkeypatch):
             scores, status, _, cnt = gpu_batch(batch, algo=2, only_score=True, bandwidth=bw)
             exp = [O.oracle_align(p, t, algo=2, only_score=True, bandwidth=bw)[1] for p, t in pairs]
             assert scores.tolist() == exp, (G, bw)
+
+
+def test_reference_callers_link_and_run():
+    """the reference's own harness, examples and C++ binding, compiled unmodified against the reference's
+    headers and linked with libquicked_hip.so (quicked_amd/build.py: build_ref_callers): the drop-in claim.
+    Mirrors tests/CMakeLists.txt:10-13 and examples/CMakeLists.txt:14-41 of the reference."""
+    import os
+    import subprocess
+    from quicked_amd import build
+    d = build.REF_CALLERS
+    if not os.path.isdir(d) or not os.listdir(d):
+        pytest.skip("reference callers were not built (no /root/reference in the build container)")
+    run = lambda *a: subprocess.run([os.path.join(d, a[0]), *a[1:]], capture_output=True, text=True, timeout=120)
+    r = run("quicked_harness", "", "")                                  # test_empty
+    assert "ERROR: Tried to align an empty sequence" in r.stderr and r.returncode != 0
+    r = run("quicked_harness", "GATC", "GATO", "1")                     # test_nonDNA
+    assert r.returncode == 0 and "Got score: 1" in r.stdout
+    r = run("quicked_harness", "ACGTACGTAC", "ACGT", "6")
+    assert r.returncode == 0
+    for exe in sorted(os.listdir(d)):
+        if exe.startswith(("example_", "binding_")):
+            r = run(exe)
+            assert r.returncode == 0, (exe, r.stderr)
+            assert "Score: 1" in r.stdout or "score: 1" in r.stdout.lower(), (exe, r.stdout)
