@@ -296,3 +296,13 @@ def test_reference_callers_link_and_run():
             r = run(exe)
             assert r.returncode == 0, (exe, r.stderr)
             assert "Score: 1" in r.stdout or "score: 1" in r.stdout.lower(), (exe, r.stdout)
+
+
+def test_pyquicked_module_name():
+    """`from pyquicked import ...` as in the reference's examples/bindings/basic.py"""
+    import pyquicked
+    al = pyquicked.QuickedAligner()
+    al.setAlgorithm(pyquicked.QuickedAlgo.HIRSCHBERG)
+    al.align("ACGT", "ACTT")
+    assert (al.getScore(), al.getCigar()) == (1, "2M1X1M")
+    assert pyquicked.BANDED == 2 and pyquicked.QUICKED_WIP == 1
