@@ -308,7 +308,7 @@ static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs) {
         size_t bytes = (size_t)2 * (ns + 1) * 64 * 8 + (size_t)nr * 64 * 4 + (size_t)2 * nch * 64 * 2;
         B.ws_bytes += (bytes + 255) & ~(size_t)255;
         B.mat_off[g] = (int64_t)B.mat_u4;
-        if (fill) B.mat_u4 += ((size_t)(nmax + 8) / 8 + 1) * ns * 512;     // 8-column tiles, see tile_elem()
+        if (fill) B.mat_u4 += (size_t)9 * nch * ns * 64;                   // checkpoints cp[8 nch][ns][64] + carry words hw[nch][ns][64]
         B.runs_off[g] = (int64_t)B.runs_u32;
         if (want_runs) B.runs_u32 += (size_t)cap * 64;
     }

@@ -109,7 +109,9 @@ __device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32
 //           that column reads (Pv[h+1], Mv[h]; bpm_banded.c:994-1003).  Chunk column c is stored
 //           column 64k + c + 1 = st + ((c+1) >> 3) * tstride + ((c+1) & 7); c == 63 goes to st_last
 // ---------------------------------------------------------------------------
-template <bool STORE>
+// STORE: 0 nothing | 1 every column's {Pv after, Mv before} (tiled; WindowEd history) |
+//        2 a checkpoint {Pv, Mv after} every 8th column (BandEd fill: the traceback recomputes the 8 columns between)
+template <int STORE>
 __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0, u64 T1,
                                            u64 hinP, u64 hinM, u64& houtP, u64& houtM,
                                            bool act, uint4* st, int64_t st_stride, uint4* st_last) {
@@ -133,7 +135,7 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
             const u32 MHin = __builtin_amdgcn_ubfe(hm, j, 1);
             const u32 Mblo = Mlo, Mbhi = Mhi;
             block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, gP, gM);
-            if (STORE) {
+            if (STORE == 1) {
                 if (act) {
                     // chunk column c = 8 grp + j is stored column (64k) + c + 1
                     uint4* q = st + ((j + 1) >> 3) * st_stride + ((j + 1) & 7);
@@ -141,11 +143,18 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
                     *q = make_uint4(Plo, Phi, Mblo, Mbhi);   // {Pv after, Mv before} this column
                 }
             }
+            if (STORE == 2 && j == 7) {
+                if (act) {
+                    // checkpoint of stored column 64k + 8 (grp + 1): st addresses checkpoint column 8k of this slot
+                    uint4* q = (grp == 7) ? st_last : st + (grp + 1) * st_stride;
+                    *q = make_uint4(Plo, Phi, Mlo, Mhi);     // {Pv, Mv} after this column
+                }
+            }
         }
         // gP / gM hold the group's carries MSB-first in their low byte
         oP |= (u64)(__builtin_bitreverse32(gP) >> 24) << (8 * grp);
         oM |= (u64)(__builtin_bitreverse32(gM) >> 24) << (8 * grp);
-        if (STORE) st += st_stride;
+        if (STORE == 1) st += st_stride;
     }
     P = mk64(Plo, Phi);
     M = mk64(Mlo, Mhi);
@@ -159,7 +168,7 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
 // the last pattern block (level_mask, bpm_banded.c:88-102).  sP/sM collect bit
 // lvl of every column's horizontal delta, houtP/M bit 63.
 // ---------------------------------------------------------------------------
-template <bool STORE>
+template <int STORE>
 __device__ __forceinline__ void run64_general(u64& P, u64& M, u64 a, u64 b, u64 nn, u64 T0, u64 T1, u64 TN,
                                            u64 hinP, u64 hinM, u64& houtP, u64& houtM, u64& sP, u64& sM,
                                            int lvl, int ncols, bool st_on, uint4* st, int64_t st_stride, uint4* st_last) {
@@ -177,9 +186,13 @@ __device__ __forceinline__ void run64_general(u64& P, u64& M, u64 a, u64 b, u64 
             oM |= (Mh >> 63) << c;
             qP |= ((Ph >> lvl) & 1) << c;
             qM |= ((Mh >> lvl) & 1) << c;
-            if (STORE && st_on) {
+            if (STORE == 1 && st_on) {
                 uint4* q = (c == 63) ? st_last : st + (int64_t)((c + 1) >> 3) * st_stride + ((c + 1) & 7);
                 *q = make_uint4(lo32(P), hi32(P), lo32(Min), hi32(Min));
+            }
+            if (STORE == 2 && st_on && (c & 7) == 7) {
+                uint4* q = (c == 63) ? st_last : st + (int64_t)((c >> 3) + 1) * st_stride;
+                *q = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));
             }
         }
     }
@@ -342,8 +355,11 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
     u64* const Pv = W.Pv + 64 + lane;        // slot s lives at Pv[s * 64]; slot -1 is addressable
     u64* const Mv = W.Mv + 64 + lane;
     int32_t* const S = W.S + lane;           // scores[] indexed by absolute block row (bpm_banded.c:180-197)
-    uint4* const mat = FILL ? A.mat + A.g_mat_off[g] + lane * 8 : nullptr;   // tiled layout, see tile_elem()
-    const int64_t tstride = (int64_t)gns * 512;                    // uint4 units between 8-column tiles
+    // fill: per group  cp[8 nch][ns][64] = {Pv, Mv} after every 8th stored column (in the slot numbering of the
+    // chunk that starts at / contains it), then  hw[nch][ns][64] = the carry-in words of every (chunk, slot)
+    uint4* const cp = FILL ? A.mat + A.g_mat_off[g] + lane : nullptr;
+    const int64_t cps = (int64_t)gns * 64;                         // uint4 units between checkpoint columns
+    uint4* const hw = FILL ? cp + (int64_t)8 * gnch * cps : nullptr;
 
     // bpm_reset_search (bpm_banded.c:180-197)
     for (int s = 0; s < gns; ++s) {
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
             Pv[(int64_t)s * 64] = QE_ONES;
             Mv[(int64_t)s * 64] = 0;
             S[(int64_t)s * 64] = 64 * (s + 1);
-            if (FILL) mat[tile_elem(0, s, gns)] = make_uint4(~0u, ~0u, 0u, 0u);
+            if (FILL) cp[(int64_t)s * 64] = make_uint4(~0u, ~0u, 0u, 0u);
         }
     }
     if (FILL && valid) { W.cf[lane] = (int16_t)first; W.cl[lane] = (int16_t)last; }
@@ -384,20 +400,20 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
             const bool lastblk = (r == nw - 1);
             uint4* st = nullptr; uint4* st_last = nullptr;
             if (FILL) {
-                // column c of this chunk is stored as matrix column 64k + c + 1; the chunk's last
-                // column is stored under the NEXT chunk's slot numbering (bpm_banded.c:279-287)
-                st = mat + tile_elem(64 * k, i, gns);
-                st_last = mat + tile_elem(64 * k + 64, i - 1, gns);
-                if (i == 0) st_last = st + 8 * tstride;            // slot -1 does not exist; dropped row, never read
+                // the chunk's last column belongs to the NEXT chunk's slot numbering (bpm_banded.c:279-287)
+                st = cp + (int64_t)(8 * k) * cps + (int64_t)i * 64;
+                st_last = cp + (int64_t)(8 * k + 8) * cps + (int64_t)(i - 1) * 64;
+                if (i == 0) st_last = st + 8 * cps;                // slot -1 does not exist; dropped row, never read
+                if (act) hw[((int64_t)k * gns + i) * 64] = make_uint4(lo32(hinP), hi32(hinP), lo32(hinM), hi32(hinM));
             }
             u64 houtP, houtM, sP, sM;
             const bool slow = act && (ncols != 64 || hasN || lastblk);
             if (!__any(slow)) {
-                run64_fast<FILL>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, tstride, st_last);
+                run64_fast<FILL ? 2 : 0>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, cps, st_last);
                 sP = houtP; sM = houtM;
             } else {
-                run64_general<FILL>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
-                                    lastblk ? lvl_last : 63, act ? ncols : 0, true, st, tstride, st_last);
+                run64_general<FILL ? 2 : 0>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
+                                            lastblk ? lvl_last : 63, act ? ncols : 0, true, st, cps, st_last);
             }
             if (act) {
                 sc += __popcll(sP) - __popcll(sM);
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
             else if (!cut_lo && pos_h < G.prolog) first--;
             Pv[(int64_t)last * 64] = QE_ONES;
             Mv[(int64_t)last * 64] = 0;
-            if (FILL) mat[tile_elem(64 * k + 64, last, gns)] = make_uint4(~0u, ~0u, 0u, 0u);
+            if (FILL) cp[(int64_t)(8 * k + 8) * cps + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
             const int pos = last + pos_v;
             S[(int64_t)(pos + 1) * 64] = S[(int64_t)pos * 64] + 64;
             max_row_init = max(max_row_init, pos + 1);
@@ -579,10 +595,10 @@ __global__ __launch_bounds__(64) void k_banded_coop(CoopArgs A) {
             u64 houtP = 0, houtM = 0, sP, sM;
             const bool slow = act && (ncols != 64 || hasN || lastblk);
             if (!__any(slow)) {
-                run64_fast<false>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, nullptr, 0, nullptr);
+                run64_fast<0>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, nullptr, 0, nullptr);
                 sP = houtP; sM = houtM;
             } else {
-                run64_general<false>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
+                run64_general<0>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
                                      lastblk ? lvl_last : 63, act ? ncols : 0, false, nullptr, 0, nullptr);
             }
             if (act) {
@@ -756,68 +772,97 @@ struct EqTest {
 };
 
 // ===========================================================================
-// BandEd traceback (bpm_banded.c:967-1036): priority D -> I -> M/X.  One lane
-// per task walks its own path through the [col][slot][lane] matrix.  Cells
-// outside the stored band read as P = 0, M = 0 (see oracle header).
+// BandEd traceback (bpm_banded.c:967-1036): priority D -> I -> M/X.  One lane per task walks its own
+// path.  The fill left a checkpoint {Pv, Mv} every 8th column and the carry-in words of every
+// (chunk, slot); a round of this kernel recomputes, for every lane at once, the 8 columns of the
+// (column tile, block row) its path is in -- 8 block steps from the checkpoint, the same arithmetic as
+// the fill, so the same bits -- into LDS as {Pv after, Mv before} per column, then lets every lane walk
+// while it stays inside that tile.  HBM sees 2 B per block-column instead of 16.
+// Cells the fill did not compute read as P = 0, M = 0 (see oracle header).
 // ===========================================================================
 __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
+    __shared__ uint4 tile[8][64];
     const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
     const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
-    if (pair < 0) return;
-    const int m = A.T.m[t], n = A.T.n[t], p0 = A.T.p0[t], t0 = A.T.t0[t];
-    const Geom G = band_geometry(m, n, A.T.cutoff[t]);
-    const int gns = A.g_nslots[g];
-    const GroupWs W = group_ws(const_cast<uint8_t*>(A.ws), A.g_ws_off[g], gns, A.g_nrows[g], A.g_nch[g]);
+    const bool valid = pair >= 0;
+    int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0;
+    const u64* pp = A.P.pl_p; const u64* tp = A.P.pl_t;
+    EqTest E; E.pp = pp; E.tp = tp; E.ap = nullptr; E.at = nullptr; E.raw = false;
+    if (valid) {
+        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t]; cut_in = A.T.cutoff[t];
+        pp = A.P.pl_p + A.P.pl_p_off[pair]; tp = A.P.pl_t + A.P.pl_t_off[pair];
+        E.pp = pp; E.tp = tp;
+        E.ap = A.P.asc_p + A.P.asc_p_off[pair]; E.at = A.P.asc_t + A.P.asc_t_off[pair];
+        E.raw = (A.P.flags[pair] & FLAG_NONCANON) != 0;
+    }
+    const Geom G = band_geometry(m, n, cut_in);
+    const int nw = (m + 63) >> 6;
+    const int gns = A.g_nslots[g], gnch = A.g_nch[g];
+    const GroupWs W = group_ws(const_cast<uint8_t*>(A.ws), A.g_ws_off[g], gns, A.g_nrows[g], gnch);
     const int16_t* cf = W.cf + lane;
     const int16_t* cl = W.cl + lane;
-    const uint4* mat = A.mat + A.g_mat_off[g] + lane * 8;
-    EqTest E;
-    E.pp = A.P.pl_p + A.P.pl_p_off[pair] ; E.tp = A.P.pl_t + A.P.pl_t_off[pair];
-    E.ap = A.P.asc_p + A.P.asc_p_off[pair]; E.at = A.P.asc_t + A.P.asc_t_off[pair];
-    E.raw = (A.P.flags[pair] & FLAG_NONCANON) != 0;
+    const uint4* cp = A.mat + A.g_mat_off[g] + lane;
+    const int64_t cps = (int64_t)gns * 64;
+    const uint4* hw = cp + (int64_t)8 * gnch * cps;
     RunSink R;
-    R.init(A.runs + A.g_runs_off[g] + lane, A.g_runs_cap[g]);
+    R.init(valid ? A.runs + A.g_runs_off[g] + lane : nullptr, valid ? A.g_runs_cap[g] : 0);
     int h = n - 1, v = m - 1;
     u32 steps = 0;
-    // stored slot range of column h + 1: chunk K = h >> 6 needs cf[K], cf[K+1], cl[K]
-    int K = -2, cf_a = 0, cf_b = 0, cl_b = 0;
-    constexpr int LOOK = 8;       // the path is mostly diagonal: fetch the next LOOK diagonal cells at once
-    while (v >= 0 && h >= 0) {
-        uint4 Q[LOOK];
+    while (__any(valid && v >= 0 && h >= 0)) {
+        const bool act = valid && v >= 0 && h >= 0;
+        const int q = h >> 3, Rb = v >> 6, k = q >> 3;
+        int cf_a = 0, cf_b = 0, cl_b = -1;
+        if (act) {
+            cf_a = cf[(int64_t)(k + 1) * 64]; cf_b = cf[(int64_t)k * 64]; cl_b = cl[(int64_t)k * 64];
+            const int pos_v = k - G.prolog, s = Rb - pos_v;
+            const bool computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
+            if (computed) {
+                const uint4 c0 = cp[(int64_t)q * cps + (int64_t)s * 64];
+                const uint4 w0 = hw[((int64_t)k * gns + s) * 64];
+                u64 P = mk64(c0.x, c0.y), M = mk64(c0.z, c0.w);
+                const u64 hinP = mk64(w0.x, w0.y), hinM = mk64(w0.z, w0.w);
+                u64 a, b, nn, T0, T1, TN;
+                load_planes(pp, p0 + 64 * Rb, a, b, nn);
+                load_planes(tp, t0 + 64 * k, T0, T1, TN);
+                const int c_first = (8 * q) & 63;
 #pragma unroll
-        for (int j = 0; j < LOOK; ++j) {
-            const int hj = max(h - j, 0), vj = max(v - j, 0);
-            const int evr = vj - 64 * (((hj + 1) >> 6) - G.prolog);
-            const int sp = min(max(evr >> 6, 0), gns - 1);
-            Q[j] = mat[tile_elem(hj + 1, sp, gns)];
-        }
-        bool go = true;
-#pragma unroll
-        for (int j = 0; j < LOOK; ++j) {
-            if (go && v >= 0 && h >= 0) {
-                if ((h >> 6) != K) {
-                    K = h >> 6;
-                    cf_a = cf[(int64_t)(K + 1) * 64]; cf_b = cf[(int64_t)K * 64];
-                    cl_b = cl[(int64_t)K * 64];
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c_first + j;
+                    const u64 m0 = (u64)0 - ((T0 >> c) & 1), m1 = (u64)0 - ((T1 >> c) & 1);
+                    const u64 acgt = ~(a ^ m0) & ~(b ^ m1) & ~nn;
+                    const u64 Eq = ((TN >> c) & 1) ? nn : acgt;
+                    const u64 Min = M;
+                    u64 Ph, Mh;
+                    block_step(Eq, P, M, (u32)((hinP >> c) & 1), (u32)((hinM >> c) & 1), Ph, Mh);
+                    tile[j][lane] = make_uint4(lo32(P), hi32(P), lo32(Min), hi32(Min));   // columns past tlen are never read
                 }
-                // one stored element answers both tests: {Pv[h+1], Mv[h]} of block row v / 64; rows the
-                // fill did not compute at column h read as P = 0, M = 0
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tile[j][lane] = make_uint4(0u, 0u, 0u, 0u);
+                // the row the band bookkeeping creates at the end of a chunk: Pv = ~0, Mv = 0 (bpm_banded.c:910)
+                if (s == cl_b + 1 && (q & 7) == 7) tile[7][lane] = make_uint4(~0u, ~0u, 0u, 0u);
+            }
+        }
+        bool in_tile = act;
+        while (__any(in_tile)) {
+            if (in_tile) {
+                const uint4 el = tile[h & 7][lane];
                 const int evr = v - 64 * (((h + 1) >> 6) - G.prolog);
                 const int lo = (((h + 1) & 63) == 0) ? cf_a : cf_b, slot = evr >> 6;
                 const u32 inb = (u32)((evr >= 0) & (slot >= lo) & (slot <= cl_b));
                 const int bit = v & 63;
-                const u32 isD = inb & (u32)((mk64(Q[j].x, Q[j].y) >> bit) & 1);
-                const u32 isI = inb & (u32)((mk64(Q[j].z, Q[j].w) >> bit) & 1) & (isD ^ 1u);
+                const u32 isD = inb & (u32)((mk64(el.x, el.y) >> bit) & 1);
+                const u32 isI = inb & (u32)((mk64(el.z, el.w) >> bit) & 1) & (isD ^ 1u);
                 const u32 eq = E.eq(p0 + v, t0 + h) ? 1u : 0u;
-                const int op = isD ? (int)OP_D : (isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X));
-                R.push(op);
+                R.push(isD ? (int)OP_D : (isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X)));
                 v -= (int)(isI ^ 1u);
                 h -= (int)(isD ^ 1u);
-                go = (isD | isI) == 0;
                 ++steps;
+                in_tile = v >= 0 && h >= 0 && (h >> 3) == q && (v >> 6) == Rb;
             }
         }
     }
+    if (!valid) return;
     R.push_n(OP_I, h + 1);
     R.push_n(OP_D, v + 1);
     R.flush();
@@ -906,9 +951,9 @@ __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
                 const bool slow = act && (ncols != 64 || hasN);
                 const bool keep = act && i >= blk_min && 64 * j + 64 >= col_min;
                 if (!__any(slow)) {
-                    run64_fast<true>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, keep, st, tstride, st + 8 * tstride);
+                    run64_fast<1>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, keep, st, tstride, st + 8 * tstride);
                 } else {
-                    run64_general<true>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
+                    run64_general<1>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
                                         63, act ? ncols : 0, keep, st, tstride, st + 8 * tstride);
                 }
                 if (act) { Pv[(int64_t)i * 64] = P; Mv[(int64_t)i * 64] = M; steps += (u32)ncols; }
