@@ -808,29 +808,38 @@ __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
     R.init(valid ? A.runs + A.g_runs_off[g] + lane : nullptr, valid ? A.g_runs_cap[g] : 0);
     int h = n - 1, v = m - 1;
     u32 steps = 0;
+    // what a round needs besides the checkpoint changes rarely: band-edge records and text planes per chunk (every 8
+    // tiles), carry words per (chunk, slot), pattern planes per block row -- kept in registers, reloaded on change
+    int ck = -1, cs = -1, cR = -1;
+    int cf_a = 0, cf_b = 0, cl_b = -1;
+    u64 T0 = 0, T1 = 0, TN = 0, hinP = 0, hinM = 0, pa = 0, pb = 0, pn = 0;
     while (__any(valid && v >= 0 && h >= 0)) {
         const bool act = valid && v >= 0 && h >= 0;
         const int q = h >> 3, Rb = v >> 6, k = q >> 3;
-        int cf_a = 0, cf_b = 0, cl_b = -1;
         if (act) {
-            cf_a = cf[(int64_t)(k + 1) * 64]; cf_b = cf[(int64_t)k * 64]; cl_b = cl[(int64_t)k * 64];
+            if (k != ck) {
+                ck = k; cs = -1;
+                cf_a = cf[(int64_t)(k + 1) * 64]; cf_b = cf[(int64_t)k * 64]; cl_b = cl[(int64_t)k * 64];
+                load_planes(tp, t0 + 64 * k, T0, T1, TN);
+            }
             const int pos_v = k - G.prolog, s = Rb - pos_v;
             const bool computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
             if (computed) {
                 const uint4 c0 = cp[(int64_t)q * cps + (int64_t)s * 64];
-                const uint4 w0 = hw[((int64_t)k * gns + s) * 64];
+                if (s != cs) {
+                    cs = s;
+                    const uint4 w0 = hw[((int64_t)k * gns + s) * 64];
+                    hinP = mk64(w0.x, w0.y); hinM = mk64(w0.z, w0.w);
+                }
+                if (Rb != cR) { cR = Rb; load_planes(pp, p0 + 64 * Rb, pa, pb, pn); }
                 u64 P = mk64(c0.x, c0.y), M = mk64(c0.z, c0.w);
-                const u64 hinP = mk64(w0.x, w0.y), hinM = mk64(w0.z, w0.w);
-                u64 a, b, nn, T0, T1, TN;
-                load_planes(pp, p0 + 64 * Rb, a, b, nn);
-                load_planes(tp, t0 + 64 * k, T0, T1, TN);
                 const int c_first = (8 * q) & 63;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = c_first + j;
                     const u64 m0 = (u64)0 - ((T0 >> c) & 1), m1 = (u64)0 - ((T1 >> c) & 1);
-                    const u64 acgt = ~(a ^ m0) & ~(b ^ m1) & ~nn;
-                    const u64 Eq = ((TN >> c) & 1) ? nn : acgt;
+                    const u64 acgt = ~(pa ^ m0) & ~(pb ^ m1) & ~pn;
+                    const u64 Eq = ((TN >> c) & 1) ? pn : acgt;
                     const u64 Min = M;
                     u64 Ph, Mh;
                     block_step(Eq, P, M, (u32)((hinP >> c) & 1), (u32)((hinM >> c) & 1), Ph, Mh);
