@@ -157,13 +157,15 @@ def main():
         if args.workload == "banded_score":
             kernel, alg_bytes, work_blocks = "k_banded<false> (BandEd score-only)", per_launch_bytes, int(counters[0])
         else:
-            # ASCII in + 16 B per stored block-column + 16 B per traceback step + ops out
+            # ASCII in + 16 B per stored block-column + 16 B per traceback step + ops out.  NB the kernels
+            # store a 16-byte checkpoint every 8th column and recompute the rest: the HBM traffic they
+            # generate (roofline.traffic) is BELOW this figure, so frac can exceed the naive bound
             alg_bytes = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
             kernel, work_blocks = "k_banded<true> (BandEd fill)", int(counters[1])
         traffic = None
         try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pm = json.load(f)["banded_score" if args.workload == "banded_score" else "quicked"]
+                pm = json.load(f)["banded_score" if args.workload == "banded_score" else "quicked_checkpointed"]
             key = "k_banded<false>" if args.workload == "banded_score" else "k_banded<true>"
             if args.pairs == 100000 and args.length == 10000:
                 traffic = pm[key]["hbm_bytes"]
