@@ -65,8 +65,11 @@ def lib():
         return _LIB
     path = build.HIP_LIB
     if not os.path.exists(path):
-        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(hipcc --offload-arch=gfx950); there is no fallback path")
+        try:
+            build.build_hip()            # hipcc --offload-arch=gfx950, in-tree
+        except Exception as e:           # noqa: BLE001
+            raise RuntimeError(f"{path} is missing and could not be built ({e}): run "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`; there is no fallback path") from e
     L = C.CDLL(path)
     L.quicked_check_error.restype = C.c_bool
     L.quicked_check_error.argtypes = [C.c_int]

@@ -306,3 +306,32 @@ def test_pyquicked_module_name():
     al.align("ACGT", "ACTT")
     assert (al.getScore(), al.getCigar()) == (1, "2M1X1M")
     assert pyquicked.BANDED == 2 and pyquicked.QUICKED_WIP == 1
+
+
+def test_config_shape_properties_and_shard_invariance():
+    """configs[1]/[2] shape (10 kb, 5 %) at a size the oracle cannot sweep in full: size-independent properties.
+    * QuickEd's CIGAR is a valid alignment whose edit count is its score, and that score is the exact distance;
+    * BandEd score-only (bandwidth 15) returns the same exact distance;
+    * sharding the pairs over 'ranks' (the multi-GPU rule of bench.py) changes nothing."""
+    lib = O.oracle()
+    N = 3072
+    whole = datagen.generate(N, 10000, 0.05, seed=0x51CED)
+    s_q, st_q, cig, _ = gpu_batch(whole, algo=0)
+    s_b, st_b, _, _ = gpu_batch(whole, algo=2, only_score=True, bandwidth=15)
+    assert (st_q == capi.QUICKED_WIP).all() and (st_b == capi.QUICKED_WIP).all()
+    assert (s_q == s_b).all()
+    pairs = list(whole.pairs())
+    for i in range(0, N, 7):                       # exact distance on a stride (full-height DP is the slow part)
+        p, t = pairs[i]
+        assert lib.qo_exact_distance(p, len(p), t, len(t)) == s_q[i]
+    for i, (p, t) in enumerate(pairs):
+        ops = O.rle_to_ops(cig[i])
+        assert lib.qo_cigar_check(p, len(p), t, len(t), ops, len(ops)), i
+        assert lib.qo_cigar_score(ops, len(ops)) == s_q[i], i
+    # shard invariance: 4 'ranks' of N/4 pairs each, generated independently from (seed, first)
+    per = N // 4
+    for r in range(4):
+        shard = datagen.generate(per, 10000, 0.05, seed=0x51CED, first=r * per)
+        s, st, cg, _ = gpu_batch(shard, algo=0)
+        assert (s == s_q[r * per:(r + 1) * per]).all()
+        assert cg == cig[r * per:(r + 1) * per]
