@@ -1,7 +1,7 @@
 // qe_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the QuickEd hot path.
 //
-// Execution model (DESIGN.md "Kernels"): ONE LANE PER ALIGNMENT, 64 alignments
-// per wavefront, no cross-lane traffic.  The reference walks a text column at a
+// Execution model: ONE LANE PER ALIGNMENT, 64 alignments per
+// wavefront, no cross-lane traffic.  The reference walks a text column at a
 // time over all band blocks and carries one PHout/MHout bit from block to block
 // (bpm_banded.c:232-262).  Here a lane instead walks ONE 64-row block over a
 // whole 64-column chunk with the block's Pv/Mv in VGPRs, reading the 64 carry-in
@@ -12,12 +12,15 @@
 // the reference's; band bookkeeping then runs per lane exactly as the
 // reference's does every 64 columns (bpm_banded.c:889-922 / 264-301).
 //
-// The 64-column inner loop is pure 32-bit integer VALU on registers (~43 ops
+// The 64-column inner loop is pure 32-bit integer VALU on registers (~36 ops
 // per 64 DP cells); global memory is touched once per (block, chunk): 16 B of
 // state + 24 B of pattern planes in, 20 B out, all as [row][lane] rows.
 //
-// No MFMA (bit manipulation, not a contraction), no LDS (nothing is shared
-// between lanes), no CUDA-compat paths.
+// Kernels: k_pack (ASCII -> bit planes by ballot), k_banded<false/true> (BandEd
+// score / fill with checkpoints), k_banded_coop (G lanes per alignment),
+// k_traceback (tile recompute in LDS + path), k_windowed (WindowEd chain),
+// k_join (Hirschberg midpoint), k_format_segs / k_scan_offsets (CIGAR strings).
+// No MFMA (bit manipulation, not a contraction), no CUDA-compat paths.
 #include <hip/hip_runtime.h>
 #include "qe_types.h"
 
@@ -29,12 +32,11 @@ __device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
 __device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
 __device__ __forceinline__ u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
-// Stored-column layout of the fill matrix and of the window history: 8 columns of
-// one (slot, lane) are contiguous (one 128-byte line), lanes next to each other:
+// Stored-column layout of the WindowEd history (every column of the reachable blocks): 8
+// columns of one (block, lane) are contiguous (one 128-byte line), lanes next to each other:
 //   element(col, slot, lane) = ((col >> 3) * nslots + slot) * 512 + lane * 8 + (col & 7)     [16-byte units]
-// A lane's traceback walks columns one at a time, so 7 of 8 steps stay inside a
-// line it already pulled; the fill's 8 consecutive column stores of a block
-// complete every line they touch.
+// A lane's in-window traceback walks columns one at a time, so 7 of 8 steps stay inside a
+// line it already pulled; 8 consecutive column stores of a block complete every line they touch.
 __device__ __forceinline__ int64_t tile_elem(int col, int slot, int nslots) {
     return ((int64_t)(col >> 3) * nslots + slot) * 512 + (col & 7);
 }
