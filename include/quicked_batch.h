@@ -11,6 +11,8 @@
 #ifndef QUICKED_BATCH_H
 #define QUICKED_BATCH_H
 
+#include <stddef.h>
+
 #include "quicked.h"
 
 #ifdef __cplusplus
@@ -30,6 +32,11 @@ quicked_status_t quicked_align_batch(quicked_aligner_t* aligner, int n,
                                      const char* const* texts, const int* text_lens,
                                      int* scores_out, char** cigars_out,
                                      quicked_status_t* status_out);
+
+/* Pinned host memory for sequence pools: quicked_batch_create() DMAs straight from it (pageable pools
+ * are pipelined through pinned staging instead). */
+void* quicked_host_alloc(size_t bytes);
+void quicked_host_free(void* p);
 
 /* ---- resident batches: upload once, run many times (what bench.py times) --- */
 typedef struct quicked_batch quicked_batch_t;

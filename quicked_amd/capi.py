@@ -54,7 +54,7 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_align", "quicked_set_device", "quicked_align_batch", "quicked_batch_create",
            "quicked_batch_destroy", "quicked_batch_run", "quicked_batch_sync", "quicked_batch_scores",
            "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters",
-           "quicked_batch_kernel_time"]
+           "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free"]
 
 _LIB = None
 
@@ -96,6 +96,10 @@ def lib():
     L.quicked_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
     L.quicked_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.quicked_host_alloc.restype = C.c_void_p
+    L.quicked_host_alloc.argtypes = [C.c_size_t]
+    L.quicked_host_free.argtypes = [C.c_void_p]
+    L.quicked_host_free.restype = None
     _LIB = L
     return L
 
@@ -233,3 +237,27 @@ class ResidentBatch:
 
     def __del__(self):
         self.close()
+
+
+def pinned_copy(batch):
+    """The same pairs with the two byte pools in pinned host memory (quicked_host_alloc)."""
+    import numpy as _np
+    L = lib()
+    out = []
+    for pool in (batch.pattern_pool, batch.text_pool):
+        ptr = L.quicked_host_alloc(max(pool.nbytes, 1))
+        if not ptr:
+            raise MemoryError("quicked_host_alloc failed")
+        arr = _np.ctypeslib.as_array((C.c_uint8 * max(pool.nbytes, 1)).from_address(ptr))
+        arr[:pool.nbytes] = pool
+        out.append((arr, ptr))
+    from .datagen import PairBatch
+    pb = PairBatch(out[0][0], batch.pattern_off, batch.pattern_len, out[1][0], batch.text_off, batch.text_len)
+    pb._pinned = [p for _, p in out]
+    return pb
+
+
+def pinned_free(pb):
+    for p in getattr(pb, "_pinned", []):
+        lib().quicked_host_free(p)
+    pb._pinned = []

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "quicked.h"
@@ -1030,6 +1031,56 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
 
 }  // namespace qe
 
+// ---------------------------------------------------------------------------
+// Host -> HBM upload of a byte span.  Pinned (hipHostMalloc / registered) memory goes straight to the DMA
+// engine; pageable memory is pipelined through pinned staging slots by a few worker threads, each with its
+// own stream, so the copy into staging overlaps the DMA of the previous slot.
+// ---------------------------------------------------------------------------
+namespace qe {
+static bool host_is_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+static void upload_span(uint8_t* dst, const uint8_t* src, size_t bytes, int device) {
+    if (bytes == 0) return;
+    if (host_is_pinned(src)) {
+        HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        return;
+    }
+    const size_t SLOT = (size_t)16 << 20;
+    const int nthreads = (int)std::min<size_t>(8, std::max<size_t>(1, bytes / (4 * SLOT)));
+    std::vector<std::thread> th;
+    std::vector<int> err((size_t)nthreads, 0);
+    for (int w = 0; w < nthreads; ++w) {
+        th.emplace_back([=, &err]() {
+            if (hipSetDevice(device) != hipSuccess) { err[(size_t)w] = 1; return; }
+            const size_t lo = bytes * (size_t)w / (size_t)nthreads, hi = bytes * (size_t)(w + 1) / (size_t)nthreads;
+            hipStream_t st; uint8_t* stage[2] = {nullptr, nullptr}; hipEvent_t ev[2];
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { err[(size_t)w] = 1; return; }
+            for (int i = 0; i < 2; ++i) {
+                if (hipHostMalloc((void**)&stage[i], SLOT, hipHostMallocDefault) != hipSuccess) err[(size_t)w] = 1;
+                if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) err[(size_t)w] = 1;
+            }
+            int slot = 0;
+            for (size_t o = lo; o < hi && !err[(size_t)w]; o += SLOT, slot ^= 1) {
+                const size_t len = std::min(SLOT, hi - o);
+                if (hipEventSynchronize(ev[slot]) != hipSuccess) err[(size_t)w] = 1;     // the slot's previous DMA is done
+                memcpy(stage[slot], src + o, len);
+                if (hipMemcpyAsync(dst + o, stage[slot], len, hipMemcpyHostToDevice, st) != hipSuccess) err[(size_t)w] = 1;
+                if (hipEventRecord(ev[slot], st) != hipSuccess) err[(size_t)w] = 1;
+            }
+            (void)hipStreamSynchronize(st);
+            for (int i = 0; i < 2; ++i) { if (stage[i]) (void)hipHostFree(stage[i]); (void)hipEventDestroy(ev[i]); }
+            (void)hipStreamDestroy(st);
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int e : err) if (e) throw HipError{hipErrorUnknown, "upload_span", __LINE__};
+}
+}  // namespace qe
+
 // ===========================================================================
 // C-ABI
 // ===========================================================================
@@ -1041,6 +1092,13 @@ static quicked_status_t guard(quicked_batch* B, quicked_status_t (*fn)(quicked_b
     }
     catch (const std::bad_alloc&) { fprintf(stderr, "[quicked_hip] out of host memory\n"); return QUICKED_ERROR; }
 }
+
+QE_API void* quicked_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+QE_API void quicked_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 QE_API quicked_status_t quicked_set_device(int device) {
     int count = 0;
@@ -1057,15 +1115,30 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
         Context& C = ctx();
         B->n = n; B->device = C.device;
         B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
-        // compact the pools (inputs may be sparse in the caller's buffers)
+        // A pool whose pairs lie (nearly) back to back is uploaded as the byte span it is, offsets kept;
+        // a sparse one is compacted first.
         B->p_off.resize((size_t)n); B->t_off.resize((size_t)n); B->plp_off.resize((size_t)n); B->plt_off.resize((size_t)n);
         size_t pb = 0, tb = 0;
+        int64_t p_lo = INT64_MAX, p_hi = 0, t_lo = INT64_MAX, t_hi = 0;
         for (int64_t i = 0; i < n; ++i) {
-            B->p_off[i] = (int64_t)pb; pb += (size_t)pattern_len[i];
-            B->t_off[i] = (int64_t)tb; tb += (size_t)text_len[i];
+            pb += (size_t)pattern_len[i]; tb += (size_t)text_len[i];
+            if (pattern_len[i]) { p_lo = std::min(p_lo, pattern_off[i]); p_hi = std::max(p_hi, pattern_off[i] + pattern_len[i]); }
+            if (text_len[i]) { t_lo = std::min(t_lo, text_off[i]); t_hi = std::max(t_hi, text_off[i] + text_len[i]); }
             B->plp_off[i] = (int64_t)B->pl_p_words; B->pl_p_words += (size_t)3 * ((size_t)(pattern_len[i] + 63) / 64 + 2);
             B->plt_off[i] = (int64_t)B->pl_t_words; B->pl_t_words += (size_t)3 * ((size_t)(text_len[i] + 63) / 64 + 2);
         }
+        if (p_lo == INT64_MAX) { p_lo = 0; p_hi = 0; }
+        if (t_lo == INT64_MAX) { t_lo = 0; t_hi = 0; }
+        const bool p_dense = (size_t)(p_hi - p_lo) <= pb + pb / 4 + ((size_t)1 << 20);
+        const bool t_dense = (size_t)(t_hi - t_lo) <= tb + tb / 4 + ((size_t)1 << 20);
+        {
+            size_t po = 0, to = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                B->p_off[i] = p_dense ? pattern_off[i] - p_lo : (int64_t)po; po += (size_t)pattern_len[i];
+                B->t_off[i] = t_dense ? text_off[i] - t_lo : (int64_t)to; to += (size_t)text_len[i];
+            }
+        }
+        const size_t p_bytes = p_dense ? (size_t)(p_hi - p_lo) : pb, t_bytes = t_dense ? (size_t)(t_hi - t_lo) : tb;
         B->order.resize((size_t)n);
         std::iota(B->order.begin(), B->order.end(), 0);
         std::stable_sort(B->order.begin(), B->order.end(), [&](int a, int b) {
@@ -1073,11 +1146,11 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
             return la > lb;
         });
         auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
-        B->arena_bytes = pad(pb + 64) + pad(tb + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
+        B->arena_bytes = pad(p_bytes + 64) + pad(t_bytes + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
                          4 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + 2 * pad((size_t)n * 4) + 4096;
         HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
         qe::ArenaCarver A{B->arena, 0};
-        B->d_asc_p = A.take<uint8_t>(pb + 64); B->d_asc_t = A.take<uint8_t>(tb + 64);
+        B->d_asc_p = A.take<uint8_t>(p_bytes + 64); B->d_asc_t = A.take<uint8_t>(t_bytes + 64);
         B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
         B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
         B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
@@ -1087,14 +1160,15 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
             B->d_flags[q] = A.take<u32>((size_t)n);
             HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
         }
-        // H2D: gather into pinned-size staging on the host, one copy per pool
-        std::vector<uint8_t> hp(pb + 64, 0), ht(tb + 64, 0);
-        for (int64_t i = 0; i < n; ++i) {
-            if (pattern_len[i]) memcpy(hp.data() + B->p_off[i], pattern_pool + pattern_off[i], (size_t)pattern_len[i]);
-            if (text_len[i]) memcpy(ht.data() + B->t_off[i], text_pool + text_off[i], (size_t)text_len[i]);
-        }
-        HIP_CHECK(hipMemcpyAsync(B->d_asc_p, hp.data(), hp.size(), hipMemcpyHostToDevice, C.stream));
-        HIP_CHECK(hipMemcpyAsync(B->d_asc_t, ht.data(), ht.size(), hipMemcpyHostToDevice, C.stream));
+        auto send = [&](uint8_t* dst, const char* pool, const int64_t* off, const int32_t* len, const std::vector<int64_t>& doff,
+                        bool dense, int64_t lo, size_t bytes) {
+            if (dense) { upload_span(dst, (const uint8_t*)pool + lo, bytes, C.device); return; }
+            std::vector<uint8_t> h(bytes + 64, 0);
+            for (int64_t i = 0; i < n; ++i) if (len[i]) memcpy(h.data() + doff[(size_t)i], pool + off[i], (size_t)len[i]);
+            upload_span(dst, h.data(), bytes, C.device);
+        };
+        send(B->d_asc_p, pattern_pool, pattern_off, pattern_len, B->p_off, p_dense, p_lo, p_bytes);
+        send(B->d_asc_t, text_pool, text_off, text_len, B->t_off, t_dense, t_lo, t_bytes);
         h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
         h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
         h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);

@@ -335,3 +335,24 @@ def test_config_shape_properties_and_shard_invariance():
         s, st, cg, _ = gpu_batch(shard, algo=0)
         assert (s == s_q[r * per:(r + 1) * per]).all()
         assert cg == cig[r * per:(r + 1) * per]
+
+
+def test_upload_paths_agree():
+    """dense pools go up as one span (pinned: straight DMA; pageable: pipelined staging), sparse pools are compacted first"""
+    batch = datagen.generate(count=500, length=3000, error=0.05, seed=5)
+    ref, _, _, _ = gpu_batch(batch, algo=2, only_score=True)
+    pinned = capi.pinned_copy(batch)
+    got, _, _, _ = gpu_batch(pinned, algo=2, only_score=True)
+    capi.pinned_free(pinned)
+    assert (got == ref).all()
+    # a sparse layout: every pair in its own 64 KiB stride
+    stride = 1 << 16
+    pp = np.zeros(len(batch) * stride, dtype=np.uint8); tp = np.zeros(len(batch) * stride, dtype=np.uint8)
+    poff = np.arange(len(batch), dtype=np.int64) * stride + 17
+    toff = np.arange(len(batch), dtype=np.int64) * stride + 3
+    for i, (p, t) in enumerate(batch.pairs()):
+        pp[poff[i]:poff[i] + len(p)] = np.frombuffer(p, dtype=np.uint8)
+        tp[toff[i]:toff[i] + len(t)] = np.frombuffer(t, dtype=np.uint8)
+    sparse = datagen.PairBatch(pp, poff, batch.pattern_len, tp, toff, batch.text_len)
+    got, _, _, _ = gpu_batch(sparse, algo=2, only_score=True)
+    assert (got == ref).all()
