@@ -356,3 +356,30 @@ def test_upload_paths_agree():
     sparse = datagen.PairBatch(pp, poff, batch.pattern_len, tp, toff, batch.text_len)
     got, _, _, _ = gpu_batch(sparse, algo=2, only_score=True)
     assert (got == ref).all()
+
+
+def test_long_reads_like_the_reference_suite():
+    """the reference's own long-sequence tests (tests/CMakeLists.txt:23-29): 1 Mb pairs with 10 edits, and a
+    500 kb pair at ONT-like 7 % error that goes through all bound stages and five Hirschberg levels"""
+    long_few = datagen.generate(2, 1000000, 10, seed=61)
+    ont_like = datagen.generate(1, 500000, 0.07, seed=62, indels_num=3, indels_len=3000)
+    for batch in (long_few, ont_like):
+        scores, status, cig, _ = gpu_batch(batch, algo=0)
+        for i, (p, t) in enumerate(batch.pairs()):
+            st, sc, cg = O.oracle_align(p, t, algo=0)
+            assert (status[i], scores[i]) == (st, sc)
+            assert cig[i] == cg
+
+
+def test_many_short_pairs():
+    """100 bp reads (the only workload the reference documents numbers for, tools/README.md:76): 50 k pairs"""
+    batch = datagen.generate(50000, 100, 0.05, seed=63)
+    scores, status, cig, _ = gpu_batch(batch, algo=0)
+    pairs = list(batch.pairs())
+    for i in range(0, len(pairs), 97):
+        st, sc, cg = O.oracle_align(*pairs[i], algo=0)
+        assert (status[i], scores[i], cig[i]) == (st, sc, cg)
+    lib = O.oracle()
+    for c, sc in zip(cig[:2000], scores[:2000]):
+        ops = O.rle_to_ops(c)
+        assert lib.qo_cigar_score(ops, len(ops)) == sc
