@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--bandwidth", type=int, default=15)
     ap.add_argument("--workload", choices=["banded_score", "quicked"], default="banded_score")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-each-step", action="store_true",
+                    help="profiling aid: no overlap between consecutive runs, so per-kernel durations are those of a kernel alone")
     ap.add_argument("--seed", type=int, default=0x51CED)
     args = ap.parse_args()
 
@@ -126,7 +128,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = rb.run(params, sync=False)     # results stay resident in HBM; the driver still syncs where a stage needs host decisions
+        st = rb.run(params, sync=args.sync_each_step)     # results stay resident in HBM; the driver still syncs where a stage needs host decisions
         assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
     rb.sync()
     barrier()

@@ -736,6 +736,17 @@ struct RunSink {
         nops += count;
         edits += (op != (int)OP_M) ? count : 0;
     }
+    // predicated form for straight-line walks: nothing happens when !pred; one guarded store, no other branch
+    __device__ __forceinline__ void emit(int op, int count, bool pred) {
+        const bool brk = pred && op != cur_op;
+        const bool st = brk && cur_len > 0;
+        if (st && nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
+        nruns += st ? 1 : 0;
+        cur_len = brk ? count : cur_len + (pred ? count : 0);
+        cur_op = brk ? op : cur_op;
+        nops += pred ? count : 0;
+        edits += (pred && op != (int)OP_M) ? count : 0;
+    }
     __device__ __forceinline__ void flush() {
         if (cur_len > 0) {
             if (nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
@@ -773,6 +784,37 @@ struct EqTest {
     }
 };
 
+// One traceback round over an 8-column tile held in registers: tP/tM/tE[j] = {Pv after, Mv before, Eq}
+// of tile column j for the lane's block row Rb.  Priority D -> I -> M/X (bpm_banded.c:994-1020).  A lane
+// enters at column h & 7, and leaves to the left (h < 8 q), upwards (v leaves block Rb) or at an edge.
+template <bool RAW>
+__device__ __forceinline__ void walk_tile(const u64 (&tP)[8], const u64 (&tM)[8], const u64 (&tE)[8], bool in_tile,
+                                          u32 inb_same, u32 inb_7, int Rb, int& v, int& h, u32& steps,
+                                          RunSink& R, EqTest& E, int p0, int t0) {
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const bool mine = in_tile && (h & 7) == j;
+        const u32 inb = (j == 7) ? inb_7 : inb_same;
+        const int bit = v & 63;
+        // deletions: Pv bits bit, bit-1, ... while set (v moves up, h stays)
+        const u64 x = tP[j] << (63 - bit);
+        int r = inb ? min(__clzll((long long)~x), bit + 1) : 0;
+        if (!mine) r = 0;
+        R.emit((int)OP_D, r, r > 0);
+        const bool up = r == bit + 1;                 // the run reached the top of the block: next round, same column
+        const bool go = mine && !up;
+        const int b1 = (bit - r) & 63;
+        const u32 isI = inb & (u32)((tM[j] >> b1) & 1);
+        u32 eq = (u32)((tE[j] >> b1) & 1);
+        if (RAW) { if (go && E.raw) eq = E.eq(p0 + v - r, t0 + h) ? 1u : 0u; }
+        R.emit(isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X), 1, go);
+        v -= r + ((go && !isI) ? 1 : 0);
+        h -= go ? 1 : 0;
+        steps += (u32)r + (go ? 1u : 0u);
+        in_tile = in_tile && !(mine && up) && v >= 0 && (v >> 6) == Rb;
+    }
+}
+
 // ===========================================================================
 // BandEd traceback (bpm_banded.c:967-1036): priority D -> I -> M/X.  One lane per task walks its own
 // path.  The fill left a checkpoint {Pv, Mv} every 8th column and the carry-in words of every
@@ -783,7 +825,6 @@ struct EqTest {
 // Cells the fill did not compute read as P = 0, M = 0 (see oracle header).
 // ===========================================================================
 __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
-    __shared__ uint4 tile[8][64];
     const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
     const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
     const bool valid = pair >= 0;
@@ -797,6 +838,7 @@ __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
         E.ap = A.P.asc_p + A.P.asc_p_off[pair]; E.at = A.P.asc_t + A.P.asc_t_off[pair];
         E.raw = (A.P.flags[pair] & FLAG_NONCANON) != 0;
     }
+    const bool any_raw = __any(E.raw);
     const Geom G = band_geometry(m, n, cut_in);
     const int nw = (m + 63) >> 6;
     const int gns = A.g_nslots[g], gnch = A.g_nch[g];
@@ -818,14 +860,30 @@ __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
     while (__any(valid && v >= 0 && h >= 0)) {
         const bool act = valid && v >= 0 && h >= 0;
         const int q = h >> 3, Rb = v >> 6, k = q >> 3;
+        // the tile: per column {Pv after, Mv before, Eq}, in registers (the loops over its columns are unrolled)
+        u64 tP[8], tM[8], tE[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { tP[j] = 0; tM[j] = 0; tE[j] = 0; }
+        u32 inb_same = 0, inb_7 = 0;
         if (act) {
             if (k != ck) {
                 ck = k; cs = -1;
                 cf_a = cf[(int64_t)(k + 1) * 64]; cf_b = cf[(int64_t)k * 64]; cl_b = cl[(int64_t)k * 64];
                 load_planes(tp, t0 + 64 * k, T0, T1, TN);
             }
+            const int s = Rb - (k - G.prolog);
+            if (Rb != cR) { cR = Rb; load_planes(pp, p0 + 64 * Rb, pa, pb, pn); }
+            // a step at column h reads Pv of stored column h + 1: inside the band of THAT column's chunk or 0
+            // (oracle header).  Columns 0..6 of the tile share this chunk; column 7 may be the last of it.
+            inb_same = (u32)((s >= 0) & (s >= cf_b) & (s <= cl_b));
+            inb_7 = ((q & 7) == 7) ? (u32)((s >= 1) & (s - 1 >= cf_a) & (s - 1 <= cl_b)) : inb_same;
+        }
+        const int c_first = (8 * q) & 63;
+        u64 P = 0, M = 0;
+        bool computed = false;
+        if (act) {
             const int pos_v = k - G.prolog, s = Rb - pos_v;
-            const bool computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
+            computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
             if (computed) {
                 const uint4 c0 = cp[(int64_t)q * cps + (int64_t)s * 64];
                 if (s != cs) {
@@ -833,45 +891,50 @@ __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
                     const uint4 w0 = hw[((int64_t)k * gns + s) * 64];
                     hinP = mk64(w0.x, w0.y); hinM = mk64(w0.z, w0.w);
                 }
-                if (Rb != cR) { cR = Rb; load_planes(pp, p0 + 64 * Rb, pa, pb, pn); }
-                u64 P = mk64(c0.x, c0.y), M = mk64(c0.z, c0.w);
-                const int c_first = (8 * q) & 63;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = c_first + j;
-                    const u64 m0 = (u64)0 - ((T0 >> c) & 1), m1 = (u64)0 - ((T1 >> c) & 1);
-                    const u64 acgt = ~(pa ^ m0) & ~(pb ^ m1) & ~pn;
-                    const u64 Eq = ((TN >> c) & 1) ? pn : acgt;
-                    const u64 Min = M;
-                    u64 Ph, Mh;
-                    block_step(Eq, P, M, (u32)((hinP >> c) & 1), (u32)((hinM >> c) & 1), Ph, Mh);
-                    tile[j][lane] = make_uint4(lo32(P), hi32(P), lo32(Min), hi32(Min));   // columns past tlen are never read
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) tile[j][lane] = make_uint4(0u, 0u, 0u, 0u);
-                // the row the band bookkeeping creates at the end of a chunk: Pv = ~0, Mv = 0 (bpm_banded.c:910)
-                if (s == cl_b + 1 && (q & 7) == 7) tile[7][lane] = make_uint4(~0u, ~0u, 0u, 0u);
+                P = mk64(c0.x, c0.y); M = mk64(c0.z, c0.w);
             }
         }
-        bool in_tile = act;
-        while (__any(in_tile)) {
-            if (in_tile) {
-                const uint4 el = tile[h & 7][lane];
-                const int evr = v - 64 * (((h + 1) >> 6) - G.prolog);
-                const int lo = (((h + 1) & 63) == 0) ? cf_a : cf_b, slot = evr >> 6;
-                const u32 inb = (u32)((evr >= 0) & (slot >= lo) & (slot <= cl_b));
-                const int bit = v & 63;
-                const u32 isD = inb & (u32)((mk64(el.x, el.y) >> bit) & 1);
-                const u32 isI = inb & (u32)((mk64(el.z, el.w) >> bit) & 1) & (isD ^ 1u);
-                const u32 eq = E.eq(p0 + v, t0 + h) ? 1u : 0u;
-                R.push(isD ? (int)OP_D : (isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X)));
-                v -= (int)(isI ^ 1u);
-                h -= (int)(isD ^ 1u);
-                ++steps;
-                in_tile = v >= 0 && h >= 0 && (h >> 3) == q && (v >> 6) == Rb;
+        // 8 block steps from the checkpoint: the same arithmetic as the fill.  The step's Eq word is also
+        // the traceback's match test for the 64 cells of the column (bpm_banded.c:1012: equal codes; raw
+        // bytes only for non-canonical input, see EqTest)
+        if (!__any(act && ((TN | pn) != 0))) {
+            const u32 alo = lo32(pa), ahi = hi32(pa), blo = lo32(pb), bhi = hi32(pb);
+            const u32 t0s = (u32)(T0 >> c_first), t1s = (u32)(T1 >> c_first);
+            const u32 hp = (u32)(hinP >> c_first), hm = (u32)(hinM >> c_first);
+            u32 Plo = lo32(P), Phi = hi32(P), Mlo = lo32(M), Mhi = hi32(M), gP = 0, gM = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0s, j, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1s, j, 1);
+                const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1), ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
+                tE[j] = mk64(elo, ehi);
+                tM[j] = mk64(Mlo, Mhi);
+                block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, __builtin_amdgcn_ubfe(hp, j, 1), __builtin_amdgcn_ubfe(hm, j, 1), gP, gM);
+                tP[j] = mk64(Plo, Phi);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c_first + j;
+                const u64 m0 = (u64)0 - ((T0 >> c) & 1), m1 = (u64)0 - ((T1 >> c) & 1);
+                const u64 acgt = ~(pa ^ m0) & ~(pb ^ m1) & ~pn;
+                const u64 Eq = ((TN >> c) & 1) ? pn : acgt;
+                tE[j] = Eq;
+                tM[j] = M;
+                u64 Ph, Mh;
+                block_step(Eq, P, M, (u32)((hinP >> c) & 1), (u32)((hinM >> c) & 1), Ph, Mh);
+                tP[j] = P;
             }
         }
+        if (!computed) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { tP[j] = 0; tM[j] = 0; }
+            // the row the band bookkeeping creates at the end of a chunk: Pv = ~0, Mv = 0 (bpm_banded.c:910)
+            if (act && (Rb - (k - G.prolog)) == cl_b + 1 && (q & 7) == 7) tP[7] = QE_ONES;
+        }
+        // walk, column by column, straight-line: at its column a lane takes the whole run of deletions
+        // (consecutive set Pv bits below its row) and then the one step that leaves the column
+        if (any_raw) walk_tile<true>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, R, E, p0, t0);
+        else walk_tile<false>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, R, E, p0, t0);
     }
     if (!valid) return;
     R.push_n(OP_I, h + 1);
