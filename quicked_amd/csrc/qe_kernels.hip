@@ -113,6 +113,7 @@ __device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32
 // ---------------------------------------------------------------------------
 // STORE: 0 nothing | 1 every column's {Pv after, Mv before} (tiled; WindowEd history) |
 //        2 a checkpoint {Pv, Mv after} every 8th column (BandEd fill: the traceback recomputes the 8 columns between)
+//        3 the same checkpoints, taken before each group of 8 columns, to st[grp * st_stride] (on-chip WindowEd windows)
 template <int STORE>
 __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0, u64 T1,
                                            u64 hinP, u64 hinM, u64& houtP, u64& houtM,
@@ -127,6 +128,7 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
         const u32 t0 = (u32)(T0 >> (8 * grp)), t1 = (u32)(T1 >> (8 * grp));
         const u32 hp = (u32)(hinP >> (8 * grp)), hm = (u32)(hinM >> (8 * grp));
         u32 gP = 0, gM = 0;
+        if (STORE == 3) st[grp * st_stride] = make_uint4(Plo, Phi, Mlo, Mhi);   // {Pv, Mv} BEFORE column 8 grp
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0, j, 1);    // 0 / ~0: text code bit 0
@@ -214,6 +216,21 @@ __device__ __forceinline__ void load_planes(const u64* __restrict__ base, int bi
         n0 = (n0 >> sh) | (n1 << (64 - sh));
     }
     a = a0; b = b0; nn = n0;
+}
+
+// planes of 128 bases starting at bit offset `bit`: [bit, bit+64) -> x, [bit+64, bit+128) -> y
+__device__ __forceinline__ void load_planes2(const u64* __restrict__ base, int bit, u64 (&x)[3], u64 (&y)[3]) {
+    const int w = bit >> 6, sh = bit & 63;
+    const u64* q = base + 3 * (int64_t)w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const u64 r0 = q[k], r1 = q[3 + k];
+        if (sh) {
+            const u64 r2 = q[6 + k];
+            x[k] = (r0 >> sh) | (r1 << (64 - sh));
+            y[k] = (r1 >> sh) | (r2 << (64 - sh));
+        } else { x[k] = r0; y[k] = r1; }
+    }
 }
 
 // base code (0..3, 4 = not ACGT) at position `pos` of a packed sequence
@@ -946,12 +963,45 @@ __global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
     A.o_steps[t] = steps;
 }
 
+// In-window traceback over one recomputed 8-column tile of the window's last block row (W = 2, O = 1:
+// the walk stays in window rows 64..127 and columns 64..127, bpm_windowed.c:448-561).  vw / hw are window
+// coordinates.  SCORE_ONLY: D -> I -> match -> X, cost only (527-549); else match -> D -> I -> X (476-495).
+template <bool SCORE_ONLY>
+__device__ __forceinline__ void window_walk_tile(const u64 (&tP)[8], const u64 (&tM)[8], const u64 (&tE)[8],
+                                                 bool& inr, int& vw, int& hw, int& wscore, RunSink& R) {
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const bool mine = inr && (hw & 7) == j;
+        const int bit = vw & 63;
+        const u64 del = SCORE_ONLY ? tP[j] : (tP[j] & ~tE[j]);       // cells that take a deletion
+        int r = min(__clzll((long long)~(del << (63 - bit))), bit + 1);
+        if (!mine) r = 0;
+        const bool up = r == bit + 1;                                 // the run left the block row: window done
+        const bool go = mine && !up;
+        const int b1 = (bit - r) & 63;
+        const u32 mb = (u32)((tM[j] >> b1) & 1), eq = (u32)((tE[j] >> b1) & 1);
+        u32 isI;
+        if (SCORE_ONLY) {
+            isI = mb;
+            wscore += r + (go ? (int)(isI | (eq ^ 1u)) : 0);
+        } else {
+            isI = mb & (eq ^ 1u);
+            R.emit((int)OP_D, r, r > 0);
+            R.emit(eq ? (int)OP_M : (isI ? (int)OP_I : (int)OP_X), 1, go);
+        }
+        vw -= r + ((go && !isI) ? 1 : 0);
+        hw -= go ? 1 : 0;
+        inr = inr && !(mine && up) && vw >= 64;
+    }
+}
+
 // ===========================================================================
 // WindowEd chain (bpm_windowed.c:563-628): windows of W x W blocks anchored at
 // the current traceback position, filled (202-280; SSE semantics 283-445 when
 // sse && W == 2), traced back inside the non-overlap region (448-561).
 // ===========================================================================
 __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
+    __shared__ uint4 wck[8][64];
     const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
     const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
     const bool valid = pair >= 0;
@@ -982,8 +1032,67 @@ __global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
     int score = 0, hew = 0;
     u32 steps = 0;
 
+    const bool w2 = W == 2 && O == 1 && !__any(valid && (hasN || E.raw));
     while (__any(valid && pos_v >= 0 && pos_h >= 0)) {
         const bool on = valid && pos_v >= 0 && pos_h >= 0;
+        if (w2 && !__any(on && (pos_v < 127 || pos_h < 127))) {
+            // ---- every live lane has a full 128 x 128 window: the whole window stays on chip.  Fill the four
+            // block-chunks in registers, keep {Pv, Mv} of the last one every 8 columns in LDS, and let the
+            // traceback recompute 8-column tiles from those (same arithmetic, same bits as a stored history)
+            const int v0 = on ? pos_v - 127 : 0, h0 = on ? pos_h - 127 : 0;
+            u64 pl0[3] = {0, 0, 0}, pl1[3] = {0, 0, 0}, tx0[3] = {0, 0, 0}, tx1[3] = {0, 0, 0};
+            if (on) { load_planes2(pp, p0 + v0, pl0, pl1); load_planes2(tp, t0 + h0, tx0, tx1); }
+            const u64 ph_first = (v0 == 0) ? QE_ONES : 0;
+            const u64 pinit = (h0 == 0) ? QE_ONES : 0;
+            u64 P0 = pinit, M0 = 0, P1 = pinit, M1 = 0;
+            u64 hP, hM, gP, gM, xP, xM;
+            run64_fast<0>(P0, M0, pl0[0], pl0[1], tx0[0], tx0[1], sse ? (0x5555555555555556ull | (ph_first & 1)) : ph_first, 0, hP, hM, false, nullptr, 0, nullptr);
+            run64_fast<0>(P1, M1, pl1[0], pl1[1], tx0[0], tx0[1], hP, hM, xP, xM, false, nullptr, 0, nullptr);
+            run64_fast<0>(P0, M0, pl0[0], pl0[1], tx1[0], tx1[1], sse ? 0x5555555555555555ull : ph_first, 0, gP, gM, false, nullptr, 0, nullptr);
+            if (sse) {
+                // the SSE kernel runs block 0 one column past the window and feeds THAT column's carries to
+                // block 1's last column (bpm_windowed.c:428-444); 127 is odd, so always here
+                int tc = 4;                                              // text[tlen] reads as N (A.7(4))
+                if (on && pos_h + 1 < n) tc = plane_code(tp, t0 + pos_h + 1);
+                const u64 Eq = (tc == 4) ? pl0[2] : (~(pl0[0] ^ ((u64)0 - (u64)(tc & 1))) & ~(pl0[1] ^ ((u64)0 - (u64)((tc >> 1) & 1))) & ~pl0[2]);
+                u64 Ph, Mh, Pe = P0, Me = M0;
+                block_step(Eq, Pe, Me, 1u, 0u, Ph, Mh);
+                gP = (gP & ~(1ull << 63)) | (Ph & (1ull << 63));
+                gM = (gM & ~(1ull << 63)) | (Mh & (1ull << 63));
+            }
+            run64_fast<3>(P1, M1, pl1[0], pl1[1], tx1[0], tx1[1], gP, gM, xP, xM, true, &wck[0][lane], 64, nullptr);
+            if (on) steps += 256u;
+            int vw = 127, hw = 127, wscore = 0;
+            bool inr = on;
+            const u32 alo = lo32(pl1[0]), ahi = hi32(pl1[0]), blo = lo32(pl1[1]), bhi = hi32(pl1[1]);
+#pragma unroll 1
+            for (int q = 7; q >= 0 && __any(inr); --q) {
+                const uint4 c0 = wck[q][lane];
+                const u32 t0s = (u32)(tx1[0] >> (8 * q)), t1s = (u32)(tx1[1] >> (8 * q));
+                const u32 hp = (u32)(gP >> (8 * q)), hm = (u32)(gM >> (8 * q));
+                u32 Plo = c0.x, Phi = c0.y, Mlo = c0.z, Mhi = c0.w, aP = 0, aM = 0;
+                u64 tP[8], tM[8], tE[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0s, j, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1s, j, 1);
+                    const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1), ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
+                    tE[j] = mk64(elo, ehi);
+                    tM[j] = mk64(Mlo, Mhi);
+                    block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, __builtin_amdgcn_ubfe(hp, j, 1), __builtin_amdgcn_ubfe(hm, j, 1), aP, aM);
+                    tP[j] = mk64(Plo, Phi);
+                }
+                if (A.score_only) window_walk_tile<true>(tP, tM, tE, inr, vw, hw, wscore, R);
+                else window_walk_tile<false>(tP, tM, tE, inr, vw, hw, wscore, R);
+            }
+            if (on) {
+                if (A.score_only) {
+                    if (wscore > (W - O) * 64 * A.hew_threshold / 100) ++hew;
+                    score += wscore;
+                }
+                pos_v = v0 + vw; pos_h = h0 + hw;
+            }
+            continue;
+        }
         const int v_fi = pos_v, h_fi = pos_h;
         const int v0 = max(v_fi - 64 * W + 1, 0), h0 = max(h_fi - 64 * W + 1, 0);
         const int steps_v = on ? (v_fi - v0) / 64 + 1 : 0;
