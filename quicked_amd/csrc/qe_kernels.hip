@@ -242,11 +242,23 @@ __device__ __forceinline__ int plane_code(const u64* __restrict__ base, int pos)
 }
 
 // ===========================================================================
-// pack: ASCII -> planes.  One wave per sequence; lane l reads byte 64 r + l
-// (one coalesced 64-byte row per load) and three ballots ARE the three plane
-// words of row r.  Lane r % 64 keeps row r; every 64 rows the wave stores 64
-// rows x 24 B = one contiguous 1.5 KB block.
+// pack: ASCII -> planes.  One wave per sequence; a lane takes 16 consecutive
+// bases with one 16-byte load (a wave reads 1 KB = 16 rows per load instruction)
+// and classifies them four at a time in 32-bit SWAR:
+//   (c >> 1) & 3 is an injective 2-bit code of A, C, G, T in either case
+//   (A 0, C 1, T 2, G 3; any injective code works) and indexes a 4-byte table of
+//   the upper-case letters (v_perm_b32); the base is ACGT iff the table byte
+//   equals its upper-cased self, anything else is the reference's code 4
+//   (dna_text.c:41-46).
+// Per-byte flags live in bit 7 of their byte; three shift-ors gather the four
+// flags of a word into a nibble.  Four neighbouring lanes make one 64-base row.
 // ===========================================================================
+__device__ __forceinline__ u32 gather_msb4(u32 x) {        // flags at bits 7, 15, 23, 31 -> bits 28..31
+    u32 t = (x << 7) | x;
+    t = (x << 14) | t;
+    return (x << 21) | t;
+}
+
 __global__ __launch_bounds__(256) void k_pack(PackArgs A) {
     const int lane = threadIdx.x & 63;
     const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -254,41 +266,66 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A) {
     const int len = A.len[seq];
     const uint8_t* __restrict__ src = A.asc + A.asc_off[seq];
     u64* __restrict__ dst = A.planes + A.pl_off[seq];
-    const int nw = (len + 63) >> 6;
+    const int nrows = ((len + 63) >> 6) + 2;                 // two zero rows of padding (funnel-shift over-read)
+    const int nspan = (nrows + 15) >> 4;
     u32 fl = 0;
-    u64 ka = 0, kb = 0, kn = 0;
-    const int nrows = nw + 2;
-    constexpr int UNR = 8;     // 8 independent 64-byte row loads in flight per wave (the loop is latency-bound otherwise)
-    for (int r0 = 0; r0 < nrows; r0 += UNR) {
-        u32 chv[UNR];
+    constexpr int UNR = 4;                                    // 16-byte loads in flight per lane
+    constexpr u32 ALL_A = 0x41414141u;                        // filler past the end: 'A' packs to all-zero planes
+    for (int s0 = 0; s0 < nspan; s0 += UNR) {
+        uint4 raw[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int pos = (r0 + u) * 64 + lane;
-            chv[u] = 0;
-            if (pos < len) chv[u] = A.reverse ? src[len - 1 - pos] : src[pos];
+            const int pos = (s0 + u) * 1024 + 16 * lane;
+            uint4 x = make_uint4(ALL_A, ALL_A, ALL_A, ALL_A);
+            if (pos + 16 <= len) {
+                if (A.reverse) {
+                    uint4 y; __builtin_memcpy(&y, src + (len - 16 - pos), 16);
+                    x = make_uint4(__builtin_bswap32(y.w), __builtin_bswap32(y.z), __builtin_bswap32(y.y), __builtin_bswap32(y.x));
+                } else {
+                    __builtin_memcpy(&x, src + pos, 16);
+                }
+            } else if (pos < len) {                           // the one ragged lane of a sequence
+                u32 wv[4] = {ALL_A, ALL_A, ALL_A, ALL_A};
+                for (int i = 0; i < len - pos; ++i) {
+                    const u32 c = A.reverse ? src[len - 1 - pos - i] : src[pos + i];
+                    wv[i >> 2] = (wv[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | (c << (8 * (i & 3)));
+                }
+                x = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+            raw[u] = x;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int r = r0 + u;
-            if (r < nrows) {
-                const u32 ch = chv[u];
-                const bool in = r * 64 + lane < len;
-                const u32 up = ch & 0xDFu;                            // case-insensitive (dna_text.c:44-45)
-                const bool acgt = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
-                // A=0x41 C=0x43 G=0x47 T=0x54: bits 1,2 give 0,1,3,2 -- any injective 2-bit code works
-                const u64 wa = __ballot(in && acgt && ((ch >> 1) & 1));
-                const u64 wb = __ballot(in && acgt && ((ch >> 2) & 1));
-                const u64 wn = __ballot(in && !acgt);
-                if (in && !acgt) fl |= FLAG_HAS_N;
-                if (in && !(acgt && ch == up) && ch != 'N') fl |= FLAG_NONCANON;   // lower case or IUPAC: raw != encoded compare
-                if (lane == (r & 63)) { ka = wa; kb = wb; kn = wn; }
-                if ((r & 63) == 63 || r == nrows - 1) {
-                    const int row = (r & ~63) + lane;
-                    if (row <= r) {
-                        u64* q = dst + 3 * (int64_t)row;
-                        q[0] = ka; q[1] = kb; q[2] = kn;
-                    }
+            const int span = s0 + u;
+            if (span >= nspan) break;
+            const u32 wv[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+            u32 accA = 0, accB = 0, accN = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 w = wv[k];
+                const u32 want = __builtin_amdgcn_perm(0u, 0x47544341u, (w >> 1) & 0x03030303u);   // 'A','C','T','G'
+                const u32 y = want ^ (w & 0xDFDFDFDFu);                                              // case-insensitive (dna_text.c:44-45)
+                const u32 z = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;                                 // bit 7 of a byte set <=> not ACGT
+                const u32 ok = ~z & 0x80808080u, bad = z & 0x80808080u;
+                accA = (accA >> 4) | (gather_msb4((w << 6) & ok) & 0xF0000000u);                     // code bit 0 = ASCII bit 1
+                accB = (accB >> 4) | (gather_msb4((w << 5) & ok) & 0xF0000000u);                     // code bit 1 = ASCII bit 2
+                accN = (accN >> 4) | (gather_msb4(bad) & 0xF0000000u);
+                if ((w << 2) & ok) fl |= FLAG_NONCANON;                                              // lower-case base: raw != encoded compare
+                if (bad) {
+                    fl |= FLAG_HAS_N;
+                    for (int i = 0; i < 4; ++i)
+                        if (((bad >> (8 * i + 7)) & 1) && ((w >> (8 * i)) & 0xFF) != 'N') fl |= FLAG_NONCANON;   // IUPAC and the rest
                 }
+            }
+            // 16-bit masks of this lane's 16 bases -> 64-bit row words on every fourth lane
+            const u32 ab = (accA >> 16) | (accB & 0xFFFF0000u), nn = accN >> 16;
+            const u32 ab1 = __shfl_down(ab, 1), nn1 = __shfl_down(nn, 1);
+            const u32 a32 = (ab & 0xFFFFu) | (ab1 << 16), b32 = (ab >> 16) | (ab1 & 0xFFFF0000u), n32 = nn | (nn1 << 16);
+            const u32 a32h = __shfl_down(a32, 2), b32h = __shfl_down(b32, 2), n32h = __shfl_down(n32, 2);
+            const int row = span * 16 + (lane >> 2);
+            if ((lane & 3) == 0 && row < nrows) {
+                u64* q = dst + 3 * (int64_t)row;
+                q[0] = mk64(a32, a32h); q[1] = mk64(b32, b32h); q[2] = mk64(n32, n32h);
             }
         }
     }
