@@ -234,6 +234,35 @@ static PairView pair_view(const quicked_batch& B, bool reversed) {
     return v;
 }
 
+// ---------------------------------------------------------------------------
+// Launch of a lane-per-alignment kernel: ngroups waves.  Such a kernel is bound by VALU issue per SIMD:
+// one or two waves on a SIMD take the same time, three take 1.4 x as long (measured).  Left
+// to the dispatcher, 1563 one-wave workgroups land three-deep on some SIMDs in a good share of the
+// launches (27.4 vs 38.8 ms for the same kernel).  So the placement is made a matter of resources: a
+// workgroup is 4 waves -- the CU spreads them one per SIMD -- and claims a third-plus of the CU's LDS, so
+// at most two workgroups share a CU and no SIMD ever holds more than two of these waves, whichever
+// kernels and streams they come from.  A second kernel on another stream then fills exactly the SIMD
+// slots the first one left empty, at no cost to either.  QE_WG_WAVES / QE_PIN_LDS override the shape.
+// ---------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+template <typename Kernel, typename Args>
+static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ngroups, int max_waves, size_t lds_per_wave) {
+    if (ngroups == 0) return;
+    int wpb = 4;
+    static const int wpb_env = env_int("QE_WG_WAVES", 0);
+    if (wpb_env > 0) wpb = std::min(wpb_env, max_waves);
+    static const int pin_env = env_int("QE_PIN_LDS", 54 * 1024);      // 3 x 54 KB > 160 KB >= 2 x 54 KB
+    const size_t lds = std::max((size_t)pin_env, lds_per_wave * (size_t)wpb);
+    static thread_local std::vector<std::pair<const void*, int>> configured;      // per host thread and device
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    if (std::find(configured.begin(), configured.end(), std::make_pair(fn, tl_device)) == configured.end()) {
+        HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured.emplace_back(fn, tl_device);
+    }
+    const unsigned blocks = (unsigned)((ngroups + wpb - 1) / wpb);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * wpb), lds, C.stream, args);
+}
+
 static void launch_pack(quicked_batch& B, Context& C, bool reversed) {
     PackArgs a;
     a.nseq = (int32_t)B.n;
@@ -397,7 +426,7 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     a.only_if = nullptr;
     auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-    hipLaunchKernelGGL(k_banded<false>, dim3(L.ngroups()), dim3(64), 0, C.stream, a);
+    launch_groups(C, k_banded<false>, a, L.ngroups(), 16, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
 }
@@ -462,7 +491,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     HIP_CHECK(hipMemsetAsync(S.O.hew, 0, S.nt * sizeof(int32_t), C.stream));
     auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-    hipLaunchKernelGGL(k_banded_coop, dim3((unsigned)nwaves), dim3(64), 0, C.stream, a);
+    launch_groups(C, k_banded_coop, a, (size_t)nwaves, 16, 0);
     // fallback pass: one lane per task, only where a band-edge decision could not be resolved in time
     const BandLayout lay = band_layout(L, false, false);
     S.D = upload_layout(lay, C);
@@ -472,7 +501,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     b.mat = nullptr; b.g_mat_off = S.D.mat_off;
     b.o_score = S.O.score; b.o_first = S.O.first; b.o_last = S.O.last; b.o_posv = S.O.posv; b.o_adv = S.O.adv;
     b.o_maxrow = S.O.len; b.only_if = S.O.hew;
-    hipLaunchKernelGGL(k_banded<false>, dim3(L.ngroups()), dim3(64), 0, C.stream, b);
+    launch_groups(C, k_banded<false>, b, L.ngroups(), 16, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
 }
@@ -592,7 +621,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
     a.W = W; a.O = O_; a.hew_threshold = hew_threshold; a.score_only = score_only ? 1 : 0; a.sse = sse ? 1 : 0; a.reversed = reversed ? 1 : 0;
     a.ws = D.ws; a.g_ws_off = D.ws_off; a.runs = D.runs; a.g_runs_off = D.runs_off; a.g_runs_cap = D.runs_cap;
     a.o_score = O.score; a.o_hew = O.hew; a.o_nruns = O.nruns; a.o_nops = O.nops; a.o_edits = O.edits; a.o_steps = O.steps;
-    hipLaunchKernelGGL(k_windowed, dim3(ng), dim3(64), 0, C.stream, a);
+    launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192);
     if (d_score_out) *d_score_out = O.score;
     SegList SL; AlignOut AO;
     if (!score_only) {
@@ -782,7 +811,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         a.only_if = nullptr;
         auto* ke = C.kernel_events();
         if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-        hipLaunchKernelGGL(k_banded<true>, dim3(g1 - g0), dim3(64), 0, C.stream, a);
+        launch_groups(C, k_banded<true>, a, (size_t)(g1 - g0), 8, 0);
         if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
         TraceArgs tr;
         tr.P = a.P; tr.T = a.T;
@@ -790,7 +819,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         tr.mat = mat; tr.g_mat_off = a.g_mat_off;
         tr.runs = d_runs; tr.g_runs_off = d_runs_off + g0; tr.g_runs_cap = d_runs_cap + g0;
         tr.o_nruns = O.nruns + o; tr.o_nops = O.nops + o; tr.o_edits = O.edits + o; tr.o_steps = O.steps + o;
-        hipLaunchKernelGGL(k_traceback, dim3(g1 - g0), dim3(64), 0, C.stream, tr);
+        launch_groups(C, k_traceback, tr, (size_t)(g1 - g0), 8, 0);
         if (sb + 2 < sub_start.size()) {
             HIP_CHECK(hipStreamSynchronize(C.stream));       // the next sub-batch reuses this scratch
             C.scratch_p->release(mark);
@@ -859,9 +888,16 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     const int par = B.parity;
     // ---- phase W: pack + bound stages on stream_w with pool_w.  The planes of this parity were last read by
     // the A phase two runs ago: wait for it on the device, not on the host.
-    C.phase_w();
-    C.pool_w.reset();
-    if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.stream_w, B.ev_done[par], 0));
+    // BandEd and WindowEd have no bound stage: their pack goes on stream_a, in order with the kernel.  Overlapping it
+    // with the previous run's kernel would save ~0.5 ms, but a 25 k-workgroup kernel dispatched next to the 1563
+    // one-wave workgroups of k_banded skews their placement over the SIMDs and doubles the kernel's time.
+    const bool serial = p.algo == BANDED || p.algo == WINDOWED;
+    if (serial) { C.phase_a(); C.pool_a.reset(); }
+    else {
+        C.phase_w();
+        C.pool_w.reset();
+        if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.stream_w, B.ev_done[par], 0));
+    }
     B.only_score_run = p.only_score;
     B.score.assign((size_t)B.n, -1);
     B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
@@ -875,10 +911,11 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     HIP_CHECK(hipEventRecord(C.ev0, C.stream));
     HIP_CHECK(hipMemsetAsync(B.d_flags[par], 0, (size_t)B.n * sizeof(u32), C.stream));
     launch_pack(B, C, false);
-    HIP_CHECK(hipEventRecord(C.ev_pack, C.stream_w));
+    if (!serial) HIP_CHECK(hipEventRecord(C.ev_pack, C.stream_w));
     // phase A starts on the device when the planes are there and (stream order) the previous run's A phase is over;
     // its pool can be reset now because everything it launches is ordered behind that previous A phase
     auto enter_a = [&]() {
+        if (serial) return;
         C.phase_a();
         C.pool_a.reset();
         HIP_CHECK(hipStreamWaitEvent(C.stream_a, C.ev_pack, 0));

@@ -27,6 +27,12 @@
 namespace qe {
 
 #define QE_ONES (~(u64)0)
+// One wave per group of 64 tasks.  A workgroup is 4 w waves -- w per SIMD of the CU it lands on -- and
+// the host pins one workgroup per CU (launch_groups, qe_driver.hip): the number of waves that share a
+// SIMD sets a lane-per-alignment kernel's duration, so their placement is not left to the dispatcher.
+#define QE_WAVE_IN_BLOCK() ((int)(threadIdx.x >> 6))
+#define QE_GROUP_INDEX() ((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)))
+extern __shared__ uint4 qe_dyn_lds[];
 
 __device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
 __device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
@@ -377,8 +383,9 @@ __device__ __forceinline__ GroupWs group_ws(uint8_t* ws, int64_t off, int ns, in
 // (FILL = true, bpm_banded.c:199-316).  One lane per task.
 // ===========================================================================
 template <bool FILL>
-__global__ __launch_bounds__(64) void k_banded(BandedArgs A) {
-    const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
+__global__ __launch_bounds__(FILL ? 512 : 1024) void k_banded(BandedArgs A) {
+    const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
+    if (g * 64 >= A.T.ntasks) return;
     int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
     if (A.only_if != nullptr && pair >= 0 && A.only_if[t] == 0) pair = -1;
     const bool valid = pair >= 0;
@@ -545,9 +552,10 @@ template __global__ void k_banded<true>(BandedArgs);
 // Every value is bit-identical to k_banded<false>; a flagged task (o_abort) is
 // simply recomputed by k_banded<false>.
 // ===========================================================================
-__global__ __launch_bounds__(64) void k_banded_coop(CoopArgs A) {
-    const int lane = threadIdx.x, w = blockIdx.x;
+__global__ __launch_bounds__(1024) void k_banded_coop(CoopArgs A) {
+    const int lane = threadIdx.x & 63, w = QE_GROUP_INDEX();
     const int G = A.G, NA = 64 / G;
+    if (w * NA >= A.T.ntasks) return;
     const int q = lane / G, g = lane - q * G;
     const int t = w * NA + q;
     const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
@@ -878,8 +886,9 @@ __device__ __forceinline__ void walk_tile(const u64 (&tP)[8], const u64 (&tM)[8]
 // while it stays inside that tile.  HBM sees 2 B per block-column instead of 16.
 // Cells the fill did not compute read as P = 0, M = 0 (see oracle header).
 // ===========================================================================
-__global__ __launch_bounds__(64) void k_traceback(TraceArgs A) {
-    const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
+__global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
+    const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
+    if (g * 64 >= A.T.ntasks) return;
     const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
     const bool valid = pair >= 0;
     int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0;
@@ -1037,9 +1046,10 @@ __device__ __forceinline__ void window_walk_tile(const u64 (&tP)[8], const u64 (
 // the current traceback position, filled (202-280; SSE semantics 283-445 when
 // sse && W == 2), traced back inside the non-overlap region (448-561).
 // ===========================================================================
-__global__ __launch_bounds__(64) void k_windowed(WindowArgs A) {
-    __shared__ uint4 wck[8][64];
-    const int g = blockIdx.x, lane = threadIdx.x, t = g * 64 + lane;
+__global__ __launch_bounds__(512) void k_windowed(WindowArgs A) {
+    uint4 (*wck)[64] = (uint4 (*)[64])(qe_dyn_lds + QE_WAVE_IN_BLOCK() * 512);    // [8][64] per wave
+    const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
+    if (g * 64 >= A.T.ntasks) return;
     const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
     const bool valid = pair >= 0;
     const int W = A.W, O = A.O;
