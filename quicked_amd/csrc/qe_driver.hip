@@ -103,9 +103,14 @@ struct Context {
     //   W: pack + bound stages (WindowEd, band doubling)      A: the BandEd kernels (score / fill / traceback / format)
     // Run k+1's W phase overlaps run k's A phase (different resources: W is latency / VALU-light, A is
     // VALU- or HBM-bound); a batch double-buffers its planes for that.
-    hipStream_t stream_w = nullptr, stream_a = nullptr;
+    // Consecutive runs alternate between two A streams / pools: a 100 k-pair kernel fills 391 of the 512 workgroup
+    // slots launch_groups() allows, and the next run's kernel takes the other 121 at once instead of waiting.
+    hipStream_t stream_w = nullptr, stream_a2[2] = {nullptr, nullptr};
     hipStream_t stream = nullptr;            // where the current phase launches
-    DevicePool pool_w, pool_a;
+    DevicePool pool_w, pool_a2[2];
+    int ai = 0;                              // which A stream / pool the current run uses
+    hipStream_t& sa() { return stream_a2[ai]; }
+    DevicePool& pa() { return pool_a2[ai]; }
     DevicePool* scratch_p = nullptr;         // the current phase's pool
     hipEvent_t ev_pack = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -122,12 +127,12 @@ struct Context {
         return &kev[kev_used++];
     }
     void phase_w() { stream = stream_w; scratch_p = &pool_w; }
-    void phase_a() { stream = stream_a; scratch_p = &pool_a; }
+    void phase_a() { stream = sa(); scratch_p = &pa(); }
     void init() {
         if (stream) return;
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&stream_w, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&stream_a, hipStreamNonBlocking));
+        for (auto& q : stream_a2) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
         phase_w();
         HIP_CHECK(hipEventCreate(&ev0));
@@ -892,7 +897,11 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // with the previous run's kernel would save ~0.5 ms, but a 25 k-workgroup kernel dispatched next to the 1563
     // one-wave workgroups of k_banded skews their placement over the SIMDs and doubles the kernel's time.
     const bool serial = p.algo == BANDED || p.algo == WINDOWED;
-    if (serial) { C.phase_a(); C.pool_a.reset(); }
+    C.ai ^= 1;
+    if (serial) {
+        C.phase_a(); C.pa().reset();
+        if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.sa(), B.ev_done[par], 0));
+    }
     else {
         C.phase_w();
         C.pool_w.reset();
@@ -917,14 +926,14 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     auto enter_a = [&]() {
         if (serial) return;
         C.phase_a();
-        C.pool_a.reset();
-        HIP_CHECK(hipStreamWaitEvent(C.stream_a, C.ev_pack, 0));
+        C.pa().reset();
+        HIP_CHECK(hipStreamWaitEvent(C.sa(), C.ev_pack, 0));
     };
     const bool sse = !p.force_scalar;
     const bool want_cigar = !p.only_score;
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const size_t matrix_budget = std::max<size_t>((free_b + C.pool_a.cap) / 10 * 7, (size_t)1 << 28);
+    const size_t matrix_budget = std::max<size_t>((free_b + C.pool_a2[0].cap + C.pool_a2[1].cap) / 20 * 7, (size_t)1 << 28);   // two runs in flight
     quicked_status_t ret = QUICKED_WIP;
     QE_TRACE_POINT("setup+pack launch");
     TaskList L = all_pairs(B, p);
@@ -1051,13 +1060,13 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     default: break;
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
-    HIP_CHECK(hipEventRecord(B.ev_done[par], C.stream_a));
+    HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
     B.ev_done_set[par] = true;
     C.phase_w();
     B.pending = true;
     if (fetch) {
         HIP_CHECK(hipStreamSynchronize(C.stream_w));
-        HIP_CHECK(hipStreamSynchronize(C.stream_a));
+        for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, C.ev0, C.ev1));
         B.counters[5] = (int64_t)(ms * 1e6);
@@ -1237,7 +1246,7 @@ QE_API quicked_status_t quicked_batch_sync(quicked_batch_t* batch) {
         tl_device = B->device;
         Context& C = ctx();
         HIP_CHECK(hipStreamSynchronize(C.stream_w));
-        HIP_CHECK(hipStreamSynchronize(C.stream_a));
+        for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
         B->pending = false;
         return QUICKED_OK;
     }, nullptr);
@@ -1250,7 +1259,7 @@ QE_API quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double
         tl_device = B->device;
         Context& C = ctx();
         HIP_CHECK(hipStreamSynchronize(C.stream_w));
-        HIP_CHECK(hipStreamSynchronize(C.stream_a));
+        for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
         double total = 0;
         for (size_t i = 0; i < C.kev_used; ++i) {
             float ms = 0;

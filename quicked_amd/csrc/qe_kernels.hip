@@ -1374,14 +1374,34 @@ __global__ __launch_bounds__(64) void k_join(JoinArgs A) {
 struct RunMerger {
     int op = -1, len = 0, total = 0, edits = 0, nops = 0;
     char* out = nullptr;
+    u64 buf = 0; int nb = 0;        // up to 7 characters waiting for an 8-byte store
+    __device__ __forceinline__ void put(u64 tok, int n) {            // n <= 8 characters, first one in the low byte
+        buf |= tok << (8 * nb);                                      // nb <= 7
+        if (nb + n >= 8) {
+            __builtin_memcpy(out, &buf, 8);                          // one (unaligned) 8-byte store
+            out += 8;
+            buf = nb ? (tok >> (8 * (8 - nb))) : 0;
+            nb += n - 8;
+        } else nb += n;
+    }
     template <bool WRITE> __device__ __forceinline__ void emit() {
         if (len <= 0) return;
         const int d = dec_digits((u32)len);
         if (WRITE) {
+            const u64 opc = (u64)((0x4449584Du >> (8 * (op & 3))) & 0xFFu);   // "MXID"
             u32 x = (u32)len;
-            for (int k = d - 1; k >= 0; --k) { out[k] = (char)('0' + x % 10); x /= 10; }
-            out[d] = (char)(0x4449584Du >> (8 * (op & 3)));   // "MXID"
-            out += d + 1;
+            if (d <= 7) {
+                u64 tok = opc;
+                for (int k = 0; k < d; ++k) { tok = (tok << 8) | (u64)('0' + x % 10); x /= 10; }
+                put(tok, d + 1);
+            } else {                                                 // 8..10 digits: two tokens
+                u64 lo = opc; int k = 0;
+                for (; k < 3; ++k) { lo = (lo << 8) | (u64)('0' + x % 10); x /= 10; }     // last 3 digits + op
+                u64 hi = 0;
+                for (; k < d; ++k) { hi = (hi << 8) | (u64)('0' + x % 10); x /= 10; }
+                put(hi, d - 3);
+                put(lo, 4);
+            }
         }
         total += d + 1;
     }
@@ -1391,6 +1411,10 @@ struct RunMerger {
         else { emit<WRITE>(); op = o; len = n; }
         nops += n;
         if (o != (int)OP_M) edits += n;
+    }
+    __device__ __forceinline__ void finish() {                       // the waiting characters and the terminator
+        for (int k = 0; k < nb; ++k) out[k] = (char)(buf >> (8 * k));
+        out[nb] = '\0';
     }
 };
 
@@ -1410,7 +1434,7 @@ __global__ __launch_bounds__(64) void k_format_segs(SegFormatArgs A) {
         }
     }
     Mg.emit<WRITE>();
-    if (WRITE) *Mg.out = '\0';
+    if (WRITE) Mg.finish();
     else { A.o_len[i] = Mg.total; A.o_edits[i] = Mg.edits; A.o_nops[i] = Mg.nops; }
 }
 template __global__ void k_format_segs<false>(SegFormatArgs);
