@@ -83,6 +83,15 @@ struct DevicePool {
         top += bytes;
         return p;
     }
+    // Grow to the chunk list of a pool that serves the same request sequence (the other A pool), so that the run
+    // which first uses this one does not pay for its allocations; skipped when memory is short.
+    void mirror(const DevicePool& o) {
+        for (size_t i = chunks.size(); i < o.chunks.size(); ++i) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * o.chunks[i].cap) return;
+            add_chunk(o.chunks[i].cap);
+        }
+    }
     size_t used_hint() const { return cap; }
     ~DevicePool() { for (auto& c : chunks) if (c.base) (void)hipFree(c.base); }
 };
@@ -1061,6 +1070,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
+    C.pool_a2[C.ai ^ 1].mirror(C.pa());
     B.ev_done_set[par] = true;
     C.phase_w();
     B.pending = true;

@@ -383,3 +383,40 @@ def test_many_short_pairs():
     for c, sc in zip(cig[:2000], scores[:2000]):
         ops = O.rle_to_ops(c)
         assert lib.qo_cigar_score(ops, len(ops)) == sc
+
+
+def test_pack_boundaries_forward_and_reversed(monkeypatch):
+    """k_pack takes 16 bases per lane and 1 KB per wave load: sweep lengths across every boundary of that
+    scheme (16-byte lane spans, 64-base rows, 1 KB spans, the ragged last lane), with non-ACGT symbols at
+    the edges, forward (BandEd / WindowEd) and reversed (forced Hirschberg splits pack the reversed strings)"""
+    monkeypatch.setenv("QE_SPLIT_BYTES", "4096")
+    rng = np.random.default_rng(99)
+    lens = sorted(set(list(range(1, 36)) + [47, 48, 49, 63, 64, 65, 79, 80, 81, 127, 128, 129, 1007, 1008, 1009,
+                                            1023, 1024, 1025, 1039, 1040, 1041, 2047, 2048, 2049, 3071, 3089]))
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    pairs = []
+    for k, n in enumerate(lens):
+        p = alpha[rng.integers(0, 4, n)].copy()
+        t = p.copy()
+        for pos in rng.integers(0, n, max(1, n // 25)):           # a few substitutions
+            t[pos] = alpha[rng.integers(0, 4)]
+        if n > 8 and k % 3 == 0:                                  # an indel: lengths differ by one
+            t = np.delete(t, int(rng.integers(0, n)))
+        if k % 4 == 1:
+            p[0] = ord("N"); t[-1] = ord("N")
+        if k % 4 == 2:
+            p[-1] = ord("a"); t[0] = ord("n")
+        if k % 4 == 3 and n > 17:
+            p[15] = ord("R"); p[16] = ord("N"); t[n // 2] = ord("c")
+        pairs.append((p.tobytes(), t.tobytes()))
+    for kw in (dict(algo=2, only_score=True), dict(algo=2), dict(algo=1), dict(algo=0), dict(algo=3)):
+        al = capi.QuickedAligner()
+        for key, v in kw.items():
+            setattr(al._params, key, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            est, esc, ecg = O.oracle_align(p, t, **kw)
+            assert out[i][0] == est, (kw, len(p), len(t))
+            if est >= 0:
+                assert out[i][1] == esc, (kw, len(p), len(t))
+                assert out[i][2] == ecg, (kw, len(p), len(t))
