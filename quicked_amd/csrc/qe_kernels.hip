@@ -86,21 +86,33 @@ __device__ __forceinline__ void block_step(u64 Eq, u64& P, u64& M, u32 PHin, u32
 template <int TT>
 __device__ __forceinline__ u32 bitop3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, TT); }
 
+// Issue cost on gfx950 (tools/valu_rate.hip, 8 waves per SIMD): v_and/or/xor/add_u32/ashr and v_bitop3
+// take ~2.5 cycles of a SIMD, v_alignbit/bfe/or3/lshl_or/lshlrev and the 64-bit v_lshl_add_u64 ~4.2,
+// a v_add_co + v_addc pair 6.4.  Hence: every boolean goes through v_bitop3 (also plain 3-input ORs),
+// the 64-bit sum is one v_lshl_add_u64, and the two "<< 1 | carry-in" shifts are one v_lshl_add_u64
+// each ((x << 1) + carry) instead of a v_lshl_or + v_alignbit pair.
+__device__ __forceinline__ u64 lshl_add_u64(u64 x, u64 y) {          // x + y
+    u64 r; asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(y)); return r;
+}
+__device__ __forceinline__ u64 shl1_add_u64(u64 x, u64 y) {          // (x << 1) + y
+    u64 r; asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(x), "v"(y)); return r;
+}
+
 __device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32& Phi, u32& Mlo, u32& Mhi,
                                                  u32 PHin, u32 MHin, u32& accP, u32& accM) {
     const u32 xvlo = elo | Mlo, xvhi = ehi | Mhi;
     const u32 eclo = elo | MHin;
-    const u64 P = mk64(Plo, Phi);
-    const u64 sum = mk64(eclo & Plo, ehi & Phi) + P;
+    const u64 sum = lshl_add_u64(mk64(eclo & Plo, ehi & Phi), mk64(Plo, Phi));
     const u32 slo = lo32(sum), shi = hi32(sum);
-    const u32 phlo = bitop3<0xF3>(Mlo, slo | Plo | eclo, 0u);          // M | ~x
-    const u32 phhi = bitop3<0xF3>(Mhi, shi | Phi | ehi, 0u);
+    const u32 phlo = bitop3<0xF3>(Mlo, bitop3<0xFE>(slo, Plo, eclo), 0u);   // M | ~(sum | P | Eqc)
+    const u32 phhi = bitop3<0xF3>(Mhi, bitop3<0xFE>(shi, Phi, ehi), 0u);
     const u32 mhlo = bitop3<0xB0>(Plo, slo, eclo);                     // P & ((sum ^ P) | Eqc)
     const u32 mhhi = bitop3<0xB0>(Phi, shi, ehi);
     accP = __builtin_amdgcn_alignbit(accP, phhi, 31);                  // (accP << 1) | (Ph >> 63)
     accM = __builtin_amdgcn_alignbit(accM, mhhi, 31);
-    const u32 pslo = (phlo << 1) | PHin, pshi = __builtin_amdgcn_alignbit(phhi, phlo, 31);
-    const u32 mslo = (mhlo << 1) | MHin, mshi = __builtin_amdgcn_alignbit(mhhi, mhlo, 31);
+    const u64 phs = shl1_add_u64(mk64(phlo, phhi), (u64)PHin);         // (Ph << 1) | PHin
+    const u64 mhs = shl1_add_u64(mk64(mhlo, mhhi), (u64)MHin);
+    const u32 pslo = lo32(phs), pshi = hi32(phs), mslo = lo32(mhs), mshi = hi32(mhs);
     Plo = bitop3<0xF1>(mslo, xvlo, pslo);                              // Mhs | ~(Xv | Phs)
     Phi = bitop3<0xF1>(mshi, xvhi, pshi);
     Mlo = pslo & xvlo;
