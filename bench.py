@@ -26,12 +26,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Integer VALU peak for the block-step instruction mix: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU (quad-cycles) on
-# k_banded<false>, i.e. every VALU instruction of this mix holds its SIMD for 4 cycles = 16 lanes/clk/SIMD
-# (profiles/README.md); 256 CU x 4 SIMD x 16 lanes x 2.4 GHz.  A 400 k-pair launch saturates at 35 Tops/s.
-VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-OPS_PER_BLOCK_COLUMN = 36        # 32-bit VALU ops per 64-row block per column (ISA count of the fused v_bitop3 loop)
-
+# Integer-VALU issue roofline of the block step.  gfx950 does not issue every VALU op at the same
+# rate: measured with tools/valu_rate.hip (profiles/r01_valu_rates.txt), v_and/or/xor/add and v_bitop3 hold a SIMD for
+# ~2.5 cycles per wave64 op, v_bfe/v_alignbit/v_lshl_add_u64/64-bit shifts for ~4.2-4.5.  The 8-column body of
+# run64_fast (ISA of k_banded<false>: 176 fast + 80 slow ops) therefore needs 784 SIMD cycles = 98 per block-column;
+# 1024 SIMDs x 2.4 GHz x 64 lanes / 98 cycles is what the chip can issue if nothing else ever stalls a SIMD.
+ISSUE_CYCLES_PER_BLOCK_COLUMN = 98.0
+VALU_PEAK_BLOCK_COLUMNS = 256 * 4 * 2.4e9 * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN
+OPS_PER_BLOCK_COLUMN = 32        # VALU instructions per 64-row block per column in that loop (256 / 8)
 
 def cpu_baseline(batch, params_kw, budget_s=15.0):
     """The compiled reference (oracle/_ref, kind "reference") or the oracle
@@ -75,8 +77,8 @@ def cpu_baseline(batch, params_kw, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU per step")
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--error", type=float, default=0.05)
@@ -174,12 +176,12 @@ def main():
         except Exception:
             traffic = None
         achieved = alg_bytes / kern_s / 1e9
-        valu_tops = work_blocks * OPS_PER_BLOCK_COLUMN / kern_s / 1e12
+        valu_rate = work_blocks / kern_s
         # consecutive runs overlap on two streams (the next run's kernel takes the SIMD slots this one leaves empty), so
         # a launch lasts longer than its share of the wall clock: the aggregate figures divide the same per-launch
         # work by the step time instead of the launch duration
         step_s = max_elapsed / args.steps
-        agg_valu_tops = work_blocks * OPS_PER_BLOCK_COLUMN / step_s / 1e12
+        agg_valu_rate = work_blocks / step_s
         line = {
             "metric": "alignments/sec + GCUPS, 10kb x 10kb 5%-error pairs",
             "value": value, "unit": "alignments/s", "gcups": tot_cells * args.steps / max_elapsed / 1e9,
@@ -195,10 +197,12 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
                          "aggregate_achieved": alg_bytes / step_s / 1e9,
                          "note": "score-only BandEd is integer-VALU-bound, not HBM-bound (SURVEY 8d); see valu"},
-            "valu": {"achieved": valu_tops, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (32-bit lane ops)",
-                     "frac": valu_tops / VALU_PEAK_TOPS, "aggregate_achieved": agg_valu_tops,
-                     "aggregate_frac": agg_valu_tops / VALU_PEAK_TOPS, "block_columns_per_launch": work_blocks,
-                     "ops_per_block_column": OPS_PER_BLOCK_COLUMN},
+            "valu": {"bound": "integer VALU issue", "achieved": valu_rate, "peak": VALU_PEAK_BLOCK_COLUMNS,
+                     "unit": "block-columns/s", "frac": valu_rate / VALU_PEAK_BLOCK_COLUMNS,
+                     "aggregate_achieved": agg_valu_rate, "aggregate_frac": agg_valu_rate / VALU_PEAK_BLOCK_COLUMNS,
+                     "block_columns_per_launch": work_blocks, "issue_cycles_per_block_column": ISSUE_CYCLES_PER_BLOCK_COLUMN,
+                     "instructions_per_block_column": OPS_PER_BLOCK_COLUMN,
+                     "note": "achieved uses the launch duration (launches of consecutive runs overlap); aggregate uses the step time"},
             "score_checksum": tot_checksum,
         }
         if not args.no_cpu_baseline:

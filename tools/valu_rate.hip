@@ -27,10 +27,6 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters
             }
             if (KIND == 3) { fa = fa * fb + fc; fb = fb * fc + fd; fc = fc * fd + fe; fd = fd * fe + ff; fe = fe * ff + fg; ff = ff * fg + fh; fg = fg * fh + fa; fh = fh * fa + fb; }
             if (KIND == 4) { a += b; b += c; c += d; d += e; e += f; f += g; g += h; h += a; }
-            if (KIND == 7) {   // v_bfe_u32 with literal offset/width
-                a = __builtin_amdgcn_ubfe(b, 3, 9) + 0; b = __builtin_amdgcn_ubfe(c, 5, 11); c = __builtin_amdgcn_ubfe(d, 7, 13); d = __builtin_amdgcn_ubfe(e, 2, 17);
-                e = __builtin_amdgcn_ubfe(f, 1, 19); f = __builtin_amdgcn_ubfe(g, 4, 21); g = __builtin_amdgcn_ubfe(h, 6, 23); h = __builtin_amdgcn_ubfe(a, 8, 24) | 0x10000;
-            }
             if (KIND == 8) {   // v_or3_b32
                 asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(b), "v"(c));
                 asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(b) : "v"(b), "v"(c), "v"(d));
@@ -231,7 +227,7 @@ int main() {
     uint32_t* out; hipMalloc(&out, 256 * 8 * 256 * 4);
     run<0>("v_xor_b32", out); run<1>("v_bitop3_b32", out); run<2>("v_alignbit_b32", out);
     run<3>("v_fma_f32", out); run<4>("v_add_u32", out); run<5>("v_lshl_add_u64", out);
-    run<7>("v_bfe_u32", out); run<8>("v_or3_b32", out); run<9>("v_lshl_or_b32", out); run<10>("add_co+addc", out); run<11>("v_or_b32", out);
+    run<8>("v_or3_b32", out); run<9>("v_lshl_or_b32", out); run<10>("add_co+addc", out); run<11>("v_or_b32", out);
     run<12>("v_bfe_u32", out);
     run<13>("v_bfe_i32", out);
     run<14>("v_lshlrev_b32", out);
