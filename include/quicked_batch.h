@@ -51,11 +51,17 @@ void quicked_batch_destroy(quicked_batch_t* batch);
 
 /* Runs the hot path for every pair with `params` (algo, only_score, ...), from
  * the ASCII bytes resident in HBM to scores (and CIGAR runs) resident in HBM.
- * Synchronous w.r.t. the host only if `sync` is non-zero. */
+ * sync != 0: waits for the run and copies scores / statuses / CIGARs / counters
+ * to the host, where the getters below read them.
+ * sync == 0: returns once the run is queued (QUICKED / HIRSCHBERG: once their
+ * bound stages, which need host decisions, are done); nothing is copied to the
+ * host.  Consecutive runs of a thread alternate between two streams and two
+ * device pools, so the kernels of run k+1 overlap those of run k; the device
+ * results of a run stay valid until the second next run of that thread. */
 quicked_status_t quicked_batch_run(quicked_batch_t* batch, const quicked_params_t* params, int sync);
 quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
 
-/* D2H of the results of the last run */
+/* results of the last sync != 0 run (host copies made by that run) */
 quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_out, int32_t* status_out);
 /* total bytes of all CIGAR strings incl. terminators, then the strings themselves
  * (cigar_off[i] = offset of string i in cigar_pool, -1 if none) */

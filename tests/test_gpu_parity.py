@@ -420,3 +420,38 @@ def test_pack_boundaries_forward_and_reversed(monkeypatch):
             if est >= 0:
                 assert out[i][1] == esc, (kw, len(p), len(t))
                 assert out[i][2] == ecg, (kw, len(p), len(t))
+
+
+def test_interleaved_batches_and_async_runs():
+    """consecutive runs alternate between two streams / pools and overlap on the device: results of a
+    synchronous run must not depend on what was queued around it (other batches, other algorithms, async runs)"""
+    ba = datagen.generate(count=300, length=1500, error=0.06, seed=611)
+    bb = datagen.generate(count=200, length=2500, error=0.08, seed=612)
+    ra, rb = capi.ResidentBatch(ba), capi.ResidentBatch(bb)
+    pa = capi.make_params(algo=capi.BANDED, only_score=True, bandwidth=15)
+    pb = capi.make_params(algo=capi.QUICKED)
+    pc = capi.make_params(algo=capi.HIRSCHBERG)
+    for _ in range(3):
+        assert ra.run(pa, sync=False) >= 0
+        assert rb.run(pb, sync=False) >= 0
+    assert rb.run(pc, sync=False) >= 0
+    assert ra.run(pa, sync=True) >= 0           # queued behind all of the above
+    sa, sta = ra.scores()
+    assert rb.run(pb, sync=False) >= 0
+    assert rb.run(pb, sync=True) >= 0
+    sb, stb = rb.scores()
+    cb = rb.cigars()
+    assert ra.run(pa, sync=False) >= 0          # leave work in flight while the other batch is read again
+    assert rb.run(pc, sync=True) >= 0
+    sc, stc = rb.scores()
+    cc = rb.cigars()
+    ra.sync()
+    for i, (p, t) in enumerate(ba.pairs()):
+        st, s, _ = O.oracle_align(p, t, algo=2, only_score=True, bandwidth=15)
+        assert (sta[i], sa[i]) == (st, s), i
+    for i, (p, t) in enumerate(bb.pairs()):
+        st, s, cg = O.oracle_align(p, t, algo=0)
+        assert (stb[i], sb[i], cb[i]) == (st, s, cg), i
+        st, s, cg = O.oracle_align(p, t, algo=3)
+        assert (stc[i], sc[i], cc[i]) == (st, s, cg), i
+    ra.close(); rb.close()
