@@ -68,6 +68,23 @@ quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_ou
 int64_t quicked_batch_cigar_bytes(quicked_batch_t* batch);
 quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar_pool, int64_t* cigar_off);
 
+/* Output options of the runs to come.
+ * cigar_style: 0 = the reference's RLE "MXID" (cigar_sprint, quicked_utils/src/cigar.c:453-488; default),
+ *              1 = SAM CIGAR with mismatches, "=XID", 2 = SAM CIGAR "MID" with X folded into M before
+ *              runs are merged (cigar_compute_CIGAR + cigar_sprint_SAM_CIGAR, cigar.c:194-240, 504-529),
+ *              byte-identical to that printer including its one quirk: an alignment that STARTS with a
+ *              mismatch keeps it as "1X" (the first operation is read before the mapping step).
+ * check != 0:  every CIGAR is validated on the device against the raw bytes of its pair, the same walk
+ *              as cigar_check_alignment (cigar.c:363-434); verdicts via quicked_batch_check_results
+ *              (1 valid, 0 not, -1 the pair has no alignment) after a sync != 0 run. */
+quicked_status_t quicked_batch_configure(quicked_batch_t* batch, int cigar_style, int check);
+quicked_status_t quicked_batch_check_results(quicked_batch_t* batch, int32_t* ok_out);
+/* The same validator for CIGAR strings from anywhere ("<len><op>", op in MXID, '=' read as M): string i is
+ * cigar_pool + cigar_off[i], NUL-terminated, against the batch's resident pair i; cigar_off[i] < 0 -> -1.
+ * What `align_benchmark -c correct` does per pair on the host (benchmark_check.c), at batch scale. */
+quicked_status_t quicked_batch_validate(quicked_batch_t* batch, const char* cigar_pool, int64_t pool_bytes,
+                                        const int64_t* cigar_off, int32_t* ok_out);
+
 /* counters of the last run, for the measurement harness:
  *   [0] block-advances of score-only BandEd passes   [1] of fills
  *   [2] WindowEd block steps   [3] traceback steps   [4] CIGAR ops

@@ -610,6 +610,27 @@ int qo_cigar_check(const char* pattern, int plen, const char* text, int tlen,
     return v == plen && h == tlen;
 }
 
+/* SAM CIGAR of an operations string: cigar_compute_CIGAR (cigar.c:194-240) + cigar_sprint_SAM_CIGAR
+ * (cigar.c:504-529: "%d%c" over "MIDN---=X").  With show_mismatches M prints as '='; without it every X
+ * becomes M before equal neighbours are merged -- except the very first operation, which the reference
+ * reads before its mapping step (cigar.c:211 vs 217): a leading X is emitted as "1X" and only the
+ * operations after it fold.  Kept as is: the compiled reference pins it.  buf >= 2*n+10 bytes. */
+int64_t qo_cigar_sam(const char* ops, int64_t n, int show_mismatches, char* buf) {
+    int64_t cur = 0;
+    buf[0] = '\0';
+    if (n <= 0) return 0;
+    char last = ops[0];
+    int64_t len = 1;
+    for (int64_t i = 1; i <= n; ++i) {
+        char op = 0;
+        if (i < n) { op = ops[i]; if (!show_mismatches && op == 'X') op = 'M'; }
+        if (i < n && op == last) { ++len; continue; }
+        cur += sprintf(buf + cur, "%lld%c", (long long)len, (show_mismatches && last == 'M') ? '=' : last);
+        last = op; len = 1;
+    }
+    return cur;
+}
+
 int64_t qo_rle_to_ops(const char* rle, char* ops, int64_t max_ops) {   /* cigar.c:252-270 */
     int64_t n = 0, num = 0;
     for (const char* p = rle; *p; ++p) {

@@ -102,6 +102,8 @@ int64_t qo_cigar_score(const char* ops, int64_t n);
 /* alignment validity: ops transform pattern into text (cigar.c:363-434) */
 int qo_cigar_check(const char* pattern, int plen, const char* text, int tlen,
                    const char* ops, int64_t n);
+/* SAM CIGAR string ("=XID" with show_mismatches, else "MID" with X folded into M; cigar.c:194-240, 504-529) */
+int64_t qo_cigar_sam(const char* ops, int64_t n, int show_mismatches, char* buf);
 /* parse an RLE string back into ops (cigar.c:252-270); returns count */
 int64_t qo_rle_to_ops(const char* rle, char* ops, int64_t max_ops);
 

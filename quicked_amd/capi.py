@@ -54,7 +54,8 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_align", "quicked_set_device", "quicked_align_batch", "quicked_batch_create",
            "quicked_batch_destroy", "quicked_batch_run", "quicked_batch_sync", "quicked_batch_scores",
            "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters",
-           "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free"]
+           "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free",
+           "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate"]
 
 _LIB = None
 
@@ -96,6 +97,9 @@ def lib():
     L.quicked_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
     L.quicked_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.quicked_batch_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.quicked_batch_check_results.argtypes = [C.c_void_p, C.c_void_p]
+    L.quicked_batch_validate.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.quicked_host_alloc.restype = C.c_void_p
     L.quicked_host_alloc.argtypes = [C.c_size_t]
     L.quicked_host_free.argtypes = [C.c_void_p]
@@ -197,6 +201,29 @@ class ResidentBatch:
 
     def sync(self):
         return self._lib.quicked_batch_sync(self._h)
+
+    def configure(self, cigar_style=0, check=False):
+        """cigar_style 0 = reference RLE "MXID", 1 = SAM "=XID", 2 = SAM "MID"; check = device-side validator"""
+        return self._lib.quicked_batch_configure(self._h, cigar_style, 1 if check else 0)
+
+    def validate(self, cigars):
+        """device-side cigar_check_alignment of one CIGAR string (or None) per pair -> int32 verdicts"""
+        off = np.full(self.n, -1, dtype=np.int64)
+        blob = bytearray()
+        for i, c in enumerate(cigars):
+            if c is not None:
+                off[i] = len(blob)
+                blob += c.encode() + b"\0"
+        ok = np.zeros(self.n, dtype=np.int32)
+        st = self._lib.quicked_batch_validate(self._h, bytes(blob), len(blob), off.ctypes.data, ok.ctypes.data)
+        if st < 0:
+            raise QuickedException(st)
+        return ok
+
+    def check_results(self):
+        ok = np.zeros(self.n, dtype=np.int32)
+        self._lib.quicked_batch_check_results(self._h, ok.ctypes.data)
+        return ok
 
     def scores(self):
         s = np.zeros(self.n, dtype=np.int32)

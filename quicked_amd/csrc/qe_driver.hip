@@ -224,6 +224,9 @@ struct quicked_batch {
     std::vector<int64_t> cigar_off;
     std::vector<char> cigar_pool;
     bool only_score_run = true;
+    int cigar_style = 0;                          // SegFormatArgs::style of the runs to come (quicked_batch_configure)
+    bool check = false;                           // validate every CIGAR on the device (k_check_segs)
+    std::vector<int32_t> check_ok;                // last run: 1 valid, 0 not, -1 no alignment
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // results of the last run, device side, indexed by task (what a timed run leaves in HBM)
     int32_t* d_score = nullptr;
@@ -549,10 +552,11 @@ struct AlignOut {                             // device, per root
     int32_t *len = nullptr, *edits = nullptr, *nops = nullptr;
     int64_t *str_off = nullptr, *total = nullptr;
     char* pool = nullptr;
+    int32_t* ok = nullptr;                    // validator verdicts (null unless the batch asks for them)
     size_t nroots = 0;
 };
 
-static AlignOut format_segments(Context& C, const SegList& SL, const u32* runs, const int64_t* g_runs_off,
+static AlignOut format_segments(const quicked_batch& B, Context& C, const SegList& SL, const u32* runs, const int64_t* g_runs_off,
                                 const int32_t* nruns, bool want_strings) {
     AlignOut A;
     A.nroots = SL.root_pair.size();
@@ -572,7 +576,14 @@ static AlignOut format_segments(Context& C, const SegList& SL, const u32* runs, 
     f.npairs = (int32_t)nr; f.seg_off = d_off; f.seg_kind = d_kind; f.seg_a = d_a; f.seg_b = d_b;
     f.runs = runs; f.g_runs_off = g_runs_off; f.nruns = nruns;
     f.o_len = A.len; f.o_edits = A.edits; f.o_nops = A.nops; f.str_off = A.str_off; f.pool = A.pool;
+    f.style = B.cigar_style;
     const int blocks = (int)((nr + 63) / 64);
+    if (B.check && want_strings) {
+        A.ok = C.scratch_p->take<int32_t>(nr + 1);
+        SegCheckArgs ck;
+        ck.F = f; ck.P = pair_view(B, false); ck.root_pair = d_rootpair; ck.o_ok = A.ok;
+        hipLaunchKernelGGL(k_check_segs, dim3(blocks), dim3(64), 0, C.stream, ck);
+    }
     hipLaunchKernelGGL(k_format_segs<false>, dim3(blocks), dim3(64), 0, C.stream, f);
     if (want_strings) {
         hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, C.stream, A.len, d_rootpair, A.str_off, A.total, (int)nr);
@@ -587,6 +598,8 @@ static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, co
     std::vector<int32_t> len, edits, nops; std::vector<int64_t> off;
     d2h(len, A.len, A.nroots, C.stream); d2h(edits, A.edits, A.nroots, C.stream); d2h(nops, A.nops, A.nroots, C.stream);
     if (want_strings) d2h(off, A.str_off, A.nroots, C.stream);
+    std::vector<int32_t> okv;
+    if (A.ok) d2h(okv, A.ok, A.nroots, C.stream);
     HIP_CHECK(hipStreamSynchronize(C.stream));
     int64_t total = 0;
     if (want_strings) for (size_t i = 0; i < A.nroots; ++i) total = std::max<int64_t>(total, off[i] + len[i] + 1);
@@ -600,6 +613,7 @@ static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, co
         B.score[pr] = edits[i];
         B.status[pr] = root_status ? (*root_status)[i] : ok_status;
         B.counters[4] += nops[i];
+        if (A.ok) B.check_ok[pr] = okv[i];
         if (want_strings && len[i] > 0) {
             B.cigar_off[pr] = (int64_t)B.cigar_pool.size();
             B.cigar_pool.insert(B.cigar_pool.end(), tmp.begin() + off[i], tmp.begin() + off[i] + len[i] + 1);
@@ -646,7 +660,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
             SL.off.push_back((int64_t)SL.kind.size());
             SL.root_pair.push_back(L.pair[t]); SL.bound.push_back(cigar_bound(L.m[t], L.n[t]));
         }
-        AO = format_segments(C, SL, D.runs, D.runs_off, O.nruns, want_cigar);
+        AO = format_segments(B, C, SL, D.runs, D.runs_off, O.nruns, want_cigar);
         if (d_score_out) *d_score_out = AO.edits;
     }
     if (fetch && R) {
@@ -839,7 +853,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             C.scratch_p->release(mark);
         }
     }
-    const AlignOut AO = format_segments(C, SL, d_runs, d_runs_off, O.nruns, want_cigar);
+    const AlignOut AO = format_segments(B, C, SL, d_runs, d_runs_off, O.nruns, want_cigar);
     if (d_score_out) *d_score_out = AO.edits;
     if (fetch) {
         if (stats) {
@@ -921,6 +935,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
     B.cigar_off.assign((size_t)B.n, -1);
     B.cigar_pool.clear();
+    B.check_ok.assign((size_t)B.n, -1);
     for (auto& c : B.counters) c = 0;
     if ((unsigned)p.algo > (unsigned)HIRSCHBERG) {
         if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNKNOWN_ALGO);
@@ -1296,6 +1311,48 @@ QE_API quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar
     if (cigar_pool && !batch->cigar_pool.empty()) memcpy(cigar_pool, batch->cigar_pool.data(), batch->cigar_pool.size());
     if (cigar_off) memcpy(cigar_off, batch->cigar_off.data(), (size_t)batch->n * sizeof(int64_t));
     return QUICKED_OK;
+}
+
+QE_API quicked_status_t quicked_batch_configure(quicked_batch_t* batch, int cigar_style, int check) {
+    if (!batch || cigar_style < 0 || cigar_style > 2) return QUICKED_ERROR;
+    batch->cigar_style = cigar_style;
+    batch->check = check != 0;
+    return QUICKED_OK;
+}
+
+QE_API quicked_status_t quicked_batch_check_results(quicked_batch_t* batch, int32_t* ok_out) {
+    if (!batch || batch->check_ok.size() != (size_t)batch->n) return QUICKED_ERROR;
+    memcpy(ok_out, batch->check_ok.data(), (size_t)batch->n * sizeof(int32_t));
+    return QUICKED_OK;
+}
+
+QE_API quicked_status_t quicked_batch_validate(quicked_batch_t* batch, const char* cigar_pool, int64_t pool_bytes,
+                                               const int64_t* cigar_off, int32_t* ok_out) {
+    struct Arg { const char* pool; int64_t bytes; const int64_t* off; int32_t* ok; } arg{cigar_pool, pool_bytes, cigar_off, ok_out};
+    return guard(batch, [](quicked_batch* B, void* a) {
+        Arg* x = (Arg*)a;
+        if (!x->off || !x->ok || (x->bytes > 0 && !x->pool)) return QUICKED_ERROR;
+        tl_device = B->device;
+        Context& C = ctx();
+        for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+        HIP_CHECK(hipStreamSynchronize(C.stream_w));
+        C.phase_w();
+        const DevicePool::Mark mk = C.pool_w.mark();
+        char* d_pool = C.pool_w.take<char>((size_t)x->bytes + 16);
+        int64_t* d_off = C.pool_w.take<int64_t>((size_t)B->n + 1);
+        int32_t* d_ok = C.pool_w.take<int32_t>((size_t)B->n + 1);
+        if (x->bytes > 0) HIP_CHECK(hipMemcpyAsync(d_pool, x->pool, (size_t)x->bytes, hipMemcpyHostToDevice, C.stream));
+        HIP_CHECK(hipMemsetAsync(d_pool + x->bytes, 0, 16, C.stream));      // a missing terminator cannot run off the pool
+        HIP_CHECK(hipMemcpyAsync(d_off, x->off, (size_t)B->n * sizeof(int64_t), hipMemcpyHostToDevice, C.stream));
+        for (int64_t i = 0; i < B->n; ++i) if (x->off[i] >= x->bytes) return QUICKED_ERROR;
+        const int blocks = (int)((B->n + 63) / 64);
+        hipLaunchKernelGGL(k_check_strings, dim3(blocks), dim3(64), 0, C.stream, pair_view(*B, false), (int)B->n,
+                           (const char*)d_pool, (const int64_t*)d_off, d_ok);
+        HIP_CHECK(hipMemcpyAsync(x->ok, d_ok, (size_t)B->n * sizeof(int32_t), hipMemcpyDeviceToHost, C.stream));
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        C.pool_w.release(mk);
+        return QUICKED_OK;
+    }, &arg);
 }
 
 QE_API quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]) {

@@ -1384,6 +1384,7 @@ __global__ __launch_bounds__(64) void k_join(JoinArgs A) {
 // leaf's runs were emitted back to front), merging equal neighbours.
 // ===========================================================================
 struct RunMerger {
+    int style = 0;                  // SegFormatArgs::style
     int op = -1, len = 0, total = 0, edits = 0, nops = 0;
     char* out = nullptr;
     u64 buf = 0; int nb = 0;        // up to 7 characters waiting for an 8-byte store
@@ -1400,7 +1401,8 @@ struct RunMerger {
         if (len <= 0) return;
         const int d = dec_digits((u32)len);
         if (WRITE) {
-            const u64 opc = (u64)((0x4449584Du >> (8 * (op & 3))) & 0xFFu);   // "MXID"
+            const u32 letters = (style == 1) ? 0x4449583Du : 0x4449584Du;     // "=XID" : "MXID"
+            const u64 opc = (u64)((letters >> (8 * (op & 3))) & 0xFFu);
             u32 x = (u32)len;
             if (d <= 7) {
                 u64 tok = opc;
@@ -1419,10 +1421,17 @@ struct RunMerger {
     }
     template <bool WRITE> __device__ __forceinline__ void push(int o, int n) {
         if (n <= 0) return;
-        if (o == op) len += n;
-        else { emit<WRITE>(); op = o; len = n; }
         nops += n;
         if (o != (int)OP_M) edits += n;
+        if (style == 2 && o == (int)OP_X) {                           // SAM "M" covers matches and mismatches ...
+            if (nops == n && op < 0) {                                // ... but the reference reads the alignment's very first
+                op = (int)OP_X; len = 1;                              // operation before its mapping step (cigar.c:211 vs 217):
+                if (--n == 0) return;                                 // a leading X stays "1X"
+            }
+            o = (int)OP_M;
+        }
+        if (o == op) len += n;
+        else { emit<WRITE>(); op = o; len = n; }
     }
     __device__ __forceinline__ void finish() {                       // the waiting characters and the terminator
         for (int k = 0; k < nb; ++k) out[k] = (char)(buf >> (8 * k));
@@ -1435,6 +1444,7 @@ __global__ __launch_bounds__(64) void k_format_segs(SegFormatArgs A) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= A.npairs) return;
     RunMerger Mg;
+    Mg.style = A.style;
     if (WRITE) Mg.out = A.pool + A.str_off[i];
     for (int64_t sidx = A.seg_off[i]; sidx < A.seg_off[i + 1]; ++sidx) {
         if (A.seg_kind[sidx] == 1) { Mg.push<WRITE>(A.seg_a[sidx], A.seg_b[sidx]); continue; }
@@ -1451,6 +1461,79 @@ __global__ __launch_bounds__(64) void k_format_segs(SegFormatArgs A) {
 }
 template __global__ void k_format_segs<false>(SegFormatArgs);
 template __global__ void k_format_segs<true>(SegFormatArgs);
+
+// ===========================================================================
+// Validator (cigar_check_alignment, cigar.c:363-434): one lane per alignment walks its operations front
+// to back over the RAW bytes of the pair: M needs equal bytes, X different ones, I consumes text, D
+// pattern; both sequences must be consumed exactly.
+// ===========================================================================
+struct AlignCheck {
+    const uint8_t* ap; const uint8_t* at; int m, n, v = 0, h = 0; bool ok = true;
+    __device__ __forceinline__ void apply(int op, int cnt) {
+        if (!ok || cnt <= 0) return;
+        if (op == (int)OP_I) { h += cnt; return; }
+        if (op == (int)OP_D) { v += cnt; return; }
+        if (v + cnt > m || h + cnt > n) { ok = false; return; }
+        int k = 0;
+        if (op == (int)OP_M) {
+            for (; k + 8 <= cnt; k += 8) {
+                u64 x, y; __builtin_memcpy(&x, ap + v + k, 8); __builtin_memcpy(&y, at + h + k, 8);
+                if (x != y) { ok = false; return; }
+            }
+            for (; k < cnt; ++k) if (ap[v + k] != at[h + k]) { ok = false; return; }
+        } else {
+            for (; k < cnt; ++k) if (ap[v + k] == at[h + k]) { ok = false; return; }
+        }
+        v += cnt; h += cnt;
+    }
+    __device__ __forceinline__ int verdict() const { return (ok && v == m && h == n) ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(64) void k_check_segs(SegCheckArgs C) {
+    const SegFormatArgs& A = C.F;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= A.npairs) return;
+    const int pair = C.root_pair[i];
+    AlignCheck K;
+    K.ap = C.P.asc_p + C.P.asc_p_off[pair]; K.at = C.P.asc_t + C.P.asc_t_off[pair];
+    K.m = C.P.p_len[pair]; K.n = C.P.t_len[pair];
+    for (int64_t sidx = A.seg_off[i]; sidx < A.seg_off[i + 1]; ++sidx) {
+        if (A.seg_kind[sidx] == 1) { K.apply(A.seg_a[sidx], A.seg_b[sidx]); continue; }
+        const int t = A.seg_a[sidx];
+        const u32* runs = A.runs + A.g_runs_off[t >> 6] + (t & 63);
+        for (int k = A.nruns[t] - 1; k >= 0; --k) {
+            const u32 r = runs[(int64_t)k * 64];
+            K.apply((int)(r & 3), (int)(r >> 2));
+        }
+    }
+    C.o_ok[i] = K.verdict();
+}
+
+// The same walk over caller-supplied CIGAR strings ("<len><op>" with op in MXID, or '=' for M): pair i's string
+// starts at pool + off[i] and is NUL-terminated; off[i] < 0 = no string (verdict -1)
+__global__ __launch_bounds__(64) void k_check_strings(PairView P, int npairs, const char* pool, const int64_t* off, int32_t* o_ok) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= npairs) return;
+    if (off[i] < 0) { o_ok[i] = -1; return; }
+    AlignCheck K;
+    K.ap = P.asc_p + P.asc_p_off[i]; K.at = P.asc_t + P.asc_t_off[i];
+    K.m = P.p_len[i]; K.n = P.t_len[i];
+    const char* q = pool + off[i];
+    int64_t num = 0; bool have = false;
+    for (;; ++q) {
+        const char c = *q;
+        if (c == 0) break;
+        if (c >= '0' && c <= '9') { num = num * 10 + (c - '0'); have = true; if (num > 0x7fffffff) { K.ok = false; break; } continue; }
+        int op = -1;
+        if (c == 'M' || c == '=') op = (int)OP_M; else if (c == 'X') op = (int)OP_X;
+        else if (c == 'I') op = (int)OP_I; else if (c == 'D') op = (int)OP_D;
+        if (op < 0 || !have || num == 0) { K.ok = false; break; }
+        K.apply(op, (int)num);
+        num = 0; have = false;
+    }
+    if (have) K.ok = false;                 // digits without an operation
+    o_ok[i] = K.verdict();
+}
 
 // exclusive scan of (len + 1) over tasks -> string offsets; single block
 __global__ __launch_bounds__(1024) void k_scan_offsets(const int32_t* len, const int32_t* pair, int64_t* off, int64_t* total, int n) {

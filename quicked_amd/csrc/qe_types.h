@@ -124,6 +124,17 @@ struct SegFormatArgs {
     const u32* runs;  const int64_t* g_runs_off;  const int32_t* nruns;   // per leaf task
     int32_t* o_len;  int32_t* o_edits;  int32_t* o_nops;                  // per pair-list entry
     const int64_t* str_off;  char* pool;
+    // 0: the reference's RLE "MXID" (cigar_sprint, cigar.c:453-488); 1: SAM with mismatches "=XID";
+    // 2: SAM "MID", X folded into M before runs are merged (cigar_compute_CIGAR, cigar.c:194-240, 504-529)
+    int32_t style;
+};
+
+// cigar_check_alignment (cigar.c:363-434) of every entry's alignment against the raw bytes of its pair
+struct SegCheckArgs {
+    SegFormatArgs F;
+    PairView P;
+    const int32_t* root_pair;
+    int32_t* o_ok;               // 1 valid, 0 not
 };
 
 }  // namespace qe

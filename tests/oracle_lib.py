@@ -70,6 +70,8 @@ def oracle():
         lib.qo_cigar_score.argtypes = [C.c_char_p, C.c_int64]
         lib.qo_cigar_check.restype = C.c_int
         lib.qo_cigar_check.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int64]
+        lib.qo_cigar_sam.restype = C.c_int64
+        lib.qo_cigar_sam.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_char_p]
         lib.qo_rle_to_ops.restype = C.c_int64
         lib.qo_rle_to_ops.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
         lib.qo_exact_distance.restype = C.c_int64
@@ -113,6 +115,36 @@ def rle_to_ops(rle):
     got = lib.qo_rle_to_ops(rle.encode(), buf, n)
     assert got == n
     return buf.raw[:n]
+
+
+def sam_cigar(rle, show_mismatches):
+    """oracle: the reference's RLE string -> SAM CIGAR ("=XID" or, with X folded into M, "MID")"""
+    if rle is None:
+        return None
+    ops = rle_to_ops(rle)
+    buf = C.create_string_buffer(2 * len(ops) + 16)
+    oracle().qo_cigar_sam(ops, len(ops), 1 if show_mismatches else 0, buf)
+    return buf.value.decode()
+
+
+class RefCigar(C.Structure):
+    """cigar_t, quicked_utils/include/cigar.h:33-46"""
+    _fields_ = [("operations", C.c_char_p), ("cigar_buffer", C.POINTER(C.c_uint32)), ("cigar_length", C.c_int),
+                ("max_operations", C.c_int), ("begin_offset", C.c_int), ("end_offset", C.c_int),
+                ("score", C.c_int), ("end_v", C.c_int), ("end_h", C.c_int)]
+
+
+def ref_sam_cigar(ops, show_mismatches):
+    """the compiled reference's cigar_sprint_SAM_CIGAR (cigar.c:504-529) over an operations string"""
+    lib = ref()
+    lib.cigar_sprint_SAM_CIGAR.restype = C.c_int
+    lib.cigar_sprint_SAM_CIGAR.argtypes = [C.c_char_p, C.c_int, C.POINTER(RefCigar), C.c_bool]
+    n = len(ops)
+    cbuf = (C.c_uint32 * (n + 1))()
+    cg = RefCigar(ops, cbuf, 0, n, 0, n, 0, -1, -1)
+    out = C.create_string_buffer(12 * n + 16)     # the reference passes buf_size to every snprintf: be generous
+    lib.cigar_sprint_SAM_CIGAR(out, 12 * n + 16, C.byref(cg), bool(show_mismatches))
+    return out.value.decode()
 
 
 def cigar_is_valid(pattern, text, rle):

@@ -455,3 +455,67 @@ def test_interleaved_batches_and_async_runs():
         st, s, cg = O.oracle_align(p, t, algo=3)
         assert (stc[i], sc[i], cc[i]) == (st, s, cg), i
     ra.close(); rb.close()
+
+
+def test_sam_cigar_styles_and_device_validator(monkeypatch):
+    """SAM CIGAR output ("=XID" / "MID") byte-identical to the oracle's restatement of the reference
+    printer, and the device-side cigar_check_alignment: in-run verdicts and caller-supplied strings"""
+    monkeypatch.setenv("QE_SPLIT_BYTES", "65536")           # Hirschberg roots made of several segments
+    batch = datagen.generate(count=150, length=1200, error=0.1, seed=4242)
+    pairs = list(batch.pairs())
+    rb = capi.ResidentBatch(batch)
+    for algo in (capi.QUICKED, capi.BANDED, capi.WINDOWED, capi.HIRSCHBERG):
+        kw = dict(algo=algo) if algo != capi.WINDOWED else dict(algo=algo, window_size=2)
+        exp = [O.oracle_align(p, t, **kw) for p, t in pairs]
+        for style in (0, 1, 2):
+            assert rb.configure(cigar_style=style, check=True) == 0
+            assert rb.run(capi.make_params(**kw), sync=True) >= 0
+            sc, st = rb.scores()
+            cg = rb.cigars()
+            ok = rb.check_results()
+            for i, (est, esc, ecg) in enumerate(exp):
+                assert (st[i], sc[i]) == (est, esc)
+                want = ecg if style == 0 else O.sam_cigar(ecg, style == 1)
+                assert cg[i] == want, (algo, style, i)
+                assert ok[i] == 1, (algo, style, i)
+    rb.configure(cigar_style=0, check=False)
+    # caller-supplied strings: good ones (all three styles), broken ones, missing ones
+    good = [O.oracle_align(p, t, algo=0)[2] for p, t in pairs]
+    assert (rb.validate(good) == 1).all()
+    assert (rb.validate([O.sam_cigar(c, True) for c in good]) == 1).all()
+    bad = list(good)
+    bad[0] = None                                            # no string
+    bad[1] = good[1] + "1M"                                  # runs past both sequences
+    bad[2] = "1X" + good[2]                                  # shifted
+    bad[3] = good[3].replace("X", "M", 1) if "X" in good[3] else "1M"      # a mismatch claimed as match
+    bad[4] = good[4][:-1]                                    # digits without an operation
+    bad[5] = "7Q"                                            # unknown operation
+    bad[6] = good[7]                                         # another pair's alignment
+    v = rb.validate(bad)
+    assert v[0] == -1 and (v[1:7] == 0).all() and (v[7:] == 1).all()
+    for i in range(1, 7):                                    # the oracle's validator agrees on the parsable ones
+        if i in (4, 5):
+            continue
+        assert not O.cigar_is_valid(pairs[i][0], pairs[i][1], bad[i])
+    rb.close()
+    # ragged / empty / non-canonical input: raw-byte semantics of the validator
+    mixed = mixed_batch()
+    al = capi.QuickedAligner()
+    st, out = al.alignBatch(mixed)
+    mb = datagen.PairBatch(*_pools(mixed))
+    rm = capi.ResidentBatch(mb)
+    v = rm.validate([o[2] if o[0] >= 0 else None for o in out])
+    for i, o in enumerate(out):
+        assert v[i] == (1 if o[0] >= 0 else -1), i
+    rm.close()
+
+
+def _pools(pairs):
+    import numpy as np
+    pp = np.frombuffer(b"".join(p for p, _ in pairs) or b"\0", dtype=np.uint8).copy()
+    tp = np.frombuffer(b"".join(t for _, t in pairs) or b"\0", dtype=np.uint8).copy()
+    pl = np.array([len(p) for p, _ in pairs], dtype=np.int32)
+    tl = np.array([len(t) for _, t in pairs], dtype=np.int32)
+    po = np.concatenate([[0], np.cumsum(pl[:-1])]).astype(np.int64)
+    to = np.concatenate([[0], np.cumsum(tl[:-1])]).astype(np.int64)
+    return pp, po, pl, tp, to, tl

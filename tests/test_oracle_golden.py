@@ -55,3 +55,14 @@ def test_exact_distance_agrees_with_golden_quicked(golden):
     lib = O.oracle()
     for i, (p, t) in enumerate(batch.pairs()):
         assert lib.qo_exact_distance(p, len(p), t, len(t)) == entry["runs"]["quicked"]["score"][i]
+
+
+def test_sam_cigar_known_answers():
+    """SAM CIGAR restatement (cigar.c:194-240, 504-529): X folds into M before merging unless mismatches are shown"""
+    assert O.sam_cigar("2M1X1M", True) == "2=1X1="
+    assert O.sam_cigar("2M1X1M", False) == "4M"
+    assert O.sam_cigar("4M6D", True) == "4=6D" and O.sam_cigar("4M6D", False) == "4M6D"
+    assert O.sam_cigar("1X3M2I1X1M1D", False) == "1X3M2I2M1D"      # the reference does not fold the very first op
+    assert O.sam_cigar("3X2M", False) == "1X4M"
+    assert O.sam_cigar("2M1X3M2I1X1M1D", False) == "6M2I2M1D"
+    assert O.sam_cigar("1X3M2I1X1M1D", True) == "1X3=2I1X1=1D"

@@ -58,3 +58,18 @@ def test_hirschberg_small_splits_are_optimal():
             assert st == O.OK and tr.hirschberg_splits > 0
             assert lib.qo_cigar_check(p, len(p), t, len(t), ops, n.value)
             assert lib.qo_cigar_score(ops, n.value) == exact
+
+
+def test_sam_cigar_restatement_matches_the_reference_printer():
+    """qo_cigar_sam against cigar_compute_CIGAR + cigar_sprint_SAM_CIGAR of the compiled reference
+    (cigar.c:194-240, 504-529), both mismatch modes, on real alignments and on hand-made op strings"""
+    cases = [b"M", b"X", b"MMXMM", b"XXMMIIDDMX", b"IIII", b"DMD", b"MXMXMX", b"XMMMMMMMMMMMMX" * 3]
+    batch = datagen.generate(count=12, length=400, error=0.12, seed=777)
+    for p, t in batch.pairs():
+        st, sc, cg = O.oracle_align(p, t, algo=0)
+        cases.append(O.rle_to_ops(cg))
+    for ops in cases:
+        for show in (False, True):
+            buf = C.create_string_buffer(2 * len(ops) + 16)
+            O.oracle().qo_cigar_sam(ops, len(ops), int(show), buf)
+            assert buf.value.decode() == O.ref_sam_cigar(ops, show), (ops[:40], show)
