@@ -49,6 +49,23 @@ quicked_batch_t* quicked_batch_create(int64_t n,
                                       const char* text_pool, const int64_t* text_off, const int32_t* text_len);
 void quicked_batch_destroy(quicked_batch_t* batch);
 
+/* ---- packed wire format (supersedes sequence_buffer_t, tools/align_benchmark/utils/sequence_buffer.h:30-50)
+ * For sequences over upper-case A, C, G, T (and N in PLANES3) -- the symbols whose raw-byte and encoded
+ * comparisons agree (dna_text.c:41-46, bpm_banded.c:1012); everything else must use the ASCII form.
+ *   QUICKED_WIRE_2BIT     2 bits per base: base i of a sequence in bits 2(i%32).. of its word i/32,
+ *                         codes A 0, C 1, G 2, T 3; ceil(len/32) words
+ *   QUICKED_WIRE_PLANES3  per 64 bases three words {code bit 0, code bit 1, not-ACGT}; 3 ceil(len/64) words
+ * A packed batch uploads 4x / 2.7x fewer bytes than ASCII, keeps no bytes in HBM and skips the pack stage of
+ * every run; scores and CIGARs are identical to the ASCII batch of the same sequences.  The raw-byte
+ * validator is not available for it (QUICKED_UNIMPLEMENTED). */
+typedef enum { QUICKED_WIRE_2BIT = 2, QUICKED_WIRE_PLANES3 = 3 } quicked_wire_t;
+int64_t quicked_wire_words(int32_t len, int wire);
+/* host-side serializer of one sequence; QUICKED_ERROR if a symbol is not representable in `wire` */
+quicked_status_t quicked_wire_pack(const char* seq, int32_t len, int wire, uint64_t* out);
+quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
+                                             const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
+                                             const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len);
+
 /* Runs the hot path for every pair with `params` (algo, only_score, ...), from
  * the ASCII bytes resident in HBM to scores (and CIGAR runs) resident in HBM.
  * sync != 0: waits for the run and copies scores / statuses / CIGARs / counters

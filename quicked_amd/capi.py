@@ -55,7 +55,8 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_destroy", "quicked_batch_run", "quicked_batch_sync", "quicked_batch_scores",
            "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters",
            "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free",
-           "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate"]
+           "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
+           "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed"]
 
 _LIB = None
 
@@ -100,6 +101,11 @@ def lib():
     L.quicked_batch_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.quicked_batch_check_results.argtypes = [C.c_void_p, C.c_void_p]
     L.quicked_batch_validate.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.quicked_wire_words.restype = C.c_int64
+    L.quicked_wire_words.argtypes = [C.c_int32, C.c_int]
+    L.quicked_wire_pack.argtypes = [C.c_char_p, C.c_int32, C.c_int, C.c_void_p]
+    L.quicked_batch_create_packed.restype = C.c_void_p
+    L.quicked_batch_create_packed.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_host_alloc.restype = C.c_void_p
     L.quicked_host_alloc.argtypes = [C.c_size_t]
     L.quicked_host_free.argtypes = [C.c_void_p]
@@ -183,18 +189,61 @@ class QuickedAligner:
         return st, out
 
 
-class ResidentBatch:
-    """quicked_batch_* : upload once, run many times (what bench.py times)."""
+WIRE_2BIT, WIRE_PLANES3 = 2, 3
 
-    def __init__(self, batch):
+
+def wire_pack_pool(pool, off, length, wire):
+    """host-side serializer over a byte pool: -> (uint64 words back to back, word offsets); QuickedException if a
+    sequence holds a symbol the wire format cannot represent"""
+    L = lib()
+    nw = np.array([L.quicked_wire_words(int(n), wire) for n in length], dtype=np.int64)
+    woff = np.concatenate([[0], np.cumsum(nw[:-1])]).astype(np.int64) if len(nw) else np.zeros(0, np.int64)
+    words = np.zeros(int(nw.sum()) + 1, dtype=np.uint64)
+    base = pool.ctypes.data
+    for i in range(len(length)):
+        st = L.quicked_wire_pack(C.cast(base + int(off[i]), C.c_char_p), int(length[i]), wire,
+                                 words.ctypes.data + 8 * int(woff[i]))
+        if st < 0:
+            raise QuickedException(st)
+    return words, woff
+
+
+class ResidentBatch:
+    """quicked_batch_* : upload once, run many times (what bench.py times).  wire = WIRE_2BIT / WIRE_PLANES3 sends the
+    packed form (quicked_batch_create_packed) instead of the ASCII pools."""
+
+    def __init__(self, batch, wire=None):
+        self._h = None
         self._lib = lib()
         self.n = len(batch)
         self._keep = batch
-        self._h = self._lib.quicked_batch_create(
-            self.n, batch.pattern_pool.ctypes.data, batch.pattern_off.ctypes.data, batch.pattern_len.ctypes.data,
-            batch.text_pool.ctypes.data, batch.text_off.ctypes.data, batch.text_len.ctypes.data)
+        if wire is None:
+            self._h = self._lib.quicked_batch_create(
+                self.n, batch.pattern_pool.ctypes.data, batch.pattern_off.ctypes.data, batch.pattern_len.ctypes.data,
+                batch.text_pool.ctypes.data, batch.text_off.ctypes.data, batch.text_len.ctypes.data)
+        else:
+            pw, po = wire_pack_pool(batch.pattern_pool, batch.pattern_off, batch.pattern_len, wire)
+            tw, to = wire_pack_pool(batch.text_pool, batch.text_off, batch.text_len, wire)
+            self._wire = (pw, po, tw, to)
+            self._h = self._lib.quicked_batch_create_packed(
+                self.n, wire, pw.ctypes.data, po.ctypes.data, batch.pattern_len.ctypes.data,
+                tw.ctypes.data, to.ctypes.data, batch.text_len.ctypes.data)
         if not self._h:
             raise RuntimeError("quicked_batch_create failed (no GPU / out of memory?)")
+
+    @classmethod
+    def from_wire(cls, batch, wire, pw, po, tw, to):
+        """a batch from wire words that are already serialized (what a client holding packed data calls)"""
+        self = cls.__new__(cls)
+        self._lib = lib()
+        self.n = len(batch)
+        self._keep = (batch, pw, po, tw, to)
+        self._h = self._lib.quicked_batch_create_packed(
+            self.n, wire, pw.ctypes.data, po.ctypes.data, batch.pattern_len.ctypes.data,
+            tw.ctypes.data, to.ctypes.data, batch.text_len.ctypes.data)
+        if not self._h:
+            raise RuntimeError("quicked_batch_create_packed failed")
+        return self
 
     def run(self, params, sync=True):
         return self._lib.quicked_batch_run(self._h, C.byref(params), 1 if sync else 0)
@@ -282,6 +331,18 @@ def pinned_copy(batch):
     pb = PairBatch(out[0][0], batch.pattern_off, batch.pattern_len, out[1][0], batch.text_off, batch.text_len)
     pb._pinned = [p for _, p in out]
     return pb
+
+
+def pinned_array(arr):
+    """a copy of a numpy array in pinned host memory -> (array, pointer for quicked_host_free)"""
+    import numpy as _np
+    L = lib()
+    ptr = L.quicked_host_alloc(max(arr.nbytes, 8))
+    if not ptr:
+        raise MemoryError("quicked_host_alloc failed")
+    out = _np.ctypeslib.as_array((C.c_uint8 * max(arr.nbytes, 8)).from_address(ptr))[:arr.nbytes].view(arr.dtype)
+    out[:] = arr
+    return out, ptr
 
 
 def pinned_free(pb):

@@ -224,6 +224,7 @@ struct quicked_batch {
     std::vector<int64_t> cigar_off;
     std::vector<char> cigar_pool;
     bool only_score_run = true;
+    bool packed = false;                          // created from wire words: planes are the resident input, no ASCII, no k_pack
     int cigar_style = 0;                          // SegFormatArgs::style of the runs to come (quicked_batch_configure)
     bool check = false;                           // validate every CIGAR on the device (k_check_segs)
     std::vector<int32_t> check_ok;                // last run: 1 valid, 0 not, -1 no alignment
@@ -281,6 +282,18 @@ static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ng
 }
 
 static void launch_pack(quicked_batch& B, Context& C, bool reversed) {
+    if (B.packed) {                       // forward planes are the input; reversed ones come from them
+        if (!reversed) return;
+        const int blocks = (int)((B.n + 3) / 4);
+        RevArgs r;
+        r.nseq = (int32_t)B.n;
+        r.fwd = B.d_pl_p[0]; r.rev = B.d_pl_pr[0]; r.pl_off = B.d_plp_off; r.len = B.d_p_len;
+        hipLaunchKernelGGL(k_reverse_planes, dim3(blocks), dim3(256), 0, C.stream, r);
+        r.fwd = B.d_pl_t[0]; r.rev = B.d_pl_tr[0]; r.pl_off = B.d_plt_off; r.len = B.d_t_len;
+        hipLaunchKernelGGL(k_reverse_planes, dim3(blocks), dim3(256), 0, C.stream, r);
+        B.have_rev[0] = B.have_rev[1] = true;   // both parities alias the same buffers
+        return;
+    }
     PackArgs a;
     a.nseq = (int32_t)B.n;
     a.reverse = reversed ? 1 : 0;
@@ -942,7 +955,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         return QUICKED_UNKNOWN_ALGO;
     }
     HIP_CHECK(hipEventRecord(C.ev0, C.stream));
-    HIP_CHECK(hipMemsetAsync(B.d_flags[par], 0, (size_t)B.n * sizeof(u32), C.stream));
+    if (!B.packed) HIP_CHECK(hipMemsetAsync(B.d_flags[par], 0, (size_t)B.n * sizeof(u32), C.stream));
     launch_pack(B, C, false);
     if (!serial) HIP_CHECK(hipEventRecord(C.ev_pack, C.stream_w));
     // phase A starts on the device when the planes are there and (stream order) the previous run's A phase is over;
@@ -1252,6 +1265,104 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
     }
 }
 
+// ---- packed wire format (supersedes sequence_buffer_t, sequence_buffer.h:30-50) ----------------
+QE_API int64_t quicked_wire_words(int32_t len, int wire) {
+    if (len < 0) return -1;
+    if (wire == QUICKED_WIRE_2BIT) return ((int64_t)len + 31) / 32;
+    if (wire == QUICKED_WIRE_PLANES3) return 3 * (((int64_t)len + 63) / 64);
+    return -1;
+}
+
+// host-side serializer of one sequence (upper-case A, C, G, T; N only in PLANES3): the reference's code table
+// (dna_text.c:41-46) restricted to the symbols whose raw-byte and encoded comparisons agree
+QE_API quicked_status_t quicked_wire_pack(const char* seq, int32_t len, int wire, uint64_t* out) {
+    const int64_t nwords = quicked_wire_words(len, wire);
+    if (nwords < 0 || (len > 0 && (!seq || !out))) return QUICKED_ERROR;
+    for (int64_t i = 0; i < nwords; ++i) out[i] = 0;
+    for (int32_t i = 0; i < len; ++i) {
+        int code;
+        switch (seq[i]) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break;
+                          case 'N': code = 4; break; default: return QUICKED_ERROR; }
+        if (wire == QUICKED_WIRE_2BIT) {
+            if (code == 4) return QUICKED_ERROR;
+            out[i >> 5] |= (uint64_t)code << (2 * (i & 31));
+        } else {
+            uint64_t* row = out + 3 * (int64_t)(i >> 6);
+            const uint64_t bit = (uint64_t)1 << (i & 63);
+            if (code == 4) row[2] |= bit;
+            else { if (code & 1) row[0] |= bit; if (code & 2) row[1] |= bit; }
+        }
+    }
+    return QUICKED_OK;
+}
+
+QE_API quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
+                                                    const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
+                                                    const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len) {
+    if (wire != QUICKED_WIRE_2BIT && wire != QUICKED_WIRE_PLANES3) return nullptr;
+    quicked_batch* B = new quicked_batch();
+    try {
+        Context& C = ctx();
+        B->n = n; B->device = C.device; B->packed = true;
+        B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
+        B->p_off.assign((size_t)n, 0); B->t_off.assign((size_t)n, 0);
+        B->plp_off.resize((size_t)n); B->plt_off.resize((size_t)n);
+        // the wire pools are uploaded as the word spans they are
+        int64_t p_lo = INT64_MAX, p_hi = 0, t_lo = INT64_MAX, t_hi = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t pw = quicked_wire_words(pattern_len[i], wire), tw = quicked_wire_words(text_len[i], wire);
+            if (pw > 0) { p_lo = std::min(p_lo, pattern_word_off[i]); p_hi = std::max(p_hi, pattern_word_off[i] + pw); }
+            if (tw > 0) { t_lo = std::min(t_lo, text_word_off[i]); t_hi = std::max(t_hi, text_word_off[i] + tw); }
+            B->plp_off[i] = (int64_t)B->pl_p_words; B->pl_p_words += (size_t)3 * ((size_t)(pattern_len[i] + 63) / 64 + 2);
+            B->plt_off[i] = (int64_t)B->pl_t_words; B->pl_t_words += (size_t)3 * ((size_t)(text_len[i] + 63) / 64 + 2);
+        }
+        if (p_lo == INT64_MAX) { p_lo = 0; p_hi = 0; }
+        if (t_lo == INT64_MAX) { t_lo = 0; t_hi = 0; }
+        const size_t pw_total = (size_t)(p_hi - p_lo), tw_total = (size_t)(t_hi - t_lo);
+        std::vector<int64_t> pwo((size_t)n), two((size_t)n);
+        for (int64_t i = 0; i < n; ++i) { pwo[(size_t)i] = pattern_word_off[i] - p_lo; two[(size_t)i] = text_word_off[i] - t_lo; }
+        B->order.resize((size_t)n);
+        std::iota(B->order.begin(), B->order.end(), 0);
+        std::stable_sort(B->order.begin(), B->order.end(), [&](int a, int b) {
+            return std::max(B->p_len[a], B->t_len[a]) > std::max(B->p_len[b], B->t_len[b]);
+        });
+        auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+        B->arena_bytes = pad((pw_total + 8) * 8) + pad((tw_total + 8) * 8) + 6 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
+                         2 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + pad((size_t)n * 4) + 4096;
+        HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
+        qe::ArenaCarver A{B->arena, 0};
+        u64* d_pw = A.take<u64>(pw_total + 8); u64* d_tw = A.take<u64>(tw_total + 8);
+        int64_t* d_pwo = A.take<int64_t>((size_t)n); int64_t* d_two = A.take<int64_t>((size_t)n);
+        B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
+        B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
+        B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
+        B->d_pl_p[0] = B->d_pl_p[1] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[0] = B->d_pl_t[1] = A.take<u64>(B->pl_t_words + 8);
+        B->d_pl_pr[0] = B->d_pl_pr[1] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[0] = B->d_pl_tr[1] = A.take<u64>(B->pl_t_words + 8);
+        B->d_flags[0] = B->d_flags[1] = A.take<u32>((size_t)n);
+        for (int q = 0; q < 2; ++q) HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
+        if (pw_total) upload_span((uint8_t*)d_pw, (const uint8_t*)(pattern_words + p_lo), pw_total * 8, C.device);
+        if (tw_total) upload_span((uint8_t*)d_tw, (const uint8_t*)(text_words + t_lo), tw_total * 8, C.device);
+        h2d(d_pwo, pwo, C.stream); h2d(d_two, two, C.stream);
+        h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
+        h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
+        h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
+        HIP_CHECK(hipMemsetAsync(B->d_flags[0], 0, (size_t)n * sizeof(u32), C.stream));
+        const int blocks = (int)((n + 3) / 4);
+        WireArgs w;
+        w.nseq = (int32_t)n; w.wire = wire; w.flags = B->d_flags[0];
+        w.words = d_pw; w.w_off = d_pwo; w.len = B->d_p_len; w.planes = B->d_pl_p[0]; w.pl_off = B->d_plp_off;
+        hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
+        w.words = d_tw; w.w_off = d_two; w.len = B->d_t_len; w.planes = B->d_pl_t[0]; w.pl_off = B->d_plt_off;
+        hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        return B;
+    } catch (const HipError& e) {
+        fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+        delete B;
+        return nullptr;
+    }
+}
+
 QE_API void quicked_batch_destroy(quicked_batch_t* batch) {
     if (!batch) return;
     (void)hipDeviceSynchronize();
@@ -1315,6 +1426,7 @@ QE_API quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar
 
 QE_API quicked_status_t quicked_batch_configure(quicked_batch_t* batch, int cigar_style, int check) {
     if (!batch || cigar_style < 0 || cigar_style > 2) return QUICKED_ERROR;
+    if (check && batch->packed) return QUICKED_UNIMPLEMENTED;
     batch->cigar_style = cigar_style;
     batch->check = check != 0;
     return QUICKED_OK;
@@ -1332,6 +1444,7 @@ QE_API quicked_status_t quicked_batch_validate(quicked_batch_t* batch, const cha
     return guard(batch, [](quicked_batch* B, void* a) {
         Arg* x = (Arg*)a;
         if (!x->off || !x->ok || (x->bytes > 0 && !x->pool)) return QUICKED_ERROR;
+        if (B->packed) return QUICKED_UNIMPLEMENTED;          // the validator compares raw bytes; a packed batch has none
         tl_device = B->device;
         Context& C = ctx();
         for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));

@@ -355,6 +355,73 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A) {
     }
 }
 
+// ===========================================================================
+// Packed input: the wire words become planes once, at batch creation; runs skip k_pack.
+// ===========================================================================
+__device__ __forceinline__ u32 even_bits(u64 x) {          // bits 0, 2, 4, ... of x, compacted
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (u32)x;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_wire(WireArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= A.nseq) return;
+    const int len = A.len[seq];
+    const int nw = (len + 63) >> 6;
+    const u64* __restrict__ src = A.words + A.w_off[seq];
+    u64* __restrict__ dst = A.planes + A.pl_off[seq];
+    bool any_n = false;
+    for (int r = lane; r < nw + 2; r += 64) {
+        u64 a = 0, b = 0, nn = 0;
+        if (r < nw) {
+            if (A.wire == 3) { a = src[3 * (int64_t)r]; b = src[3 * (int64_t)r + 1]; nn = src[3 * (int64_t)r + 2]; }
+            else {
+                const int nwords = (len + 31) >> 5;               // 32 bases per wire word
+                const u64 w0 = src[2 * (int64_t)r], w1 = (2 * r + 1 < nwords) ? src[2 * (int64_t)r + 1] : 0;
+                a = (u64)even_bits(w0) | ((u64)even_bits(w1) << 32);
+                b = (u64)even_bits(w0 >> 1) | ((u64)even_bits(w1 >> 1) << 32);
+            }
+            const int valid = min(len - 64 * r, 64);
+            const u64 mask = (valid >= 64) ? QE_ONES : ((((u64)1) << valid) - 1);
+            nn &= mask; a &= mask & ~nn; b &= mask & ~nn;         // a non-ACGT base has code bits 0
+            any_n |= nn != 0;
+        }
+        u64* q = dst + 3 * (int64_t)r;
+        q[0] = a; q[1] = b; q[2] = nn;
+    }
+    if (A.flags && __any(any_n)) { if (lane == 0) atomicOr(&A.flags[seq], (u32)FLAG_HAS_N); }
+}
+
+__global__ __launch_bounds__(256) void k_reverse_planes(RevArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= A.nseq) return;
+    const int len = A.len[seq];
+    const int nw = (len + 63) >> 6;
+    const u64* __restrict__ src = A.fwd + A.pl_off[seq];
+    u64* __restrict__ dst = A.rev + A.pl_off[seq];
+    for (int r = lane; r < nw + 2; r += 64) {
+        u64 o[3] = {0, 0, 0};
+        if (r < nw) {
+            // reversed positions [64 r, 64 r + 64) are forward positions e-1 down to e-64, e = len - 64 r
+            const int s = len - 64 * r - 64;
+            u64 x[3];
+            if (s >= 0) load_planes(src, s, x[0], x[1], x[2]);
+            else { x[0] = src[0] << (-s); x[1] = src[1] << (-s); x[2] = src[2] << (-s); }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = __brevll(x[k]);
+        }
+        u64* q = dst + 3 * (int64_t)r;
+        q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // band geometry (bpm_banded.c:121-135)
 // ---------------------------------------------------------------------------

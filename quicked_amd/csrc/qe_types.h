@@ -50,6 +50,21 @@ struct PackArgs {
     int32_t reverse;
 };
 
+// packed wire format -> planes (quicked_batch_create_packed).  wire 2: 2 bits per base, base i of a sequence in bits
+// 2(i%32).. of word i/32, codes A0 C1 G2 T3 (dna_text.c:41-46), no N; wire 3: the plane layout itself, [row][3] =
+// {code bit 0, code bit 1, not-ACGT} per 64 bases, without the padding rows
+struct WireArgs {
+    int32_t nseq, wire;
+    const u64* words;  const int64_t* w_off;  const int32_t* len;
+    u64* planes;  const int64_t* pl_off;
+    u32* flags;          // FLAG_HAS_N is OR-ed in (may be null)
+};
+// planes of the reversed sequences from the forward planes (what k_pack(reverse) makes from ASCII)
+struct RevArgs {
+    int32_t nseq;
+    const u64* fwd;  u64* rev;  const int64_t* pl_off;  const int32_t* len;
+};
+
 // BandEd, score-only or fill (bpm_banded.c:791-964 / 199-316)
 struct BandedArgs {
     PairView P;

@@ -94,3 +94,29 @@ def test_new_free_and_early_errors_need_no_gpu(lib):
     assert lib.quicked_new(C.byref(a), C.byref(p)) == capi.QUICKED_WIP
     assert not a.timer and not a.timer_align
     assert lib.quicked_free(C.byref(a)) == capi.QUICKED_WIP
+
+
+def test_wire_serializer_known_answers():
+    """quicked_wire_pack is host code: 2-bit codes A0 C1 G2 T3 (dna_text.c:41-46), 32 bases per word; PLANES3 =
+    {code bit 0, code bit 1, not-ACGT} per 64 bases; unrepresentable symbols are refused"""
+    import ctypes as C
+    import numpy as np
+    from quicked_amd import capi
+    L = capi.lib()
+    assert L.quicked_wire_words(0, 2) == 0 and L.quicked_wire_words(32, 2) == 1 and L.quicked_wire_words(33, 2) == 2
+    assert L.quicked_wire_words(64, 3) == 3 and L.quicked_wire_words(65, 3) == 6 and L.quicked_wire_words(5, 7) == -1
+    out = np.zeros(4, dtype=np.uint64)
+    assert L.quicked_wire_pack(b"ACGTTGCA", 8, 2, out.ctypes.data) == 0
+    assert int(out[0]) == sum(c << (2 * i) for i, c in enumerate([0, 1, 2, 3, 3, 2, 1, 0]))
+    seq = b"ACGTN" + b"T" * 60
+    out = np.zeros(6, dtype=np.uint64)
+    assert L.quicked_wire_pack(seq, len(seq), 3, out.ctypes.data) == 0
+    codes = [{65: 0, 67: 1, 71: 2, 84: 3, 78: 4}[c] for c in seq]
+    for r in range(2):
+        row = codes[64 * r: 64 * r + 64]
+        assert int(out[3 * r]) == sum(1 << i for i, c in enumerate(row) if c < 4 and c & 1)
+        assert int(out[3 * r + 1]) == sum(1 << i for i, c in enumerate(row) if c < 4 and c & 2)
+        assert int(out[3 * r + 2]) == sum(1 << i for i, c in enumerate(row) if c == 4)
+    assert L.quicked_wire_pack(b"ACGN", 4, 2, out.ctypes.data) < 0      # N has no 2-bit code
+    assert L.quicked_wire_pack(b"ACgT", 4, 3, out.ctypes.data) < 0      # lower case: raw != encoded compare
+    assert L.quicked_wire_pack(b"ACRT", 4, 3, out.ctypes.data) < 0      # IUPAC

@@ -519,3 +519,41 @@ def _pools(pairs):
     po = np.concatenate([[0], np.cumsum(pl[:-1])]).astype(np.int64)
     to = np.concatenate([[0], np.cumsum(tl[:-1])]).astype(np.int64)
     return pp, po, pl, tp, to, tl
+
+
+@pytest.mark.parametrize("wire", [capi.WIRE_2BIT, capi.WIRE_PLANES3])
+def test_packed_wire_batches_equal_ascii_batches(wire, monkeypatch):
+    """a batch created from the packed wire words gives the scores / CIGARs of the ASCII batch (and of
+    the oracle) for every algorithm, including the reversed half passes of forced Hirschberg splits (planes reversed
+    on the device) and, for PLANES3, sequences with N"""
+    monkeypatch.setenv("QE_SPLIT_BYTES", "32768")
+    rng = np.random.default_rng(31 + wire)
+    base = datagen.generate(count=90, length=1500, error=0.08, seed=900 + wire)
+    pairs = []
+    for i, (p, t) in enumerate(base.pairs()):
+        p, t = bytearray(p[: 33 + 16 * i]), bytearray(t[: 47 + 16 * i])      # ragged: every row / word remainder
+        if wire == capi.WIRE_PLANES3 and i % 3 == 0:
+            for k in rng.integers(0, len(p), 3): p[k] = ord("N")
+            for k in rng.integers(0, len(t), 2): t[k] = ord("N")
+        pairs.append((bytes(p), bytes(t)))
+    batch = datagen.PairBatch(*_pools(pairs))
+    ra, rp = capi.ResidentBatch(batch), capi.ResidentBatch(batch, wire=wire)
+    for kw in (dict(algo=2, only_score=True, bandwidth=15), dict(algo=2), dict(algo=1), dict(algo=1, window_size=2),
+               dict(algo=0), dict(algo=3)):
+        prm = capi.make_params(**kw)
+        for _ in range(2):                                           # twice: the second run reuses reversed planes
+            assert ra.run(prm, sync=True) >= 0 and rp.run(prm, sync=True) >= 0
+            sa, sta = ra.scores(); sp, stp = rp.scores()
+            assert (sa == sp).all() and (sta == stp).all(), kw
+            if not kw.get("only_score"):
+                assert ra.cigars() == rp.cigars(), kw
+        for i in (0, 1, 17, 44, 89):
+            est, esc, ecg = O.oracle_align(pairs[i][0], pairs[i][1], **kw)
+            assert (stp[i], sp[i]) == (est, esc)
+    assert rp.configure(cigar_style=1, check=True) == capi.QUICKED_UNIMPLEMENTED
+    with pytest.raises(capi.QuickedException):
+        rp.validate(["1M"] * len(pairs))
+    ra.close(); rp.close()
+    if wire == capi.WIRE_2BIT:
+        with pytest.raises(capi.QuickedException):
+            capi.ResidentBatch(datagen.PairBatch(*_pools([(b"ACGN", b"ACGT")])), wire=wire)
