@@ -35,6 +35,43 @@ ISSUE_CYCLES_PER_BLOCK_COLUMN = 98.0
 VALU_PEAK_BLOCK_COLUMNS = 256 * 4 * 2.4e9 * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN
 OPS_PER_BLOCK_COLUMN = 32        # VALU instructions per 64-row block per column in that loop (256 / 8)
 
+def measured_copy_bandwidth(nbytes=1 << 30, reps=8):
+    """device-to-device copy rate on this box (print the measured bandwidth next to the 8 TB/s spec):
+    read + write bytes of hipMemcpyDtoD per second, GB/s, through the HIP runtime the library already loaded"""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        a, b, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if hip.hipMalloc(C.byref(a), C.c_size_t(nbytes)) or hip.hipMalloc(C.byref(b), C.c_size_t(nbytes)):
+            return None
+        hip.hipEventCreate(C.byref(e0)); hip.hipEventCreate(C.byref(e1))
+        hip.hipMemset(a, 1, C.c_size_t(nbytes))
+        hip.hipMemcpyDtoD(b, a, C.c_size_t(nbytes))
+        hip.hipDeviceSynchronize()
+        hip.hipEventRecord(e0, None)
+        for _ in range(reps):
+            hip.hipMemcpyDtoDAsync(b, a, C.c_size_t(nbytes), None)
+        hip.hipEventRecord(e1, None)
+        hip.hipEventSynchronize(e1)
+        ms = C.c_float()
+        hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+        hip.hipFree(a); hip.hipFree(b); hip.hipEventDestroy(e0); hip.hipEventDestroy(e1)
+        return 2.0 * nbytes * reps / (ms.value * 1e-3) / 1e9 if ms.value > 0 else None
+    except Exception:      # noqa: BLE001 -- a report field, not part of the path
+        return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(batch, params_kw, budget_s=15.0):
     """The compiled reference (oracle/_ref, kind "reference") or the oracle
     restatement (kind "port") on the host cores: oracle/cpu_bench.c, one aligner
@@ -69,7 +106,7 @@ def cpu_baseline(batch, params_kw, budget_s=15.0):
     per = w1 / n1
     n = int(min(len(batch), max(cores * 8, budget_s / per * cores)))
     wall, scores = run(n, cores)
-    return {"value": n / wall, "unit": "alignments/s", "cores": cores, "kind": kind,
+    return {"value": n / wall, "unit": "alignments/s", "cores": cores, "cpu_model": cpu_model(), "kind": kind,
             "sample": f"first {n} pairs of the same workload, {cores} OpenMP threads, one aligner per thread",
             "single_thread_value": 1.0 / per}, scores.astype(np.int64)
 
@@ -185,6 +222,8 @@ def main():
         line = {
             "metric": "alignments/sec + GCUPS, 10kb x 10kb 5%-error pairs",
             "value": value, "unit": "alignments/s", "gcups": tot_cells * args.steps / max_elapsed / 1e9,
+            # cells actually computed (SURVEY 8d "band GCUPS"): 64 rows x block-advances of the dominant kernel, this rank x world
+            "band_gcups": 64.0 * work_blocks * world * args.steps / max_elapsed / 1e9,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": max_elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -196,6 +235,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
                          "aggregate_achieved": alg_bytes / step_s / 1e9,
+                         "hbm_copy_measured_GBs": measured_copy_bandwidth(),
                          "note": "score-only BandEd is integer-VALU-bound, not HBM-bound (SURVEY 8d); see valu"},
             "valu": {"bound": "integer VALU issue", "achieved": valu_rate, "peak": VALU_PEAK_BLOCK_COLUMNS,
                      "unit": "block-columns/s", "frac": valu_rate / VALU_PEAK_BLOCK_COLUMNS,
