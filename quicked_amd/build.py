@@ -98,8 +98,21 @@ def build_ref_callers(force=False):
     return REF_CALLERS
 
 
+VALU_RATE = os.path.join(ROOT, "tools", "bin", "valu_rate")
+
+
+def build_valu_rate(force=False):
+    """tools/valu_rate.hip: per-instruction VALU issue rates of gfx950 (the table behind DESIGN.md 4.1)"""
+    src = os.path.join(ROOT, "tools", "valu_rate.hip")
+    os.makedirs(os.path.dirname(VALU_RATE), exist_ok=True)
+    if force or _newer(VALU_RATE, [src]):
+        _run(["hipcc", "--offload-arch=gfx950", "-O3", "-w", src, "-o", VALU_RATE])
+    return VALU_RATE
+
+
 def build_all(force=False):
     build_datagen(force)
     build_hip(force)
     build_harness(force)
     build_ref_callers(force)
+    build_valu_rate(force)
