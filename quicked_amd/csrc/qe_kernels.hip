@@ -132,13 +132,60 @@ __device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32
 // STORE: 0 nothing | 1 every column's {Pv after, Mv before} (tiled; WindowEd history) |
 //        2 a checkpoint {Pv, Mv after} every 8th column (BandEd fill: the traceback recomputes the 8 columns between)
 //        3 the same checkpoints, taken before each group of 8 columns, to st[grp * st_stride] (on-chip WindowEd windows)
-template <int STORE>
+// WIDE: two rolled passes over 32 literal columns instead of eight over 8.  The text / carry words are then
+// addressed as 32-bit halves with literal bit positions: the per-group 64-bit shifts (6 SIMD cycles each, seven per
+// group) and bit reversals disappear; costs 4x the code, so only the BandEd kernels use it.
+template <int STORE, bool WIDE = false>
 __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0, u64 T1,
                                            u64 hinP, u64 hinM, u64& houtP, u64& houtM,
                                            bool act, uint4* st, int64_t st_stride, uint4* st_last) {
     const u32 alo = lo32(a), ahi = hi32(a), blo = lo32(b), bhi = hi32(b);
     u32 Plo = lo32(P), Phi = hi32(P), Mlo = lo32(M), Mhi = hi32(M);
     u64 oP = 0, oM = 0;
+    if (WIDE) {
+        u32 oPlo = 0, oPhi = 0, oMlo = 0, oMhi = 0;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const u32 t0 = half ? hi32(T0) : lo32(T0), t1 = half ? hi32(T1) : lo32(T1);
+            const u32 hp = half ? hi32(hinP) : lo32(hinP), hm = half ? hi32(hinM) : lo32(hinM);
+            u32 gP = 0, gM = 0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0, c, 1);
+                const u32 m1 = (u32)__builtin_amdgcn_sbfe((int)t1, c, 1);
+                const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1);
+                const u32 ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
+                const u32 PHin = __builtin_amdgcn_ubfe(hp, c, 1);
+                const u32 MHin = __builtin_amdgcn_ubfe(hm, c, 1);
+                const u32 Mblo = Mlo, Mbhi = Mhi;
+                if (STORE == 3 && (c & 7) == 0) st[(4 * half + (c >> 3)) * st_stride] = make_uint4(Plo, Phi, Mlo, Mhi);
+                block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, gP, gM);
+                if (STORE == 1) {
+                    if (act) {
+                        // chunk column 32 half + c is stored column (64k) + 32 half + c + 1
+                        uint4* q = st + (int64_t)(4 * half + ((c + 1) >> 3)) * st_stride + ((c + 1) & 7);
+                        if (c == 31 && half == 1) q = st_last;
+                        *q = make_uint4(Plo, Phi, Mblo, Mbhi);
+                    }
+                }
+                if (STORE == 2 && (c & 7) == 7) {
+                    if (act) {
+                        uint4* q = st + (int64_t)(4 * half + (c >> 3) + 1) * st_stride;
+                        if (c == 31 && half == 1) q = st_last;
+                        *q = make_uint4(Plo, Phi, Mlo, Mhi);
+                    }
+                }
+            }
+            // gP / gM hold the 32 carries MSB-first
+            const u32 rP = __builtin_bitreverse32(gP), rM = __builtin_bitreverse32(gM);
+            if (half) { oPhi = rP; oMhi = rM; } else { oPlo = rP; oMlo = rM; }
+        }
+        P = mk64(Plo, Phi);
+        M = mk64(Mlo, Mhi);
+        houtP = mk64(oPlo, oPhi);
+        houtM = mk64(oMlo, oMhi);
+        return;
+    }
     // 8 groups of 8 columns: the group loop stays rolled (register pressure, I-cache), the
     // 8 columns inside are literal so every bit extract is a single v_bfe.
 #pragma unroll 1
@@ -551,7 +598,7 @@ __global__ __launch_bounds__(FILL ? 512 : 1024) void k_banded(BandedArgs A) {
             u64 houtP, houtM, sP, sM;
             const bool slow = act && (ncols != 64 || hasN || lastblk);
             if (!__any(slow)) {
-                run64_fast<FILL ? 2 : 0>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, cps, st_last);
+                run64_fast<FILL ? 2 : 0, true>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, st, cps, st_last);
                 sP = houtP; sM = houtM;
             } else {
                 run64_general<FILL ? 2 : 0>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,

@@ -192,6 +192,90 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters
                 asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
                 asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
             }
+            if (KIND == 25) {  // v_lshrrev_b64 by a register amount (one 64-bit shift = one op)
+                uint64_t x = ((uint64_t)b << 32) | a, y = ((uint64_t)d << 32) | c, z = ((uint64_t)f << 32) | e, w = ((uint64_t)h << 32) | g;
+                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(x) : "v"(g), "v"(x));
+                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(y) : "v"(g), "v"(y));
+                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(z) : "v"(a), "v"(z));
+                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(w) : "v"(a), "v"(w));
+                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(x) : "v"(c), "v"(x));
+                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(y) : "v"(c), "v"(y));
+                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(z) : "v"(e), "v"(z));
+                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(w) : "v"(e), "v"(w));
+                a = (uint32_t)x | 1; b = (uint32_t)(x >> 32); c = (uint32_t)y | 1; d = (uint32_t)(y >> 32); e = (uint32_t)z | 1; f = (uint32_t)(z >> 32); g = (uint32_t)w | 1; h = (uint32_t)(w >> 32);
+            }
+            if (KIND == 26) {  // v_lshlrev_b64
+                uint64_t x = ((uint64_t)b << 32) | a, y = ((uint64_t)d << 32) | c, z = ((uint64_t)f << 32) | e, w = ((uint64_t)h << 32) | g;
+                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(x) : "v"(g), "v"(x));
+                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(y) : "v"(g), "v"(y));
+                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(z) : "v"(a), "v"(z));
+                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(w) : "v"(a), "v"(w));
+                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(x) : "v"(c), "v"(x));
+                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(y) : "v"(c), "v"(y));
+                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(z) : "v"(e), "v"(z));
+                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(w) : "v"(e), "v"(w));
+                a = (uint32_t)x | 1; b = (uint32_t)(x >> 32); c = (uint32_t)y | 1; d = (uint32_t)(y >> 32); e = (uint32_t)z | 1; f = (uint32_t)(z >> 32); g = (uint32_t)w | 1; h = (uint32_t)(w >> 32);
+            }
+            if (KIND == 27) {   // v_lshrrev_b32
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(a) : "v"(b));
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(b) : "v"(c));
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(c) : "v"(d));
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(d) : "v"(e));
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(e) : "v"(f));
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(f) : "v"(g));
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(g) : "v"(h));
+                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(h) : "v"(a));
+            }
+            if (KIND == 28) {   // v_mov_b32
+                asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(b));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(c));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(d));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(e));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(e) : "v"(f));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "v"(g));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(g) : "v"(h));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(h) : "v"(a));
+            }
+            if (KIND == 29) {   // v_sub_u32
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
+            }
+            if (KIND == 30) {   // v_min_u32
+                asm volatile("v_min_u32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+                asm volatile("v_min_u32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
+                asm volatile("v_min_u32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
+                asm volatile("v_min_u32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
+                asm volatile("v_min_u32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
+                asm volatile("v_min_u32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
+                asm volatile("v_min_u32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
+                asm volatile("v_min_u32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
+            }
+            if (KIND == 31) {   // v_ffbh_u32
+                asm volatile("v_ffbh_u32 %0, %1" : "=v"(a) : "v"(b));
+                asm volatile("v_ffbh_u32 %0, %1" : "=v"(b) : "v"(c));
+                asm volatile("v_ffbh_u32 %0, %1" : "=v"(c) : "v"(d));
+                asm volatile("v_ffbh_u32 %0, %1" : "=v"(d) : "v"(e));
+                asm volatile("v_ffbh_u32 %0, %1" : "=v"(e) : "v"(f));
+                asm volatile("v_ffbh_u32 %0, %1" : "=v"(f) : "v"(g));
+                asm volatile("v_ffbh_u32 %0, %1" : "=v"(g) : "v"(h));
+                asm volatile("v_ffbh_u32 %0, %1" : "=v"(h) : "v"(a));
+            }
+            if (KIND == 32) {   // v_bcnt_u32_b32
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
+            }
             if (KIND == 5) {     // 64-bit add as one v_lshl_add_u64 (counted as ONE op per 64-bit add)
                 uint64_t x = ((uint64_t)b << 32) | a, y = ((uint64_t)d << 32) | c, z = ((uint64_t)f << 32) | e, w = ((uint64_t)h << 32) | g;
                 asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(x) : "v"(x), "v"(y));
@@ -241,5 +325,13 @@ int main() {
     run<22>("v_bfrev_b32", out);
     run<23>("v_add3_u32", out);
     run<24>("v_xnor_b32", out);
+    run<25>("v_lshrrev_b64", out);
+    run<26>("v_lshlrev_b64", out);
+    run<27>("v_lshrrev_b32", out);
+    run<28>("v_mov_b32", out);
+    run<29>("v_sub_u32", out);
+    run<30>("v_min_u32", out);
+    run<31>("v_ffbh_u32", out);
+    run<32>("v_bcnt_u32_b32", out);
     return 0;
 }
