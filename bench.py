@@ -27,13 +27,14 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Integer-VALU issue roofline of the block step.  gfx950 does not issue every VALU op at the same
-# rate: measured with tools/valu_rate.hip (profiles/r01_valu_rates.txt), v_and/or/xor/add and v_bitop3 hold a SIMD for
-# ~2.5 cycles per wave64 op, v_bfe/v_alignbit/v_lshl_add_u64/64-bit shifts for ~4.2-4.5.  The 8-column body of
-# run64_fast (ISA of k_banded<false>: 176 fast + 80 slow ops) therefore needs 784 SIMD cycles = 98 per block-column;
-# 1024 SIMDs x 2.4 GHz x 64 lanes / 98 cycles is what the chip can issue if nothing else ever stalls a SIMD.
-ISSUE_CYCLES_PER_BLOCK_COLUMN = 98.0
+# rate: measured with tools/valu_rate.hip (profiles/r01_*_valu_rates.txt), v_and/or/xor/add/lshr/mov and v_bitop3 hold
+# a SIMD for ~2.2-2.6 cycles per wave64 op, v_bfe/v_alignbit/v_lshl_add_u64 for ~4.2-4.5.  The 32-column body of
+# run64_fast<WIDE> (ISA of k_banded<false>: 654 fast + 286 slow instructions) therefore needs 2 864 SIMD cycles = 89.5
+# per block-column; 1024 SIMDs x 2.4 GHz x 64 lanes / 89.5 cycles is what the chip can issue if nothing else ever
+# stalls a SIMD.
+ISSUE_CYCLES_PER_BLOCK_COLUMN = 89.5
 VALU_PEAK_BLOCK_COLUMNS = 256 * 4 * 2.4e9 * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN
-OPS_PER_BLOCK_COLUMN = 32        # VALU instructions per 64-row block per column in that loop (256 / 8)
+OPS_PER_BLOCK_COLUMN = 29.4      # VALU instructions per 64-row block per column in that loop (940 / 32)
 
 def measured_copy_bandwidth(nbytes=1 << 30, reps=8):
     """device-to-device copy rate on this box (print the measured bandwidth next to the 8 TB/s spec):
