@@ -98,18 +98,17 @@ __device__ __forceinline__ u64 shl1_add_u64(u64 x, u64 y) {          // (x << 1)
     u64 r; asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(x), "v"(y)); return r;
 }
 
-__device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32& Phi, u32& Mlo, u32& Mhi,
-                                                 u32 PHin, u32 MHin, u32& accP, u32& accM) {
+// the step proper; phhi / mhhi are the high halves of the pre-shift horizontal deltas (bit 31 = the row-63 carry out)
+__device__ __forceinline__ void block_step_core(u32 elo, u32 ehi, u32& Plo, u32& Phi, u32& Mlo, u32& Mhi,
+                                                u32 PHin, u32 MHin, u32& phhi, u32& mhhi) {
     const u32 xvlo = elo | Mlo, xvhi = ehi | Mhi;
     const u32 eclo = elo | MHin;
     const u64 sum = lshl_add_u64(mk64(eclo & Plo, ehi & Phi), mk64(Plo, Phi));
     const u32 slo = lo32(sum), shi = hi32(sum);
     const u32 phlo = bitop3<0xF3>(Mlo, bitop3<0xFE>(slo, Plo, eclo), 0u);   // M | ~(sum | P | Eqc)
-    const u32 phhi = bitop3<0xF3>(Mhi, bitop3<0xFE>(shi, Phi, ehi), 0u);
+    phhi = bitop3<0xF3>(Mhi, bitop3<0xFE>(shi, Phi, ehi), 0u);
     const u32 mhlo = bitop3<0xB0>(Plo, slo, eclo);                     // P & ((sum ^ P) | Eqc)
-    const u32 mhhi = bitop3<0xB0>(Phi, shi, ehi);
-    accP = __builtin_amdgcn_alignbit(accP, phhi, 31);                  // (accP << 1) | (Ph >> 63)
-    accM = __builtin_amdgcn_alignbit(accM, mhhi, 31);
+    mhhi = bitop3<0xB0>(Phi, shi, ehi);
     const u64 phs = shl1_add_u64(mk64(phlo, phhi), (u64)PHin);         // (Ph << 1) | PHin
     const u64 mhs = shl1_add_u64(mk64(mhlo, mhhi), (u64)MHin);
     const u32 pslo = lo32(phs), pshi = hi32(phs), mslo = lo32(mhs), mshi = hi32(mhs);
@@ -117,6 +116,52 @@ __device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32
     Phi = bitop3<0xF1>(mshi, xvhi, pshi);
     Mlo = pslo & xvlo;
     Mhi = pshi & xvhi;
+}
+
+__device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32& Phi, u32& Mlo, u32& Mhi,
+                                                 u32 PHin, u32 MHin, u32& accP, u32& accM) {
+    u32 phhi, mhhi;
+    block_step_core(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, phhi, mhhi);
+    accP = __builtin_amdgcn_alignbit(accP, phhi, 31);                  // (accP << 1) | (Ph >> 63)
+    accM = __builtin_amdgcn_alignbit(accM, mhhi, 31);
+}
+
+// ---------------------------------------------------------------------------
+// Two vertically adjacent blocks (band slots i and i+1) over 64 columns in one pass: the text masks are extracted
+// once, the lower block takes its carry-in straight from the upper block's horizontal deltas (one v_lshrrev each,
+// no carry word), and the upper block's 64 carry-outs are never collected -- its score follows from the
+// lower block's by the cell identity  v'_i - v_i = h_i - h_(i-1)  summed over the lower block and the chunk
+// (k_banded).  Same arithmetic per cell as run64_fast, hence the same bits.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void run64_pair(u64& PA, u64& MA, u64 aA, u64 bA, u64& PB, u64& MB, u64 aB, u64 bB,
+                                           u64 T0, u64 T1, u64 hinP, u64 hinM, u64& houtP, u64& houtM) {
+    const u32 aAlo = lo32(aA), aAhi = hi32(aA), bAlo = lo32(bA), bAhi = hi32(bA);
+    const u32 aBlo = lo32(aB), aBhi = hi32(aB), bBlo = lo32(bB), bBhi = hi32(bB);
+    u32 PAlo = lo32(PA), PAhi = hi32(PA), MAlo = lo32(MA), MAhi = hi32(MA);
+    u32 PBlo = lo32(PB), PBhi = hi32(PB), MBlo = lo32(MB), MBhi = hi32(MB);
+    u32 oPlo = 0, oPhi = 0, oMlo = 0, oMhi = 0;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const u32 t0 = half ? hi32(T0) : lo32(T0), t1 = half ? hi32(T1) : lo32(T1);
+        const u32 hp = half ? hi32(hinP) : lo32(hinP), hm = half ? hi32(hinM) : lo32(hinM);
+        u32 gP = 0, gM = 0;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0, c, 1);
+            const u32 m1 = (u32)__builtin_amdgcn_sbfe((int)t1, c, 1);
+            u32 phhi, mhhi;
+            block_step_core(bitop3<0x90>(~(aAlo ^ m0), bAlo, m1), bitop3<0x90>(~(aAhi ^ m0), bAhi, m1),
+                            PAlo, PAhi, MAlo, MAhi, __builtin_amdgcn_ubfe(hp, c, 1), __builtin_amdgcn_ubfe(hm, c, 1), phhi, mhhi);
+            block_step_fused(bitop3<0x90>(~(aBlo ^ m0), bBlo, m1), bitop3<0x90>(~(aBhi ^ m0), bBhi, m1),
+                             PBlo, PBhi, MBlo, MBhi, phhi >> 31, mhhi >> 31, gP, gM);
+        }
+        const u32 rP = __builtin_bitreverse32(gP), rM = __builtin_bitreverse32(gM);
+        if (half) { oPhi = rP; oMhi = rM; } else { oPlo = rP; oMlo = rM; }
+    }
+    PA = mk64(PAlo, PAhi); MA = mk64(MAlo, MAhi);
+    PB = mk64(PBlo, PBhi); MB = mk64(MBlo, MBhi);
+    houtP = mk64(oPlo, oPhi);
+    houtM = mk64(oMlo, oMhi);
 }
 
 // ---------------------------------------------------------------------------
@@ -577,6 +622,41 @@ __global__ __launch_bounds__(FILL ? 512 : 1024) void k_banded(BandedArgs A) {
         for (int i = i0; i <= i1; ++i) {
             const bool act = on && i >= first && i <= rhi;
             const int r = i + pos_v;
+            if (!FILL && i < i1) {
+                // slots i and i+1 in one pass when every lane has both or neither, full ACGT chunks, not the last block row
+                const bool actB = on && i + 1 >= first && i + 1 <= rhi;
+                const bool odd = (act != actB) || ((act || actB) && (ncols != 64 || hasN || r + 1 == nw - 1));
+                if (!__any(odd)) {
+                    u64 PA = 0, MA = 0, PB = 0, MB = 0, aA = 0, bA = 0, nA = 0, aB = 0, bB = 0, nB = 0;
+                    int scA = 0, scB = 0;
+                    if (act) {
+                        PA = Pv[(int64_t)i * 64]; MA = Mv[(int64_t)i * 64]; scA = S[(int64_t)r * 64];
+                        PB = Pv[(int64_t)(i + 1) * 64]; MB = Mv[(int64_t)(i + 1) * 64]; scB = S[(int64_t)(r + 1) * 64];
+                        load_planes(pp, p0 + 64 * r, aA, bA, nA);
+                        load_planes(pp, p0 + 64 * (r + 1), aB, bB, nB);
+                    }
+                    if (i == first) { hinP = QE_ONES; hinM = 0; }
+                    const int vB0 = __popcll(PB) - __popcll(MB);
+                    u64 houtP, houtM;
+                    run64_pair(PA, MA, aA, bA, PB, MB, aB, bB, T0, T1, hinP, hinM, houtP, houtM);
+                    if (act) {
+                        // scores[] of the lower row from its own bottom-row deltas, as always; of the upper row from
+                        //   sum_c hout_A(c) = sum_c hin_B(c) = sum_c hout_B(c) - (v_B after - v_B before),
+                        // v_B = sum of block B's vertical deltas -- exact for any block state, because every cell of
+                        // the step satisfies v' - v = h - h_above (it evaluates the min-recurrence cell by cell)
+                        const int dB = __popcll(houtP) - __popcll(houtM);
+                        const int vB1 = __popcll(PB) - __popcll(MB);
+                        S[(int64_t)r * 64] = scA + dB + vB0 - vB1;
+                        S[(int64_t)(r + 1) * 64] = scB + dB;
+                        Pv[(int64_t)(i - 1) * 64] = PA; Mv[(int64_t)(i - 1) * 64] = MA;     // band shift, as below
+                        Pv[(int64_t)i * 64] = PB; Mv[(int64_t)i * 64] = MB;
+                        adv += 128u;
+                    }
+                    hinP = houtP; hinM = houtM;
+                    ++i;
+                    continue;
+                }
+            }
             u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
             int sc = 0;
             if (act) {
