@@ -127,18 +127,23 @@ __device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32
 }
 
 // ---------------------------------------------------------------------------
-// Two vertically adjacent blocks (band slots i and i+1) over 64 columns in one pass: the text masks are extracted
-// once, the lower block takes its carry-in straight from the upper block's horizontal deltas (one v_lshrrev each,
-// no carry word), and the upper block's 64 carry-outs are never collected -- its score follows from the
-// lower block's by the cell identity  v'_i - v_i = h_i - h_(i-1)  summed over the lower block and the chunk
-// (k_banded).  Same arithmetic per cell as run64_fast, hence the same bits.
+// K vertically adjacent blocks (band slots i .. i+K-1) over 64 columns in one pass: the text masks are extracted
+// once per column, every block below the first takes its carry-in straight from the horizontal deltas of the block
+// above (one v_lshrrev each, no carry word), and only the lowest block's 64 carry-outs are collected -- the scores
+// of the rows above follow from the cell identity (slots_pass).  Same arithmetic per cell as run64_fast, hence the
+// same bits.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void run64_pair(u64& PA, u64& MA, u64 aA, u64 bA, u64& PB, u64& MB, u64 aB, u64 bB,
-                                           u64 T0, u64 T1, u64 hinP, u64 hinM, u64& houtP, u64& houtM) {
-    const u32 aAlo = lo32(aA), aAhi = hi32(aA), bAlo = lo32(bA), bAhi = hi32(bA);
-    const u32 aBlo = lo32(aB), aBhi = hi32(aB), bBlo = lo32(bB), bBhi = hi32(bB);
-    u32 PAlo = lo32(PA), PAhi = hi32(PA), MAlo = lo32(MA), MAhi = hi32(MA);
-    u32 PBlo = lo32(PB), PBhi = hi32(PB), MBlo = lo32(MB), MBhi = hi32(MB);
+__device__ __forceinline__ void load_planes(const u64* __restrict__ base, int bit, u64& a, u64& b, u64& nn);
+
+template <int K>
+__device__ __forceinline__ void run64_multi(u64 (&P)[K], u64 (&M)[K], const u64 (&a)[K], const u64 (&b)[K],
+                                            u64 T0, u64 T1, u64 hinP, u64 hinM, u64& houtP, u64& houtM) {
+    u32 alo[K], ahi[K], blo[K], bhi[K], Plo[K], Phi[K], Mlo[K], Mhi[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        alo[k] = lo32(a[k]); ahi[k] = hi32(a[k]); blo[k] = lo32(b[k]); bhi[k] = hi32(b[k]);
+        Plo[k] = lo32(P[k]); Phi[k] = hi32(P[k]); Mlo[k] = lo32(M[k]); Mhi[k] = hi32(M[k]);
+    }
     u32 oPlo = 0, oPhi = 0, oMlo = 0, oMhi = 0;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -149,19 +154,61 @@ __device__ __forceinline__ void run64_pair(u64& PA, u64& MA, u64 aA, u64 bA, u64
         for (int c = 0; c < 32; ++c) {
             const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0, c, 1);
             const u32 m1 = (u32)__builtin_amdgcn_sbfe((int)t1, c, 1);
-            u32 phhi, mhhi;
-            block_step_core(bitop3<0x90>(~(aAlo ^ m0), bAlo, m1), bitop3<0x90>(~(aAhi ^ m0), bAhi, m1),
-                            PAlo, PAhi, MAlo, MAhi, __builtin_amdgcn_ubfe(hp, c, 1), __builtin_amdgcn_ubfe(hm, c, 1), phhi, mhhi);
-            block_step_fused(bitop3<0x90>(~(aBlo ^ m0), bBlo, m1), bitop3<0x90>(~(aBhi ^ m0), bBhi, m1),
-                             PBlo, PBhi, MBlo, MBhi, phhi >> 31, mhhi >> 31, gP, gM);
+            u32 cP = __builtin_amdgcn_ubfe(hp, c, 1), cM = __builtin_amdgcn_ubfe(hm, c, 1);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const u32 elo = bitop3<0x90>(~(alo[k] ^ m0), blo[k], m1), ehi = bitop3<0x90>(~(ahi[k] ^ m0), bhi[k], m1);
+                if (k + 1 < K) {
+                    u32 phhi, mhhi;
+                    block_step_core(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], cP, cM, phhi, mhhi);
+                    cP = phhi >> 31; cM = mhhi >> 31;
+                } else {
+                    block_step_fused(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], cP, cM, gP, gM);
+                }
+            }
         }
         const u32 rP = __builtin_bitreverse32(gP), rM = __builtin_bitreverse32(gM);
         if (half) { oPhi = rP; oMhi = rM; } else { oPlo = rP; oMlo = rM; }
     }
-    PA = mk64(PAlo, PAhi); MA = mk64(MAlo, MAhi);
-    PB = mk64(PBlo, PBhi); MB = mk64(MBlo, MBhi);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { P[k] = mk64(Plo[k], Phi[k]); M[k] = mk64(Mlo[k], Mhi[k]); }
     houtP = mk64(oPlo, oPhi);
     houtM = mk64(oMlo, oMhi);
+}
+
+// K adjacent band slots i .. i+K-1 of one chunk in one pass, with the loads, score bookkeeping and the in-place band
+// shift around it.  scores[] of the lowest row from its own bottom-row deltas, as always; of every row above from
+//   sum_c hout_k(c) = sum_c hin_(k+1)(c) = sum_c hout_(k+1)(c) - (v_(k+1) after - v_(k+1) before),
+// v = sum of a block's vertical deltas -- exact for any block state, because every cell of the step satisfies
+// v' - v = h - h_above (the step evaluates the min-recurrence cell by cell).
+template <int K>
+__device__ __forceinline__ void slots_pass(bool act, int i, int r, u64* Pv, u64* Mv, int32_t* S, const u64* pp, int p0,
+                                           u64 T0, u64 T1, u64& hinP, u64& hinM, u32& adv) {
+    u64 P[K], M[K], a[K], b[K];
+    int sc[K], v0[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        P[k] = 0; M[k] = 0; a[k] = 0; b[k] = 0; sc[k] = 0;
+        if (act) {
+            u64 nn;
+            P[k] = Pv[(int64_t)(i + k) * 64]; M[k] = Mv[(int64_t)(i + k) * 64]; sc[k] = S[(int64_t)(r + k) * 64];
+            load_planes(pp, p0 + 64 * (r + k), a[k], b[k], nn);
+        }
+        v0[k] = __popcll(P[k]) - __popcll(M[k]);
+    }
+    u64 houtP, houtM;
+    run64_multi<K>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM);
+    if (act) {
+        int d = __popcll(houtP) - __popcll(houtM);          // sum of the bottom-row deltas of slot k, from the lowest up
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            S[(int64_t)(r + k) * 64] = sc[k] + d;
+            d -= (__popcll(P[k]) - __popcll(M[k])) - v0[k];
+            Pv[(int64_t)(i + k - 1) * 64] = P[k]; Mv[(int64_t)(i + k - 1) * 64] = M[k];   // band shift (bpm_banded.c:903-909)
+        }
+        adv += 64u * K;
+    }
+    hinP = houtP; hinM = houtM;
 }
 
 // ---------------------------------------------------------------------------
@@ -554,7 +601,7 @@ __device__ __forceinline__ GroupWs group_ws(uint8_t* ws, int64_t off, int ns, in
 // (FILL = true, bpm_banded.c:199-316).  One lane per task.
 // ===========================================================================
 template <bool FILL>
-__global__ __launch_bounds__(FILL ? 512 : 1024) void k_banded(BandedArgs A) {
+__global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
     const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
     if (g * 64 >= A.T.ntasks) return;
     int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
@@ -622,40 +669,18 @@ __global__ __launch_bounds__(FILL ? 512 : 1024) void k_banded(BandedArgs A) {
         for (int i = i0; i <= i1; ++i) {
             const bool act = on && i >= first && i <= rhi;
             const int r = i + pos_v;
-            if (!FILL && i < i1) {
-                // slots i and i+1 in one pass when every lane has both or neither, full ACGT chunks, not the last block row
-                const bool actB = on && i + 1 >= first && i + 1 <= rhi;
-                const bool odd = (act != actB) || ((act || actB) && (ncols != 64 || hasN || r + 1 == nw - 1));
-                if (!__any(odd)) {
-                    u64 PA = 0, MA = 0, PB = 0, MB = 0, aA = 0, bA = 0, nA = 0, aB = 0, bB = 0, nB = 0;
-                    int scA = 0, scB = 0;
-                    if (act) {
-                        PA = Pv[(int64_t)i * 64]; MA = Mv[(int64_t)i * 64]; scA = S[(int64_t)r * 64];
-                        PB = Pv[(int64_t)(i + 1) * 64]; MB = Mv[(int64_t)(i + 1) * 64]; scB = S[(int64_t)(r + 1) * 64];
-                        load_planes(pp, p0 + 64 * r, aA, bA, nA);
-                        load_planes(pp, p0 + 64 * (r + 1), aB, bB, nB);
-                    }
-                    if (i == first) { hinP = QE_ONES; hinM = 0; }
-                    const int vB0 = __popcll(PB) - __popcll(MB);
-                    u64 houtP, houtM;
-                    run64_pair(PA, MA, aA, bA, PB, MB, aB, bB, T0, T1, hinP, hinM, houtP, houtM);
-                    if (act) {
-                        // scores[] of the lower row from its own bottom-row deltas, as always; of the upper row from
-                        //   sum_c hout_A(c) = sum_c hin_B(c) = sum_c hout_B(c) - (v_B after - v_B before),
-                        // v_B = sum of block B's vertical deltas -- exact for any block state, because every cell of
-                        // the step satisfies v' - v = h - h_above (it evaluates the min-recurrence cell by cell)
-                        const int dB = __popcll(houtP) - __popcll(houtM);
-                        const int vB1 = __popcll(PB) - __popcll(MB);
-                        S[(int64_t)r * 64] = scA + dB + vB0 - vB1;
-                        S[(int64_t)(r + 1) * 64] = scB + dB;
-                        Pv[(int64_t)(i - 1) * 64] = PA; Mv[(int64_t)(i - 1) * 64] = MA;     // band shift, as below
-                        Pv[(int64_t)i * 64] = PB; Mv[(int64_t)i * 64] = MB;
-                        adv += 128u;
-                    }
-                    hinP = houtP; hinM = houtM;
-                    ++i;
-                    continue;
-                }
+            if (!FILL) {
+                // K slots in one pass when every lane has all of them or none, full ACGT chunks, not the last block row
+                const int lo = on ? first : 0x7fffffff, hi_ = on ? rhi : -0x7fffffff;
+                const bool plain = !(on && (ncols != 64 || hasN));
+                auto uniform = [&](int K) {
+                    const bool all = i >= lo && i + K - 1 <= hi_, none = i + K - 1 < lo || i > hi_;
+                    const bool bad = !(all || none) || (all && (!plain || r + K - 1 >= nw - 1));
+                    return !__any(bad);
+                };
+                if (i == first) { hinP = QE_ONES; hinM = 0; }
+                if (i + 3 <= i1 && uniform(4)) { slots_pass<4>(act, i, r, Pv, Mv, S, pp, p0, T0, T1, hinP, hinM, adv); i += 3; continue; }
+                if (i + 1 <= i1 && uniform(2)) { slots_pass<2>(act, i, r, Pv, Mv, S, pp, p0, T0, T1, hinP, hinM, adv); i += 1; continue; }
             }
             u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
             int sc = 0;
