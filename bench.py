@@ -28,13 +28,14 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Integer-VALU issue roofline of the block step.  gfx950 does not issue every VALU op at the same
 # rate: measured with tools/valu_rate.hip (profiles/r01_*_valu_rates.txt), v_and/or/xor/add/lshr/mov and v_bitop3 hold
-# a SIMD for ~2.2-2.6 cycles per wave64 op, v_bfe/v_alignbit/v_lshl_add_u64 for ~4.2-4.5.  The 32-column body of
-# run64_fast<WIDE> (ISA of k_banded<false>: 654 fast + 286 slow instructions) therefore needs 2 864 SIMD cycles = 89.5
-# per block-column; 1024 SIMDs x 2.4 GHz x 64 lanes / 89.5 cycles is what the chip can issue if nothing else ever
-# stalls a SIMD.
-ISSUE_CYCLES_PER_BLOCK_COLUMN = 89.5
+# a SIMD for ~2.2-2.6 cycles per wave64 op, v_bfe/v_alignbit/v_lshl_add_u64 for ~4.2-4.5.  The cheapest form of the
+# walk, four band slots per pass (run64_multi<4>, ISA of k_banded<false>: 2 766 fast + 570 slow instructions per 32
+# columns x 4 blocks), needs 9 393 SIMD cycles = 73.4 per block-column (two slots: 78.6, one: 89.5); 1024 SIMDs x
+# 2.4 GHz x 64 lanes / 73.4 cycles is what the chip could issue if every slot went through the 4-slot form and nothing
+# else ever stalled a SIMD.
+ISSUE_CYCLES_PER_BLOCK_COLUMN = 73.4
 VALU_PEAK_BLOCK_COLUMNS = 256 * 4 * 2.4e9 * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN
-OPS_PER_BLOCK_COLUMN = 29.4      # VALU instructions per 64-row block per column in that loop (940 / 32)
+OPS_PER_BLOCK_COLUMN = 26.1      # VALU instructions per 64-row block per column in that loop (3 336 / 128)
 
 def measured_copy_bandwidth(nbytes=1 << 30, reps=8):
     """device-to-device copy rate on this box (print the measured bandwidth next to the 8 TB/s spec):
