@@ -1098,7 +1098,9 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
+    QE_TRACE_POINT("stages launched");
     C.pool_a2[C.ai ^ 1].mirror(C.pa());
+    QE_TRACE_POINT("pool mirror");
     B.ev_done_set[par] = true;
     C.phase_w();
     B.pending = true;
@@ -1129,7 +1131,8 @@ static bool host_is_pinned(const void* p) {
 
 static void upload_span(uint8_t* dst, const uint8_t* src, size_t bytes, int device) {
     if (bytes == 0) return;
-    if (host_is_pinned(src)) {
+    // small spans (single quicked_align calls): one plain copy; the staging threads below cost ~12 ms to set up
+    if (bytes < ((size_t)32 << 20) || host_is_pinned(src)) {
         HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
         return;
     }
@@ -1585,8 +1588,10 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
         if (plens[i]) memcpy(pp.data() + po[i], patterns[i], (size_t)plens[i]);
         if (tlens[i]) memcpy(tp.data() + to[i], texts[i], (size_t)tlens[i]);
     }
+    double tr_last = now_ms();
     quicked_batch_t* B = quicked_batch_create(n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data());
     if (!B) return QUICKED_ERROR;
+    QE_TRACE_POINT("align_pairs: create");
     const quicked_params_t* p = aligner->params;
     // the five host timers are ticked around the stages they bracket in the reference
     // (quicked.c:76-78,184-193,204-235,240-275,283-294); a batch is one lap of each.
@@ -1595,6 +1600,7 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
     qe_timer_start(aligner->timer);
     quicked_status_t st = quicked_batch_run(B, p, 1);
     qe_timer_stop(aligner->timer);
+    QE_TRACE_POINT("align_pairs: run");
     tl_timers = HostTimers();
     quicked_status_t first_err = QUICKED_OK;
     bool any_err = false;
@@ -1610,6 +1616,7 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
             cigars_out[i] = (B->cigar_off[(size_t)i] >= 0 && !p->only_score) ? pool_keep->data() + B->cigar_off[(size_t)i] : nullptr;
     }
     quicked_batch_destroy(B);
+    QE_TRACE_POINT("align_pairs: destroy");
     if (any_err) return first_err;
     return st;
 }
