@@ -252,10 +252,12 @@ def main():
             n = len(ref_scores)
             base["gpu_scores_identical_on_sample"] = bool((scores[:n].astype(np.int64) == ref_scores).all())
             line["cpu_baseline"] = base
-        print(json.dumps(line))
     rb.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:                   # the one JSON line is the last thing on stdout (RCCL prints its banner when it goes)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
