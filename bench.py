@@ -255,7 +255,14 @@ def main():
     rb.close()
     if dist is not None:
         dist.destroy_process_group()
-    if rank == 0:                   # the one JSON line is the last thing on stdout (RCCL prints its banner when it goes)
+    if rank == 0:
+        # the one JSON line is the last thing on stdout: RCCL writes a banner through C stdio, which is block-buffered
+        # when stdout is a pipe and would otherwise surface at exit, after the line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:      # noqa: BLE001
+            pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
 
