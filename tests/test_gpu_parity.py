@@ -557,3 +557,30 @@ def test_packed_wire_batches_equal_ascii_batches(wire, monkeypatch):
     if wire == capi.WIRE_2BIT:
         with pytest.raises(capi.QuickedException):
             capi.ResidentBatch(datagen.PairBatch(*_pools([(b"ACGN", b"ACGT")])), wire=wire)
+
+
+def test_large_batch_rotates_three_stream_sets():
+    """batches above 131 072 pairs rotate over three stream / pool sets (qe_driver.hip run_batch): queue several
+    asynchronous runs of two algorithms behind each other, then check a synchronous one against the oracle"""
+    batch = datagen.generate(140000, 48, 0.08, seed=1212)
+    rb = capi.ResidentBatch(batch)
+    pa = capi.make_params(algo=capi.BANDED, only_score=True, bandwidth=30)
+    pq = capi.make_params(algo=capi.QUICKED)
+    for _ in range(4):
+        assert rb.run(pa, sync=False) >= 0
+    assert rb.run(pq, sync=False) >= 0
+    assert rb.run(pa, sync=True) >= 0
+    sa, sta = rb.scores()
+    for _ in range(2):
+        assert rb.run(pa, sync=False) >= 0
+    assert rb.run(pq, sync=True) >= 0
+    sq, stq = rb.scores()
+    cq = rb.cigars()
+    rb.close()
+    pairs = list(batch.pairs())
+    for i in list(range(0, len(pairs), 1009)) + [len(pairs) - 1]:
+        st, sc, _ = O.oracle_align(*pairs[i], algo=2, only_score=True, bandwidth=30)
+        assert (sta[i], sa[i]) == (st, sc), i
+        st, sc, cg = O.oracle_align(*pairs[i], algo=0)
+        assert (stq[i], sq[i], cq[i]) == (st, sc, cg), i
+    assert int(sa.astype(np.int64).sum()) == int(sq.astype(np.int64).sum())      # both are the exact distance here
