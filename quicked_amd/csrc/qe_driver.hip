@@ -106,6 +106,37 @@ struct ArenaCarver {
     }
 };
 
+// Pinned host staging for the small per-run uploads (task lists, layouts).  A hipMemcpyAsync from pageable memory
+// returns only when the copy has been performed, i.e. when the stream has reached it -- which puts the host to sleep
+// behind run k-2 every time it queues run k.  Staged through pinned memory the copy is truly asynchronous; a stage is
+// reused only after the run that filled it is over (there are 2 x NA of them, so that run is NA runs back).
+struct PinnedStage {
+    struct Chunk { uint8_t* base; size_t cap; };
+    std::vector<Chunk> chunks;
+    size_t cur = 0, top = 0;
+    hipEvent_t done = nullptr;          // end of the run that used this stage last
+    bool pending = false;
+    void reset() {
+        if (pending) { HIP_CHECK(hipEventSynchronize(done)); pending = false; }
+        cur = 0; top = 0;
+    }
+    uint8_t* take(size_t bytes) {
+        bytes = (bytes + 63) & ~(size_t)63;
+        if (chunks.empty() || chunks[cur].cap - top < bytes) {
+            while (cur + 1 < chunks.size() && chunks[cur + 1].cap < bytes) ++cur;
+            if (!chunks.empty() && cur + 1 < chunks.size()) { ++cur; top = 0; }
+            else {
+                Chunk c; c.cap = std::max(bytes, (size_t)8 << 20); c.base = nullptr;
+                HIP_CHECK(hipHostMalloc((void**)&c.base, c.cap, hipHostMallocDefault));
+                chunks.push_back(c); cur = chunks.size() - 1; top = 0;
+            }
+        }
+        uint8_t* p = chunks[cur].base + top;
+        top += bytes;
+        return p;
+    }
+};
+
 struct Context {
     int device = 0;
     // Two phases of a run use two streams and two pools so that consecutive runs pipeline:
@@ -121,6 +152,9 @@ struct Context {
     hipStream_t stream = nullptr;            // where the current phase launches
     DevicePool pool_w, pool_a2[NA];
     int ai = 0;                              // which A stream / pool the current run uses
+    PinnedStage stage[2 * 3];                // see PinnedStage
+    int si = 0;
+    bool staging = false;                    // uploads on the current A stream go through stage[si]
     hipStream_t& sa() { return stream_a2[ai]; }
     DevicePool& pa() { return pool_a2[ai]; }
     DevicePool* scratch_p = nullptr;         // the current phase's pool
@@ -169,7 +203,16 @@ static Context& ctx() {
 
 template <typename T>
 static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
-    if (!src.empty()) HIP_CHECK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    if (src.empty()) return;
+    const size_t bytes = src.size() * sizeof(T);
+    Context* C = tl_ctx;
+    if (C && C->staging && s == C->sa()) {
+        uint8_t* st = C->stage[C->si].take(bytes);
+        memcpy(st, src.data(), bytes);
+        HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
+    HIP_CHECK(hipMemcpyAsync(dst, src.data(), bytes, hipMemcpyHostToDevice, s));
 }
 template <typename T>
 static void d2h(std::vector<T>& dst, const T* src, size_t n, hipStream_t s) {
@@ -942,6 +985,14 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     static const int na_env = env_int("QE_NA", 0);
     const int na = na_env > 0 ? std::min(na_env, (int)Context::NA) : (B.n > 131072 ? 3 : 2);
     C.ai = (C.ai + 1) % na;
+    C.si = (C.si + 1) % (2 * na);
+    {
+        PinnedStage& st = C.stage[C.si];
+        if (!st.done) HIP_CHECK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+        st.reset();                           // its last user is 2 na runs back: over unless the host is that far ahead
+        static const int staging_env = env_int("QE_STAGING", 1);
+        C.staging = staging_env != 0;
+    }
     if (serial) {
         C.phase_a(); C.pa().reset();
         if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.sa(), B.ev_done[par], 0));
@@ -960,6 +1011,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     for (auto& c : B.counters) c = 0;
     if ((unsigned)p.algo > (unsigned)HIRSCHBERG) {
         if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNKNOWN_ALGO);
+        C.staging = false;
         return QUICKED_UNKNOWN_ALGO;
     }
     HIP_CHECK(hipEventRecord(C.ev0, C.stream));
@@ -985,7 +1037,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     QE_TRACE_POINT("setup+pack launch");
     TaskList L = all_pairs(B, p);
     QE_TRACE_POINT("task list");
-    if (L.pair.empty()) { HIP_CHECK(hipStreamSynchronize(C.stream_w)); return QUICKED_EMPTY_SEQUENCE; }
+    if (L.pair.empty()) { C.staging = false; HIP_CHECK(hipStreamSynchronize(C.stream_w)); return QUICKED_EMPTY_SEQUENCE; }
     StageResult R;
 
     switch (p.algo) {
@@ -1108,6 +1160,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
+    if (C.staging) { HIP_CHECK(hipEventRecord(C.stage[C.si].done, C.sa())); C.stage[C.si].pending = true; C.staging = false; }
     QE_TRACE_POINT("stages launched");
     for (int q = 0; q < na; ++q) if (q != C.ai) C.pool_a2[q].mirror(C.pa());
     QE_TRACE_POINT("pool mirror");
