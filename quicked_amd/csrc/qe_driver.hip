@@ -1032,7 +1032,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     size_t pools_cap = 0;
     for (const auto& q : C.pool_a2) pools_cap += q.cap;
-    const size_t matrix_budget = std::max<size_t>((free_b + pools_cap) / (10 * Context::NA) * 7, (size_t)1 << 28);   // NA runs queued
+    const size_t matrix_budget = std::max<size_t>((free_b + pools_cap) / (10 * (size_t)na) * 7, (size_t)1 << 28);   // na pools in rotation
     quicked_status_t ret = QUICKED_WIP;
     QE_TRACE_POINT("setup+pack launch");
     TaskList L = all_pairs(B, p);
