@@ -12,14 +12,19 @@
 // the reference's; band bookkeeping then runs per lane exactly as the
 // reference's does every 64 columns (bpm_banded.c:889-922 / 264-301).
 //
-// The 64-column inner loop is pure 32-bit integer VALU on registers (~36 ops
-// per 64 DP cells); global memory is touched once per (block, chunk): 16 B of
-// state + 24 B of pattern planes in, 20 B out, all as [row][lane] rows.
+// The 64-column inner loop is pure 32-bit integer VALU on registers (26-29
+// instructions per 64 DP cells, built from gfx950's fast-issuing ops: see
+// block_step_core and DESIGN.md 4.1); the score-only kernel walks four (else two)
+// band slots per pass, sharing the text masks and passing carries in registers;
+// global memory is touched once per (block, chunk): 16 B of state + 24 B of
+// pattern planes in, 20 B out, all as [row][lane] rows.
 //
-// Kernels: k_pack (ASCII -> bit planes by ballot), k_banded<false/true> (BandEd
-// score / fill with checkpoints), k_banded_coop (G lanes per alignment),
-// k_traceback (tile recompute in LDS + path), k_windowed (WindowEd chain),
-// k_join (Hirschberg midpoint), k_format_segs / k_scan_offsets (CIGAR strings).
+// Kernels: k_pack (ASCII -> bit planes, 16-byte loads + SWAR), k_unpack_wire /
+// k_reverse_planes (packed input), k_banded<false/true> (BandEd score / fill with
+// checkpoints), k_banded_coop (G lanes per alignment), k_traceback (tile recompute
+// in registers + straight-line path walk), k_windowed (WindowEd chain, full
+// windows on chip), k_join (Hirschberg midpoint), k_format_segs / k_scan_offsets
+// (CIGAR strings, three styles), k_check_segs / k_check_strings (CIGAR validator).
 // No MFMA (bit manipulation, not a contraction), no CUDA-compat paths.
 #include <hip/hip_runtime.h>
 #include "qe_types.h"
@@ -27,9 +32,9 @@
 namespace qe {
 
 #define QE_ONES (~(u64)0)
-// One wave per group of 64 tasks.  A workgroup is 4 w waves -- w per SIMD of the CU it lands on -- and
-// the host pins one workgroup per CU (launch_groups, qe_driver.hip): the number of waves that share a
-// SIMD sets a lane-per-alignment kernel's duration, so their placement is not left to the dispatcher.
+// One wave per group of 64 tasks.  A workgroup is 4 waves -- one per SIMD of the CU it lands on -- and
+// claims enough LDS that at most two of them share a CU (launch_groups, qe_driver.hip): the number of
+// waves that share a SIMD sets a lane-per-alignment kernel's duration, so it is not left to the dispatcher.
 #define QE_WAVE_IN_BLOCK() ((int)(threadIdx.x >> 6))
 #define QE_GROUP_INDEX() ((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)))
 extern __shared__ uint4 qe_dyn_lds[];
