@@ -895,7 +895,7 @@ __global__ __launch_bounds__(1024) void k_banded_coop(CoopArgs A) {
             u64 houtP = 0, houtM = 0, sP, sM;
             const bool slow = act && (ncols != 64 || hasN || lastblk);
             if (!__any(slow)) {
-                run64_fast<0>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, nullptr, 0, nullptr);
+                run64_fast<0, true>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM, act, nullptr, 0, nullptr);
                 sP = houtP; sM = houtM;
             } else {
                 run64_general<0>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
