@@ -1328,10 +1328,14 @@ __global__ __launch_bounds__(512) void k_windowed(WindowArgs A) {
             const u64 ph_first = (v0 == 0) ? QE_ONES : 0;
             const u64 pinit = (h0 == 0) ? QE_ONES : 0;
             u64 P0 = pinit, M0 = 0, P1 = pinit, M1 = 0;
-            u64 hP, hM, gP, gM, xP, xM;
-            run64_fast<0>(P0, M0, pl0[0], pl0[1], tx0[0], tx0[1], sse ? (0x5555555555555556ull | (ph_first & 1)) : ph_first, 0, hP, hM, false, nullptr, 0, nullptr);
-            run64_fast<0>(P1, M1, pl1[0], pl1[1], tx0[0], tx0[1], hP, hM, xP, xM, false, nullptr, 0, nullptr);
-            run64_fast<0>(P0, M0, pl0[0], pl0[1], tx1[0], tx1[1], sse ? 0x5555555555555555ull : ph_first, 0, gP, gM, false, nullptr, 0, nullptr);
+            u64 gP, gM, xP, xM;
+            {   // first 64 columns: both blocks in one pass (shared text masks, register carries; nothing to collect)
+                u64 Pw[2] = {P0, P1}, Mw[2] = {M0, M1};
+                const u64 aw[2] = {pl0[0], pl1[0]}, bw[2] = {pl0[1], pl1[1]};
+                run64_multi<2>(Pw, Mw, aw, bw, tx0[0], tx0[1], sse ? (0x5555555555555556ull | (ph_first & 1)) : ph_first, 0, xP, xM);
+                P0 = Pw[0]; M0 = Mw[0]; P1 = Pw[1]; M1 = Mw[1];
+            }
+            run64_fast<0, true>(P0, M0, pl0[0], pl0[1], tx1[0], tx1[1], sse ? 0x5555555555555555ull : ph_first, 0, gP, gM, false, nullptr, 0, nullptr);
             if (sse) {
                 // the SSE kernel runs block 0 one column past the window and feeds THAT column's carries to
                 // block 1's last column (bpm_windowed.c:428-444); 127 is odd, so always here
@@ -1343,7 +1347,7 @@ __global__ __launch_bounds__(512) void k_windowed(WindowArgs A) {
                 gP = (gP & ~(1ull << 63)) | (Ph & (1ull << 63));
                 gM = (gM & ~(1ull << 63)) | (Mh & (1ull << 63));
             }
-            run64_fast<3>(P1, M1, pl1[0], pl1[1], tx1[0], tx1[1], gP, gM, xP, xM, true, &wck[0][lane], 64, nullptr);
+            run64_fast<3, true>(P1, M1, pl1[0], pl1[1], tx1[0], tx1[1], gP, gM, xP, xM, true, &wck[0][lane], 64, nullptr);
             if (on) steps += 256u;
             int vw = 127, hw = 127, wscore = 0;
             bool inr = on;
