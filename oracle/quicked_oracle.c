@@ -19,7 +19,10 @@
  *   - the Hirschberg midpoint join is re-derived (A.5, A.7(12)): full band
  *     overlap, first minimum, exact child scores;
  *   - QUICKED with only_score returns the edit count of the alignment it
- *     computed (reference: uninitialised cigar_out.score, quicked.c:283-299).
+ *     computed (reference: uninitialised cigar_out.score, quicked.c:283-299);
+ *   - QUICKED stage 3 with a cutoff of 0 (bandwidth % of a read shorter than
+ *     100 / bandwidth rounds to 0): the reference doubles 0 to 0 and never leaves
+ *     the loop (quicked.c:248-278); here the doubling starts from 1.
  */
 #include "quicked_oracle.h"
 
@@ -782,7 +785,9 @@ int qo_align(const qo_params_t* p, const char* pattern, int plen, const char* te
                 int64_t ns = qo_banded_score(pattern, plen, text, tlen, score, tlen, NULL, NULL, &adv);
                 tr->score_block_advances += adv; tr->banded_calls++;
                 while ((ns > max_len / 4 && score * 3 / 2 < ns) || ns < 0) {
-                    score *= 2;
+                    /* the reference doubles a cutoff of 0 (bandwidth % of a short read rounds to 0) to 0 forever;
+                     * defined behaviour here and in the kernels' driver: doubling starts from 1 */
+                    score = score * 2 > 1 ? score * 2 : 1;
                     ns = qo_banded_score(pattern, plen, text, tlen, score, tlen, NULL, NULL, &adv);
                     tr->score_block_advances += adv; tr->banded_calls++;
                 }

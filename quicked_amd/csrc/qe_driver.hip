@@ -1112,7 +1112,14 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
                 }
                 B.counters[7] = (int64_t)idx3.size();
                 // band doubling (quicked.c:248-278): relaunch on the subset that has not converged
+                int rounds = 0;
                 while (!idx3.empty()) {
+                    if (++rounds > 40) {      // cutoffs double from >= 1: 40 rounds cannot happen for int32 lengths
+                        for (size_t k = 0; k < idx3.size() && k < 8; ++k)
+                            fprintf(stderr, "[quicked_hip] stage 3 does not converge: pair %d m %d n %d cutoff %d\n",
+                                    L3.pair[k], L3.m[k], L3.n[k], L3.cutoff[k]);
+                        throw HipError{hipErrorUnknown, "QuickEd stage 3 band doubling", __LINE__};
+                    }
                     L3.pad();
                     StageResult S3;
                     qe_timer_start(tl_timers.banded);
@@ -1124,8 +1131,11 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
                         const size_t t = idx3[k];
                         const int64_t ns = S3.score[k], sc = L3.cutoff[k];
                         const int64_t mx = std::max(L.m[t], L.n[t]);
+                        if (trace_on() && rounds > 3) fprintf(stderr, "[qe] stage 3 round %d: pair %d m %d n %d cutoff %lld -> %lld\n", rounds, L.pair[t], L.m[t], L.n[t], (long long)sc, (long long)ns);
                         if ((ns > mx / 4 && sc * 3 / 2 < ns) || ns < 0) {
-                            Ln.push(L.pair[t], 0, L.m[t], 0, L.n[t], (int32_t)(sc * 2), L.n[t]); idxn.push_back(t);
+                            // a cutoff of 0 (bandwidth % of a short read rounds to 0) doubles to 0 forever in the reference
+                            // (quicked.c:248-278 never terminates there); defined here and in the oracle: doubling starts from 1
+                            Ln.push(L.pair[t], 0, L.m[t], 0, L.n[t], (int32_t)std::max<int64_t>(sc * 2, 1), L.n[t]); idxn.push_back(t);
                         } else {
                             bound[t] = (int32_t)ns;
                         }

@@ -584,3 +584,20 @@ def test_large_batch_rotates_three_stream_sets():
         st, sc, cg = O.oracle_align(*pairs[i], algo=0)
         assert (stq[i], sq[i], cq[i]) == (st, sc, cg), i
     assert int(sa.astype(np.int64).sum()) == int(sq.astype(np.int64).sum())      # both are the exact distance here
+
+
+def test_quicked_stage3_with_zero_cutoff_terminates():
+    """bandwidth 1 % of a read shorter than 100 bases is a cutoff of 0: the reference's stage-3 loop doubles it to 0
+    forever (quicked.c:248-278).  Defined here and in the oracle: the doubling starts from 1 (found by the fuzz)."""
+    p = b"ACGTTGCAAGTCCGATAGCTAGCTAGGATCGATCGGGATATAGCGCATTACGCATCAGC"
+    t = b"TTGACCAGTGACAGGGTTTACACAGATTTCCACGCGATACCCAGTTTCACGACAGA"
+    kw = dict(algo=0, bandwidth=1, window_size=2, overlap_size=1, hew_threshold=(10, 10), hew_percentage=(15, 15))
+    est, esc, ecg = O.oracle_align(p, t, **kw)
+    al = capi.QuickedAligner()
+    for k, v in kw.items():
+        if k in ("hew_threshold", "hew_percentage"):
+            getattr(al._params, k)[0], getattr(al._params, k)[1] = v
+        else:
+            setattr(al._params, k, v)
+    st, out = al.alignBatch([(p, t)] * 3)
+    assert all(o == (est, esc, ecg) for o in out)

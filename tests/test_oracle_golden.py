@@ -66,3 +66,12 @@ def test_sam_cigar_known_answers():
     assert O.sam_cigar("3X2M", False) == "1X4M"
     assert O.sam_cigar("2M1X3M2I1X1M1D", False) == "6M2I2M1D"
     assert O.sam_cigar("1X3M2I1X1M1D", True) == "1X3=2I1X1=1D"
+
+
+def test_stage3_zero_cutoff_is_defined():
+    """the oracle leaves the reference's never-ending doubling of a zero cutoff (quicked.c:248-278) after one step"""
+    p = b"ACGTTGCAAGTCCGATAGCTAGCTAGGATCGATCGGGATATAGCGCATTACGCATCAGC"
+    t = b"TTGACCAGTGACAGGGTTTACACAGATTTCCACGCGATACCCAGTTTCACGACAGA"
+    st, sc, cg = O.oracle_align(p, t, trace=True, algo=0, bandwidth=1, window_size=2, overlap_size=1,
+                                hew_threshold=(10, 10), hew_percentage=(15, 15))[:3]
+    assert st == 1 and sc == 31 and O.cigar_is_valid(p, t, cg)
