@@ -52,9 +52,17 @@ struct DevicePool {
     struct Chunk { uint8_t* base; size_t cap; };
     std::vector<Chunk> chunks;
     size_t cur = 0, top = 0, cap = 0;            // cap = total bytes over all chunks
+    // out of memory: the thread's other pools are asked to give theirs back (their runs are waited for first) and the
+    // allocation is tried once more; set by Context
+    static inline bool (*reclaim_fn)(DevicePool* keep) = nullptr;
     void add_chunk(size_t bytes) {
         Chunk c; c.cap = bytes; c.base = nullptr;
-        HIP_CHECK(hipMalloc((void**)&c.base, bytes));
+        hipError_t e = hipMalloc((void**)&c.base, bytes);
+        if (e == hipErrorOutOfMemory && reclaim_fn && reclaim_fn(this)) {
+            (void)hipGetLastError();
+            e = hipMalloc((void**)&c.base, bytes);
+        }
+        if (e != hipSuccess) throw HipError{e, "hipMalloc((void**)&c.base, bytes)", __LINE__};
         chunks.push_back(c);
         cap += bytes;
     }
@@ -91,6 +99,10 @@ struct DevicePool {
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * o.chunks[i].cap) return;
             add_chunk(o.chunks[i].cap);
         }
+    }
+    void release_all() {
+        for (auto& c : chunks) if (c.base) (void)hipFree(c.base);
+        chunks.clear(); cap = 0; cur = 0; top = 0;
     }
     size_t used_hint() const { return cap; }
     ~DevicePool() { for (auto& c : chunks) if (c.base) (void)hipFree(c.base); }
@@ -148,13 +160,14 @@ struct Context {
     // up to NA = 3 sets: at most two runs execute at a time (a batch has two plane sets); a third set lets the host
     // queue run k while runs k-2 and k-1 are still on the device instead of blocking on the pool of run k-2
     static constexpr int NA = 3;
-    hipStream_t stream_w = nullptr, stream_a2[NA] = {nullptr, nullptr, nullptr};
+    hipStream_t stream_w = nullptr, stream_a2[NA] = {};
     hipStream_t stream = nullptr;            // where the current phase launches
     DevicePool pool_w, pool_a2[NA];
     int ai = 0;                              // which A stream / pool the current run uses
-    PinnedStage stage[2 * 3];                // see PinnedStage
+    PinnedStage stage[2 * NA];               // see PinnedStage
     int si = 0;
     bool staging = false;                    // uploads on the current A stream go through stage[si]
+    bool memory_tight = false;               // a pool had to take the others' memory once: no more rotation on this thread
     hipStream_t& sa() { return stream_a2[ai]; }
     DevicePool& pa() { return pool_a2[ai]; }
     DevicePool* scratch_p = nullptr;         // the current phase's pool
@@ -191,6 +204,7 @@ static thread_local HostTimers tl_timers;
 static void qe_timer_start(profiler_timer_t* t);
 static void qe_timer_stop(profiler_timer_t* t);
 static thread_local Context* tl_ctx = nullptr;
+static bool reclaim_pools(DevicePool* keep);
 static thread_local int tl_device = 0;
 static Context& ctx() {
     if (!tl_ctx || tl_ctx->device != tl_device) {
@@ -198,7 +212,28 @@ static Context& ctx() {
         tl_ctx->device = tl_device;
     }
     tl_ctx->init();
+    DevicePool::reclaim_fn = &reclaim_pools;
     return *tl_ctx;
+}
+
+// DevicePool::reclaim_fn: every pool of this thread's context except `keep` is emptied after its stream has drained
+static bool reclaim_pools(DevicePool* keep) {
+    Context* C = tl_ctx;
+    if (!C) return false;
+    bool freed = false;
+    C->memory_tight = true;
+    for (int q = 0; q < Context::NA; ++q) {
+        if (&C->pool_a2[q] == keep || C->pool_a2[q].cap == 0) continue;
+        if (hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
+        C->pool_a2[q].release_all();
+        freed = true;
+    }
+    if (&C->pool_w != keep && C->pool_w.cap > ((size_t)1 << 30) && C->scratch_p != &C->pool_w) {
+        if (hipStreamSynchronize(C->stream_w) != hipSuccess) return false;
+        C->pool_w.release_all();
+        freed = true;
+    }
+    return freed;
 }
 
 template <typename T>
@@ -258,13 +293,16 @@ struct quicked_batch {
     int64_t *d_p_off = nullptr, *d_t_off = nullptr, *d_plp_off = nullptr, *d_plt_off = nullptr;
     int32_t *d_p_len = nullptr, *d_t_len = nullptr;
     // planes and flags are double-buffered by run parity (see Context)
-    u64 *d_pl_p[2] = {nullptr, nullptr}, *d_pl_t[2] = {nullptr, nullptr}, *d_pl_pr[2] = {nullptr, nullptr}, *d_pl_tr[2] = {nullptr, nullptr};
-    u32* d_flags[2] = {nullptr, nullptr};
+    static constexpr int NP = 3;                  // plane sets: runs k, k+1 (and for large batches k+2) may be on the device at once
+    u64 *d_pl_p[NP] = {}, *d_pl_t[NP] = {}, *d_pl_pr[NP] = {}, *d_pl_tr[NP] = {};
+    u32* d_flags[NP] = {};
     int parity = 0;
-    hipEvent_t ev_done[2] = {nullptr, nullptr};    // end of the A phase of the last run that used this parity
-    bool ev_done_set[2] = {false, false};
+    int np_used = 2;                              // plane sets in rotation = stream / pool sets in rotation (run_batch)
+    size_t last_mat_bytes = 0;                    // fill matrices of this batch's last CIGAR run
+    hipEvent_t ev_done[NP] = {};    // end of the A phase of the last run that used this parity
+    bool ev_done_set[NP] = {};
     size_t pl_p_words = 0, pl_t_words = 0;
-    bool have_rev[2] = {false, false};
+    bool have_rev[NP] = {};
     // results of the last run, host side, indexed by pair
     std::vector<int32_t> score, status;
     std::vector<int64_t> cigar_off;
@@ -337,7 +375,7 @@ static void launch_pack(quicked_batch& B, Context& C, bool reversed) {
         hipLaunchKernelGGL(k_reverse_planes, dim3(blocks), dim3(256), 0, C.stream, r);
         r.fwd = B.d_pl_t[0]; r.rev = B.d_pl_tr[0]; r.pl_off = B.d_plt_off; r.len = B.d_t_len;
         hipLaunchKernelGGL(k_reverse_planes, dim3(blocks), dim3(256), 0, C.stream, r);
-        B.have_rev[0] = B.have_rev[1] = true;   // both parities alias the same buffers
+        for (bool& h : B.have_rev) h = true;    // every set aliases the same buffers
         return;
     }
     PackArgs a;
@@ -849,6 +887,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     const size_t nt = LL.pair.size();
     const int ng = LL.ngroups();
     const BandLayout lay = band_layout(LL, true, true);
+    B.last_mat_bytes = lay.mat_u4 * 16;
     // partition the groups so that each sub-batch's matrices fit the budget; offsets restart per sub-batch
     std::vector<int> sub_start{0};
     std::vector<int64_t> ws_off(ng), mat_off(ng);
@@ -971,20 +1010,26 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     double tr_last = now_ms();
     tl_device = B.device;
     Context& C = ctx();
-    B.parity ^= 1;
-    const int par = B.parity;
-    // ---- phase W: pack + bound stages on stream_w with pool_w.  The planes of this parity were last read by
-    // the A phase two runs ago: wait for it on the device, not on the host.
+
+    // ---- phase W: pack + bound stages on stream_w with pool_w.  The planes of this set were last read by the A
+    // phase of the run that used it before (np_used runs ago): wait for it on the device, not on the host.
     // BandEd and WindowEd have no bound stage: their pack goes on stream_a, in order with the kernel.  Overlapping it
     // with the previous run's kernel would save ~0.5 ms, but a 25 k-workgroup kernel dispatched next to the 1563
     // one-wave workgroups of k_banded skews their placement over the SIMDs and doubles the kernel's time.
     const bool serial = p.algo == BANDED || p.algo == WINDOWED;
-    // two sets in rotation, three once a single launch fills every workgroup slot by itself (> 2048 waves): there the
-    // host would otherwise block on run k-2 before it can queue run k (measured: 100 k pairs 6.71 vs 6.28 M/s with
-    // 2 vs 3 sets, 400 k pairs 4.76 vs 5.03)
+    // Three sets: up to three runs of a thread are on the device at once (measured on 100 k x 10 kb: 6.69 -> 6.88 M/s
+    // BandEd, 4.70 -> 5.31 M/s QuickEd + CIGAR against two; four are slower again).  Two when three fill matrices of the
+    // size this batch needed last time would not fit (config 4: 94 GB each): sub-batching the fill costs more.
     static const int na_env = env_int("QE_NA", 0);
-    const int na = na_env > 0 ? std::min(na_env, (int)Context::NA) : (B.n > 131072 ? 3 : 2);
+    size_t free0 = 0, total0 = 0;
+    HIP_CHECK(hipMemGetInfo(&free0, &total0));
+    const bool roomy = (double)B.last_mat_bytes * 3.3 < 0.6 * (double)total0;
+    const int na = C.memory_tight ? 1 : na_env > 0 ? std::min(na_env, (int)Context::NA) : (roomy ? 3 : 2);
+    B.np_used = na;
+    for (int q = na; q < Context::NA; ++q)              // a set that left the rotation gives its memory back
+        if (C.pool_a2[q].cap > ((size_t)1 << 30)) { HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_a2[q].release_all(); }
     C.ai = (C.ai + 1) % na;
+    const int par = B.parity = (B.parity + 1) % B.np_used;
     C.si = (C.si + 1) % (2 * na);
     {
         PinnedStage& st = C.stage[C.si];
@@ -1032,7 +1077,9 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     size_t pools_cap = 0;
     for (const auto& q : C.pool_a2) pools_cap += q.cap;
-    const size_t matrix_budget = std::max<size_t>((free_b + pools_cap) / (10 * (size_t)na) * 7, (size_t)1 << 28);   // na pools in rotation
+    // a pool's share of what the na pools in rotation can have, but never more than this pool can actually get
+    const size_t matrix_budget = std::max<size_t>(std::min((free_b + pools_cap) / (10 * (size_t)na) * 7,
+                                                           (free_b + C.pool_a2[C.ai].cap) / 10 * 7), (size_t)1 << 28);
     quicked_status_t ret = QUICKED_WIP;
     QE_TRACE_POINT("setup+pack launch");
     TaskList L = all_pairs(B, p);
@@ -1172,7 +1219,12 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
     if (C.staging) { HIP_CHECK(hipEventRecord(C.stage[C.si].done, C.sa())); C.stage[C.si].pending = true; C.staging = false; }
     QE_TRACE_POINT("stages launched");
-    for (int q = 0; q < na; ++q) if (q != C.ai) C.pool_a2[q].mirror(C.pa());
+    {   // pre-size the other pools of the rotation -- only while that is cheap: big fill matrices are left to grow on demand
+        size_t cap_all = 0;
+        for (const auto& q : C.pool_a2) cap_all += q.cap;
+        if ((double)(cap_all + (size_t)(na - 1) * C.pa().cap) < 0.6 * (double)total0)
+            for (int q = 0; q < na; ++q) if (q != C.ai) C.pool_a2[q].mirror(C.pa());
+    }
     QE_TRACE_POINT("pool mirror");
     B.ev_done_set[par] = true;
     C.phase_w();
@@ -1307,14 +1359,14 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
         });
         auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
         B->arena_bytes = pad(p_bytes + 64) + pad(t_bytes + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
-                         4 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + 2 * pad((size_t)n * 4) + 4096;
+                         2 * quicked_batch::NP * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + quicked_batch::NP * pad((size_t)n * 4) + 4096;
         HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
         qe::ArenaCarver A{B->arena, 0};
         B->d_asc_p = A.take<uint8_t>(p_bytes + 64); B->d_asc_t = A.take<uint8_t>(t_bytes + 64);
         B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
         B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
         B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < quicked_batch::NP; ++q) {
             B->d_pl_p[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[q] = A.take<u64>(B->pl_t_words + 8);
             B->d_pl_pr[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[q] = A.take<u64>(B->pl_t_words + 8);
             B->d_flags[q] = A.take<u32>((size_t)n);
@@ -1412,10 +1464,14 @@ QE_API quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
         B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
         B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
         B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
-        B->d_pl_p[0] = B->d_pl_p[1] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[0] = B->d_pl_t[1] = A.take<u64>(B->pl_t_words + 8);
-        B->d_pl_pr[0] = B->d_pl_pr[1] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[0] = B->d_pl_tr[1] = A.take<u64>(B->pl_t_words + 8);
-        B->d_flags[0] = B->d_flags[1] = A.take<u32>((size_t)n);
-        for (int q = 0; q < 2; ++q) HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
+        B->d_pl_p[0] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[0] = A.take<u64>(B->pl_t_words + 8);
+        B->d_pl_pr[0] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[0] = A.take<u64>(B->pl_t_words + 8);
+        B->d_flags[0] = A.take<u32>((size_t)n);
+        for (int q = 0; q < quicked_batch::NP; ++q) {          // every set is the same resident planes
+            B->d_pl_p[q] = B->d_pl_p[0]; B->d_pl_t[q] = B->d_pl_t[0]; B->d_pl_pr[q] = B->d_pl_pr[0]; B->d_pl_tr[q] = B->d_pl_tr[0];
+            B->d_flags[q] = B->d_flags[0];
+            HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
+        }
         if (pw_total) upload_span((uint8_t*)d_pw, (const uint8_t*)(pattern_words + p_lo), pw_total * 8, C.device);
         if (tw_total) upload_span((uint8_t*)d_tw, (const uint8_t*)(text_words + t_lo), tw_total * 8, C.device);
         h2d(d_pwo, pwo, C.stream); h2d(d_two, two, C.stream);
