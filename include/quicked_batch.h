@@ -74,7 +74,7 @@ quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
  * bound stages, which need host decisions, are done); nothing is copied to the
  * host.  Consecutive runs of a thread rotate over up to three sets of stream, device
  * pool and bit-planes, so the kernels of runs k+1 and k+2 overlap those of run k;
- * the device results of a run stay valid until the second next run of that thread. */
+ * the device results of a run stay valid until the next run of that thread starts. */
 quicked_status_t quicked_batch_run(quicked_batch_t* batch, const quicked_params_t* params, int sync);
 quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
 
