@@ -601,3 +601,44 @@ def test_quicked_stage3_with_zero_cutoff_terminates():
             setattr(al._params, k, v)
     st, out = al.alignBatch([(p, t)] * 3)
     assert all(o == (est, esc, ecg) for o in out)
+
+
+def test_concurrent_host_threads_one_aligner_each():
+    """the reference's threading contract: no locks, no globals, one aligner per thread
+    (align_benchmark.c:246-284).  Here every host thread gets its own streams and device pools; results must not
+    depend on what the other threads are doing."""
+    import ctypes as C
+    import threading
+    lib = capi.lib()
+    batch = datagen.generate(count=48, length=1500, error=0.07, seed=515)
+    pairs = list(batch.pairs())
+    expect = {}
+    for algo, only in ((capi.QUICKED, False), (capi.BANDED, True), (capi.HIRSCHBERG, False), (capi.WINDOWED, False)):
+        expect[(algo, only)] = [O.oracle_align(p, t, algo=algo, only_score=only) for p, t in pairs]
+    errors = []
+
+    def worker(algo, only, lo, hi):
+        try:
+            prm = capi.make_params(algo=algo, only_score=only)
+            a = capi.Aligner()
+            assert lib.quicked_new(C.byref(a), C.byref(prm)) == capi.QUICKED_WIP
+            for i in range(lo, hi):
+                p, t = pairs[i]
+                st = lib.quicked_align(C.byref(a), p, len(p), t, len(t))
+                est, esc, ecg = expect[(algo, only)][i]
+                got = (st, a.score, a.cigar.decode() if (a.cigar and not only) else None)
+                if got != (est, esc, None if only else ecg):
+                    errors.append((algo, only, i, got[:2]))
+            lib.quicked_free(C.byref(a))
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = []
+    for k, (algo, only) in enumerate(expect):
+        for half in range(2):
+            threads.append(threading.Thread(target=worker, args=(algo, only, 24 * half, 24 * half + 24)))
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
