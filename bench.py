@@ -247,7 +247,7 @@ def main():
                      "note": "achieved uses the launch duration (launches of consecutive runs overlap); aggregate uses the step time"},
             "score_checksum": tot_checksum,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU reference is timed on rank 0 at N = 1 only
             base, ref_scores = cpu_baseline(batch, {k: v for k, v in kw.items()})
             n = len(ref_scores)
             base["gpu_scores_identical_on_sample"] = bool((scores[:n].astype(np.int64) == ref_scores).all())
