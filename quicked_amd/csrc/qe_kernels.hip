@@ -1763,27 +1763,31 @@ __global__ __launch_bounds__(64) void k_check_strings(PairView P, int npairs, co
     o_ok[i] = K.verdict();
 }
 
-// exclusive scan of (len + 1) over tasks -> string offsets; single block
+// exclusive scan of (len + 1) over tasks -> string offsets; one block, tiles of 1024 consecutive elements (coalesced
+// loads and stores), wave scan by shuffles, the 16 wave totals through LDS, a running total carried from tile to tile
 __global__ __launch_bounds__(1024) void k_scan_offsets(const int32_t* len, const int32_t* pair, int64_t* off, int64_t* total, int n) {
-    __shared__ int64_t part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(tid * per, n), hi = min(lo + per, n);
-    int64_t s = 0;
-    for (int i = lo; i < hi; ++i) s += (pair[i] >= 0) ? (int64_t)len[i] + 1 : 0;
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int64_t acc = 0;
-        for (int i = 0; i < 1024; ++i) { const int64_t v = part[i]; part[i] = acc; acc += v; }
-        *total = acc;
+    __shared__ int64_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int64_t v = (i < n && pair[i] >= 0) ? (int64_t)len[i] + 1 : 0;
+        int64_t x = v;                                      // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int64_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int64_t t = wsum[w]; if (w < wave) before += t; all += t; }
+        if (i < n) off[i] = carry + before + x - v;
+        carry += all;
+        __syncthreads();
     }
-    __syncthreads();
-    int64_t acc = part[tid];
-    for (int i = lo; i < hi; ++i) {
-        off[i] = acc;
-        acc += (pair[i] >= 0) ? (int64_t)len[i] + 1 : 0;
-    }
+    if (tid == 0) *total = carry;
 }
 
 }  // namespace qe
