@@ -1085,14 +1085,14 @@ struct EqTest {
 // One traceback round over an 8-column tile held in registers: tP/tM/tE[j] = {Pv after, Mv before, Eq}
 // of tile column j for the lane's block row Rb.  Priority D -> I -> M/X (bpm_banded.c:994-1020).  A lane
 // enters at column h & 7, and leaves to the left (h < 8 q), upwards (v leaves block Rb) or at an edge.
-template <bool RAW>
-__device__ __forceinline__ void walk_tile(const u64 (&tP)[8], const u64 (&tM)[8], const u64 (&tE)[8], bool in_tile,
+template <bool RAW, int TW>
+__device__ __forceinline__ void walk_tile(const u64 (&tP)[TW], const u64 (&tM)[TW], const u64 (&tE)[TW], bool in_tile,
                                           u32 inb_same, u32 inb_7, int Rb, int& v, int& h, u32& steps,
                                           RunSink& R, EqTest& E, int p0, int t0) {
 #pragma unroll
-    for (int j = 7; j >= 0; --j) {
-        const bool mine = in_tile && (h & 7) == j;
-        const u32 inb = (j == 7) ? inb_7 : inb_same;
+    for (int j = TW - 1; j >= 0; --j) {
+        const bool mine = in_tile && (h & (TW - 1)) == j;
+        const u32 inb = (j == TW - 1) ? inb_7 : inb_same;
         const int bit = v & 63;
         // deletions: Pv bits bit, bit-1, ... while set (v moves up, h stays)
         const u64 x = tP[j] << (63 - bit);
@@ -1158,11 +1158,12 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     u64 T0 = 0, T1 = 0, TN = 0, hinP = 0, hinM = 0, pa = 0, pb = 0, pn = 0;
     while (__any(valid && v >= 0 && h >= 0)) {
         const bool act = valid && v >= 0 && h >= 0;
-        const int q = h >> 3, Rb = v >> 6, k = q >> 3;
+        constexpr int TW = 16;             // tile width: two checkpoint intervals per round halve the rounds' fixed cost
+        const int q = h / TW, Rb = v >> 6, k = q / (64 / TW);
         // the tile: per column {Pv after, Mv before, Eq}, in registers (the loops over its columns are unrolled)
-        u64 tP[8], tM[8], tE[8];
+        u64 tP[TW], tM[TW], tE[TW];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { tP[j] = 0; tM[j] = 0; tE[j] = 0; }
+        for (int j = 0; j < TW; ++j) { tP[j] = 0; tM[j] = 0; tE[j] = 0; }
         u32 inb_same = 0, inb_7 = 0;
         if (act) {
             if (k != ck) {
@@ -1173,18 +1174,18 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
             const int s = Rb - (k - G.prolog);
             if (Rb != cR) { cR = Rb; load_planes(pp, p0 + 64 * Rb, pa, pb, pn); }
             // a step at column h reads Pv of stored column h + 1: inside the band of THAT column's chunk or 0
-            // (oracle header).  Columns 0..6 of the tile share this chunk; column 7 may be the last of it.
+            // (oracle header).  All but the last column of the tile share this chunk; the last may be the chunk's last.
             inb_same = (u32)((s >= 0) & (s >= cf_b) & (s <= cl_b));
-            inb_7 = ((q & 7) == 7) ? (u32)((s >= 1) & (s - 1 >= cf_a) & (s - 1 <= cl_b)) : inb_same;
+            inb_7 = ((q & (64 / TW - 1)) == 64 / TW - 1) ? (u32)((s >= 1) & (s - 1 >= cf_a) & (s - 1 <= cl_b)) : inb_same;
         }
-        const int c_first = (8 * q) & 63;
+        const int c_first = (TW * q) & 63;
         u64 P = 0, M = 0;
         bool computed = false;
         if (act) {
             const int pos_v = k - G.prolog, s = Rb - pos_v;
             computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
             if (computed) {
-                const uint4 c0 = cp[(int64_t)q * cps + (int64_t)s * 64];
+                const uint4 c0 = cp[(int64_t)(q * (TW / 8)) * cps + (int64_t)s * 64];
                 if (s != cs) {
                     cs = s;
                     const uint4 w0 = hw[((int64_t)k * gns + s) * 64];
@@ -1193,7 +1194,7 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
                 P = mk64(c0.x, c0.y); M = mk64(c0.z, c0.w);
             }
         }
-        // 8 block steps from the checkpoint: the same arithmetic as the fill.  The step's Eq word is also
+        // TW block steps from the checkpoint: the same arithmetic as the fill.  The step's Eq word is also
         // the traceback's match test for the 64 cells of the column (bpm_banded.c:1012: equal codes; raw
         // bytes only for non-canonical input, see EqTest)
         if (!__any(act && ((TN | pn) != 0))) {
@@ -1202,7 +1203,7 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
             const u32 hp = (u32)(hinP >> c_first), hm = (u32)(hinM >> c_first);
             u32 Plo = lo32(P), Phi = hi32(P), Mlo = lo32(M), Mhi = hi32(M), gP = 0, gM = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < TW; ++j) {
                 const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0s, j, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1s, j, 1);
                 const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1), ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
                 tE[j] = mk64(elo, ehi);
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < TW; ++j) {
                 const int c = c_first + j;
                 const u64 m0 = (u64)0 - ((T0 >> c) & 1), m1 = (u64)0 - ((T1 >> c) & 1);
                 const u64 acgt = ~(pa ^ m0) & ~(pb ^ m1) & ~pn;
@@ -1226,14 +1227,14 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
         }
         if (!computed) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { tP[j] = 0; tM[j] = 0; }
+            for (int j = 0; j < TW; ++j) { tP[j] = 0; tM[j] = 0; }
             // the row the band bookkeeping creates at the end of a chunk: Pv = ~0, Mv = 0 (bpm_banded.c:910)
-            if (act && (Rb - (k - G.prolog)) == cl_b + 1 && (q & 7) == 7) tP[7] = QE_ONES;
+            if (act && (Rb - (k - G.prolog)) == cl_b + 1 && (q & (64 / TW - 1)) == 64 / TW - 1) tP[TW - 1] = QE_ONES;
         }
         // walk, column by column, straight-line: at its column a lane takes the whole run of deletions
         // (consecutive set Pv bits below its row) and then the one step that leaves the column
-        if (any_raw) walk_tile<true>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, R, E, p0, t0);
-        else walk_tile<false>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, R, E, p0, t0);
+        if (any_raw) walk_tile<true, TW>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, R, E, p0, t0);
+        else walk_tile<false, TW>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, R, E, p0, t0);
     }
     if (!valid) return;
     R.push_n(OP_I, h + 1);
