@@ -207,7 +207,7 @@ def main():
             kernel, work_blocks = "k_banded<true> (BandEd fill)", int(counters[1])
         traffic = None
         try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")) as f:
                 pm = json.load(f)["banded_score" if args.workload == "banded_score" else "quicked"]
             key = "k_banded<false>" if args.workload == "banded_score" else "k_banded<true>"
             if args.pairs == 100000 and args.length == 10000:
