@@ -120,3 +120,30 @@ def test_wire_serializer_known_answers():
     assert L.quicked_wire_pack(b"ACGN", 4, 2, out.ctypes.data) < 0      # N has no 2-bit code
     assert L.quicked_wire_pack(b"ACgT", 4, 3, out.ctypes.data) < 0      # lower case: raw != encoded compare
     assert L.quicked_wire_pack(b"ACRT", 4, 3, out.ctypes.data) < 0      # IUPAC
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """the bench lines committed under profiles/ (what bench.py printed on the MI355X) carry every field of the
+    driver's contract, the roofline object and the CPU baseline"""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_i_bench_*.json")))
+    assert len(files) == 2
+    for f in files:
+        d = json.load(open(f))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (f, k)
+        assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["n_gpus"] == 1
+        assert "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, (f, k)
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        c = d["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c, (f, k)
+        assert c["kind"] in ("reference", "port") and c["gpu_scores_identical_on_sample"] is True
+        assert abs(d["value"] - d["config"]["pairs_per_gpu"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-6
