@@ -549,18 +549,23 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
 // (>= ~4 per SIMD) while every lane keeps >= 2 band slots; QE_COOP_G overrides (0 / 1 = off)
 static int coop_lanes(const TaskList& L) {
     const char* e = getenv("QE_COOP_G");
-    int min_nsl = 1 << 30;
+    int min_nsl = 1 << 30, n_max = 1;
     size_t live = 0;
     for (size_t t = 0; t < L.pair.size(); ++t) {
         if (L.pair[t] < 0) continue;
         ++live;
         min_nsl = std::min(min_nsl, host_geometry(L.m[t], L.n[t], L.cutoff[t]).ebb_local);
+        n_max = std::max(n_max, L.n[t]);
     }
     if (live == 0) return 1;
     int G = 1;
+    // Waves to aim for: ~700 for 10 kb reads (measured with the multi-slot one-lane kernel and overlapped runs:
+    // 8 k / 16 k pairs are best at G = 4, 32 k at G = 2, 50 k and up at G = 1), more for longer reads, whose one-lane
+    // latency grows with their length (100 kb half passes: 526 -> 430 ms from G = 8 to 32)
+    const size_t target = std::min<size_t>(4096, (size_t)700 * (size_t)std::max(1, n_max / 10000));
     if (e) G = atoi(e);
-    else if (live / 64 < 1024)                                // >= one wave per SIMD already: the one-lane kernel is issue-bound, keep it
-        while (G < 64 && (live * G) / 64 < 4096) G *= 2;      // otherwise ~4 waves per SIMD (measured: 100 kb half passes 526 -> 430 ms from G = 8 to 32)
+    else
+        while (G < 64 && (live * G) / 64 < target) G *= 2;
     // the band-height test first + 2 < last must stay decidable G-2 chunks early: keep the band >= 3 G + 4 slots
     while (G > 1 && min_nsl < 3 * G + 4) G /= 2;
     return G < 2 ? 1 : G;
