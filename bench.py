@@ -5,18 +5,32 @@ A "step" is one pass of the hot path over one batch of synthetic read pairs
 whose ASCII bytes are already resident in HBM: pack -> BandEd score-only kernel
 -> scores in HBM (configs[1] of BASELINE.json: 100 k pairs of 10 kb at 5 %
 error, reference default bandwidth 15 %).  `--workload quicked` runs configs[2]
-(QuickEd bound-and-align + CIGAR) instead.
+(QuickEd bound-and-align + CIGAR), `--workload quicked --pairs 10000 --length
+100000 --error 0.1` configs[3].
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU (torch.distributed.run), each rank owns its own
-shard of pairs (weak scaling, no data-path collective); RCCL is used only for
-the final reduction of the timings and checksums.
+N > 1: one process per GPU.  Under a launcher (WORLD_SIZE set: the driver's
+`python -m torch.distributed.run ... bench.py --gpus N`) this process is one
+rank; without one, `--gpus N` starts the N ranks itself as a child
+torch.distributed.run BEFORE anything touches the GPU and relays its JSON line.
+Every rank owns its own shard of the seeded dataset (quicked_amd/shard.py), there
+is no data-path collective, and RCCL only reduces {pairs, cells, checksum} (SUM)
+and the elapsed time (MAX) at the end.
+
+The one JSON line carries, besides the contract's fields:
+  roofline      dominant kernel, algorithmic bytes / HIP-event launch duration
+  valu          the same kernel against the chip's VALU issue rate (its real bound)
+  e2e           PCIe-inclusive rate: reload (H2D) of batch k+1 overlapped with the run
+                of batch k, scores fetched (D2H) for every batch; per input format
+  strong        (N > 1) the same workload with `--pairs` pairs IN TOTAL split over the ranks
+  cpu_baseline  the compiled reference (or the oracle port) on the host cores, N = 1 only
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,17 +39,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
+from quicked_amd import shard  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Integer-VALU issue roofline of the block step.  gfx950 does not issue every VALU op at the same
-# rate: measured with tools/valu_rate.hip (profiles/r01_*_valu_rates.txt), v_and/or/xor/add/lshr/mov and v_bitop3 hold
-# a SIMD for ~2.2-2.6 cycles per wave64 op, v_bfe/v_alignbit/v_lshl_add_u64 for ~4.2-4.5.  The cheapest form of the
-# walk, four band slots per pass (run64_multi<4>, ISA of k_banded<false>: 2 766 fast + 570 slow instructions per 32
-# columns x 4 blocks), needs 9 393 SIMD cycles = 73.4 per block-column (two slots: 78.6, one: 89.5); 1024 SIMDs x
-# 2.4 GHz x 64 lanes / 73.4 cycles is what the chip could issue if every slot went through the 4-slot form and nothing
-# else ever stalled a SIMD.
-ISSUE_CYCLES_PER_BLOCK_COLUMN = 73.4
-VALU_PEAK_BLOCK_COLUMNS = 256 * 4 * 2.4e9 * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN
-OPS_PER_BLOCK_COLUMN = 26.1      # VALU instructions per 64-row block per column in that loop (3 336 / 128)
+# VALU issue: a SIMD issues one wave64 VALU instruction per 2 cycles at best (MI355X_MICROARCH.md, "Wave scheduling":
+# SIMD-32, 2 passes per wave64 op); 1024 SIMDs at the 2.4 GHz peak clock.  The block step of k_banded<false> is
+# INSTR_PER_BLOCK_COLUMN VALU instructions per 64-row block per text column (ISA count of the 4-slot loop),
+# some of which (v_lshl_add_u64, v_bfe, v_alignbit) hold the SIMD for 4 cycles: ISSUE_CYCLES_PER_BLOCK_COLUMN is the sum
+# over the loop at the guide's rates (2 / 4 cycles), the bound nothing can beat without removing instructions.
+SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9
+INSTR_PER_BLOCK_COLUMN = 26.1
+ISSUE_CYCLES_PER_BLOCK_COLUMN = 61.0     # (2 766 x 2 + 570 x 4) / 128 block-columns of the unrolled 4-slot loop
+# reference anchors of BASELINE.md section 2 (one core of the survey container's 2.1 GHz Xeon, AVX2 build)
+CPU_ANCHOR_PER_CORE = {"banded_score": 2463.0, "quicked": 1680.0}
+
 
 def measured_copy_bandwidth(nbytes=1 << 30, reps=8):
     """device-to-device copy rate on this box (print the measured bandwidth next to the 8 TB/s spec):
@@ -74,11 +91,38 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(batch, params_kw, budget_s=15.0):
-    """The compiled reference (oracle/_ref, kind "reference") or the oracle
-    restatement (kind "port") on the host cores: oracle/cpu_bench.c, one aligner
-    per OpenMP thread over disjoint pair ranges (the reference's own model,
-    align_benchmark.c:246-284), on a bounded prefix of the same workload."""
+def usable_cpus():
+    """threads this process can really run at once: the scheduler affinity mask, capped by the cgroup CPU quota
+    (cpu.max = "<quota> <period>"), not os.cpu_count() (which counts the machine's CPUs, not ours)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        quota = q / float(g.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def cpu_baseline(batch, params_kw, workload, budget_s=15.0):
+    """The compiled reference (oracle/_ref, kind "reference") or the oracle restatement (kind "port") on the host cores:
+    oracle/cpu_bench.c, one aligner per OpenMP thread over disjoint pair ranges (the reference's own model,
+    align_benchmark.c:246-284), on a bounded prefix of the same workload.  Threads = what this process may really use."""
     import ctypes as C
     import subprocess
     import oracle_lib as O
@@ -91,7 +135,7 @@ def cpu_baseline(batch, params_kw, budget_s=15.0):
                                   C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p]
     kind = "reference" if O.have_ref() else "port"
     ref_so = O.REF_SO.encode() if kind == "reference" else None
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cpus()
 
     def run(n, threads):
         scores = np.zeros(n, dtype=np.int32)
@@ -104,13 +148,109 @@ def cpu_baseline(batch, params_kw, budget_s=15.0):
 
     run(min(len(batch), cores), cores)                   # warm the library, the arenas and the page cache
     n1 = min(len(batch), 64)
-    w1, _ = run(n1, 1)                                   # single-thread calibration
+    w1 = min(run(n1, 1)[0] for _ in range(3))            # single-thread calibration, best of three
     per = w1 / n1
     n = int(min(len(batch), max(cores * 8, budget_s / per * cores)))
     wall, scores = run(n, cores)
-    return {"value": n / wall, "unit": "alignments/s", "cores": cores, "cpu_model": cpu_model(), "kind": kind,
-            "sample": f"first {n} pairs of the same workload, {cores} OpenMP threads, one aligner per thread",
-            "single_thread_value": 1.0 / per}, scores.astype(np.int64)
+    single = 1.0 / per
+    per_thread = n / wall / cores
+    anchor = CPU_ANCHOR_PER_CORE.get(workload)
+    out = {"value": n / wall, "unit": "alignments/s", "cores": cores, "cpu_model": cpu_model(), "kind": kind,
+           "sample": f"first {n} pairs of the same workload, {cores} OpenMP threads (affinity mask"
+                     f"{'' if quota is None else f', cgroup quota {quota:.1f} CPUs'}; os.cpu_count() = {os.cpu_count()}), "
+                     "one aligner per thread",
+           "single_thread_value": single, "per_thread_value": per_thread,
+           "reference_anchor_per_core": anchor,
+           # a host whose cores run the reference far below the survey's anchor (shared / throttled
+           # cores) must be called out, not used to inflate a speed-up
+           "suspect": bool(anchor and (single < 0.5 * anchor or per_thread < 0.25 * anchor))}
+    return out, scores.astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# end to end: host buffers -> HBM (H2D) -> run -> scores on the host (D2H), batch after batch
+# ---------------------------------------------------------------------------------------------------------------
+def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflight=2):
+    """`nbatches` batches of the same host data through `slots` resident batch objects: an uploader thread reloads
+    (quicked_batch_reload*, H2D) batch k+1.. while the main thread queues run k (sync = 0) and fetches the scores of run
+    k - inflight + 1 (quicked_batch_fetch, D2H).  Returns alignments/s over everything between the first reload and
+    the last fetch; batch creation (hipMalloc) and the first upload are warm-up."""
+    L = capi.lib()
+    n = len(batch)
+    frees = []
+    if fmt == "ascii_pinned":
+        src = capi.pinned_copy(batch)
+        make = lambda: capi.ResidentBatch(src)                                       # noqa: E731
+        reload_ = lambda rb: rb.reload(src)                                          # noqa: E731
+        nbytes = int(batch.pattern_len.astype(np.int64).sum() + batch.text_len.astype(np.int64).sum())
+    elif fmt == "2bit_pinned":
+        pw, po = capi.wire_pack_pool(batch.pattern_pool, batch.pattern_off, batch.pattern_len, capi.WIRE_2BIT)
+        tw, to = capi.wire_pack_pool(batch.text_pool, batch.text_off, batch.text_len, capi.WIRE_2BIT)
+        (pwp, h1), (twp, h2) = capi.pinned_array(pw), capi.pinned_array(tw)
+        frees += [h1, h2]
+        src = None
+        make = lambda: capi.ResidentBatch.from_wire(batch, capi.WIRE_2BIT, pwp, po, twp, to)       # noqa: E731
+        reload_ = lambda rb: rb.reload_wire(batch, capi.WIRE_2BIT, pwp, po, twp, to)               # noqa: E731
+        nbytes = int(pw.nbytes + tw.nbytes)
+    else:
+        raise ValueError(fmt)
+    rbs = [make() for _ in range(slots)]
+    for rb in rbs:                                        # warm: code objects, pools of the rotation
+        assert rb.run(params, sync=True) >= 0
+    uploaded = [threading.Event() for _ in range(nbatches)]
+    fetched = [threading.Event() for _ in range(nbatches)]
+    err = []
+
+    def uploader():
+        try:
+            for k in range(nbatches):
+                if k >= slots:
+                    fetched[k - slots].wait()
+                st = reload_(rbs[k % slots])
+                if st < 0:
+                    raise RuntimeError(f"quicked_batch_reload: {st}")
+                uploaded[k].set()
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+            for ev in uploaded:
+                ev.set()
+
+    checks = []
+    t0 = time.perf_counter()
+    th = threading.Thread(target=uploader)
+    th.start()
+
+    def finish(k):
+        rb = rbs[k % slots]
+        assert rb.fetch() >= 0, "quicked_batch_fetch failed"
+        s, st = rb.scores()
+        assert (st >= 0).all()
+        checks.append(int(s.astype(np.int64).sum()))
+        fetched[k].set()
+
+    for k in range(nbatches):
+        uploaded[k].wait()
+        if err:
+            break
+        assert rbs[k % slots].run(params, sync=False) >= 0
+        if k >= inflight - 1:
+            finish(k - inflight + 1)
+    for k in range(max(nbatches - inflight + 1, 0), nbatches):
+        if not err:
+            finish(k)
+    elapsed = time.perf_counter() - t0
+    th.join()
+    for rb in rbs:
+        rb.close()
+    if src is not None:
+        capi.pinned_free(src)
+    for h in frees:
+        L.quicked_host_free(h)
+    if err:
+        raise err[0]
+    assert all(c == expect_checksum for c in checks), "end-to-end scores differ from the resident run's"
+    return {"value": n * nbatches / elapsed, "unit": "alignments/s", "batches": nbatches, "ms_per_batch": elapsed / nbatches * 1e3,
+            "h2d_bytes_per_batch": nbytes, "h2d_GBs": nbytes * nbatches / elapsed / 1e9}
 
 
 def main():
@@ -118,109 +258,151 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU per step (weak scaling: the headline value)")
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--error", type=float, default=0.05)
     ap.add_argument("--bandwidth", type=int, default=15)
     ap.add_argument("--workload", choices=["banded_score", "quicked"], default="banded_score")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-batches", type=int, default=12)
+    ap.add_argument("--no-strong", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="profiling aid: no overlap between consecutive runs, so per-kernel durations are those of a kernel alone")
     ap.add_argument("--seed", type=int, default=0x51CED)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves, as a child, before this process touches the GPU
+        import torch
+        have = torch.cuda.device_count()                    # does not initialise the GPU
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to run fewer ranks "
+                     "than asked for")
+        sys.exit(shard.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match the launcher's WORLD_SIZE {world}")
     dist = None
     torch = None
+    device = None
     if world > 1 or os.environ.get("QE_FORCE_DIST"):
         import torch
         import torch.distributed as dist
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, this node exposes {torch.cuda.device_count()}")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+        device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
 
     from quicked_amd import capi, datagen
-    capi.lib().quicked_set_device(local_rank)
+    if capi.lib().quicked_set_device(local_rank) < 0:
+        sys.exit(f"bench.py: rank {rank}: no HIP device {local_rank}")
 
-    # each rank owns pairs [rank * pairs, (rank + 1) * pairs) of the seeded dataset: independent work units
-    batch = datagen.generate(args.pairs, args.length, args.error, seed=args.seed, first=rank * args.pairs)
-    cells = batch.cells()
     if args.workload == "banded_score":
         kw = dict(algo=capi.BANDED, only_score=True, bandwidth=args.bandwidth)
     else:
         kw = dict(algo=capi.QUICKED, only_score=False, bandwidth=args.bandwidth)
     params = capi.make_params(**kw)
-    rb = capi.ResidentBatch(batch)           # H2D happens here, outside the timed region
 
-    for _ in range(max(args.warmup, 0)):
-        st = rb.run(params, sync=True)
-        assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
-    if args.warmup <= 0:
-        st = 0
-    rb.kernel_time()                         # drop the warm-up launches
-
-    def barrier():
+    def barrier(rb):
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
         rb.sync()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = rb.run(params, sync=args.sync_each_step)     # results stay resident in HBM; the driver still syncs where a stage needs host decisions
+    def timed_resident(first, count, steps, warmup):
+        """the contract's loop: `warmup` untimed steps, then exactly `steps` steps between two barrier + synchronize"""
+        batch = datagen.generate(count, args.length, args.error, seed=args.seed, first=first)
+        rb = capi.ResidentBatch(batch)           # H2D happens here, outside the timed region
+        for _ in range(max(warmup, 0)):
+            st = rb.run(params, sync=True)
+            assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
+        rb.kernel_time()                         # drop the warm-up launches
+        barrier(rb)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = rb.run(params, sync=args.sync_each_step)     # results stay resident in HBM; the driver still syncs where a stage needs host decisions
+            assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
+        rb.sync()
+        barrier(rb)
+        elapsed = time.perf_counter() - t0
+        kern_ms, kern_n = rb.kernel_time()
+        # one synchronous run to fetch results + work counters for the report
+        st = rb.run(params, sync=True)
         assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
-    rb.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = rb.kernel_time()
+        scores, status = rb.scores()
+        assert (status >= 0).all(), "some pairs failed"
+        counters = rb.counters()
+        rb.kernel_time()
+        rb.close()
+        return batch, scores, counters, elapsed, kern_ms, kern_n
 
-    # one synchronous run to fetch results + work counters for the report
-    st = rb.run(params, sync=True)
-    assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
-    scores, status = rb.scores()
-    assert (status >= 0).all(), "some pairs failed" 
-    counters = rb.counters()
-    rb.kernel_time()
+    # ---- the headline: weak scaling, `pairs` pairs per GPU, inputs resident in HBM
+    first, count, _ = shard.plan(args.pairs, rank, world, "weak")
+    batch, scores, counters, elapsed, kern_ms, kern_n = timed_resident(first, count, args.steps, args.warmup)
+    cells = batch.cells()
     checksum = int(scores.astype(np.int64).sum())
+    tot_pairs, tot_cells, tot_checksum, max_elapsed, _ = shard.reduce_totals(dist, torch, device, count, cells, checksum, elapsed)
 
-    tot_pairs, tot_cells, max_elapsed, tot_checksum = args.pairs, cells, elapsed, checksum
-    if dist is not None:
-        t = torch.tensor([float(args.pairs), float(cells), float(checksum)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        tot_pairs, tot_cells, tot_checksum, max_elapsed = int(t[0].item()), int(t[1].item()), int(t[2].item()), e.item()
+    # ---- end to end (PCIe-inclusive), every rank on its own GPU and PCIe link; rates add up
+    e2e = None
+    if not args.no_e2e and args.workload == "banded_score":
+        e2e = {}
+        for fmt in ("ascii_pinned", "2bit_pinned"):
+            r = e2e_leg(capi, batch, params, fmt, args.e2e_batches, checksum)
+            _, _, _, _, ext = shard.reduce_totals(dist, torch, device, 0, 0, 0, 0.0, extra_sum=(r["value"], r["h2d_GBs"]))
+            r["value"], r["h2d_GBs"] = ext[0], ext[1]
+            e2e[fmt] = r
+        e2e["note"] = ("create/reload (H2D) of batch k+1 overlapped with the run of batch k, scores fetched (D2H) per batch; "
+                       "summed over ranks; PCIe Gen5 x16 moves ~47-55 GB/s from pinned memory, which bounds the ASCII form at "
+                       "~2.5 M alignments/s per GPU")
 
+    # ---- strong scaling: the same workload with `pairs` pairs in total (BASELINE.json's "100 k pairs at 8 GPUs")
+    strong = None
+    if world > 1 and not args.no_strong:
+        sfirst, scount, stotal = shard.plan(args.pairs, rank, world, "strong")
+        _, s_scores, _, s_elapsed, _, _ = timed_resident(sfirst, scount, args.steps, 1)
+        s_pairs, _, s_checksum, s_max, _ = shard.reduce_totals(dist, torch, device, scount, 0, int(s_scores.astype(np.int64).sum()), s_elapsed)
+        strong = {"scaling": "strong", "total_pairs": s_pairs, "pairs_per_gpu": scount, "value": s_pairs * args.steps / s_max,
+                  "unit": "alignments/s", "ms_per_step": s_max / args.steps * 1e3, "score_checksum": s_checksum}
+
+    line = None
     if rank == 0:
         value = tot_pairs * args.steps / max_elapsed
         per_launch_bytes = float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64) + 4).sum())
         kern_s = (kern_ms / 1e3 / kern_n) if kern_n else float("nan")
+        step_s = max_elapsed / args.steps
+        roof_extra = {}
         if args.workload == "banded_score":
+            # SURVEY 8(d): B_so = plen + tlen + 4 per pair (ASCII in, int32 score out)
             kernel, alg_bytes, work_blocks = "k_banded<false> (BandEd score-only)", per_launch_bytes, int(counters[0])
         else:
-            # ASCII in + 16 B per stored block-column + 16 B per traceback step + ops out.  NB the kernels
-            # store a 16-byte checkpoint every 8th column and recompute the rest: the HBM traffic they
-            # generate (roofline.traffic) is BELOW this figure, so frac can exceed the naive bound
-            alg_bytes = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
-            kernel, work_blocks = "k_banded<true> (BandEd fill)", int(counters[1])
-        traffic = None
-        try:      # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")) as f:
-                pm = json.load(f)["banded_score" if args.workload == "banded_score" else "quicked"]
-            key = "k_banded<false>" if args.workload == "banded_score" else "k_banded<true>"
-            if args.pairs == 100000 and args.length == 10000:
-                traffic = pm[key]["hbm_bytes"]
-        except Exception:
+            # The fill stores a 16-byte checkpoint per (slot, 8 columns) and the 16-byte carry words per (slot, chunk):
+            # 2.25 B per block-column, and reads its inputs as bit-planes (3 bits per base); the traceback recomputes
+            # 16-column tiles from those.  SURVEY 8(d)'s figure (every column stored, 16 B per block-column and per
+            # traceback step) is what the reference's layout would move: kept as survey_equivalent_bytes, never divided
+            # by the time of a kernel that does not move those bytes
+            planes_in = 0.375 * float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64)).sum())
+            alg_bytes = planes_in + 2.25 * float(counters[1])
+            roof_extra["survey_equivalent_bytes"] = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
+            kernel, work_blocks = "k_banded<true> (BandEd fill, checkpointed)", int(counters[1])
+        traffic, traffic_src = None, None
+        try:      # HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profiles.sh)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+                pm = json.load(f)
+            ent = pm.get(f"{args.workload}:{args.pairs}x{args.length}")
+            if ent:
+                traffic, traffic_src = ent["hbm_bytes"], ent.get("source")
+        except Exception:      # noqa: BLE001
             traffic = None
         achieved = alg_bytes / kern_s / 1e9
-        valu_rate = work_blocks / kern_s
-        # consecutive runs overlap on two streams (the next run's kernel takes the SIMD slots this one leaves empty), so
-        # a launch lasts longer than its share of the wall clock: the aggregate figures divide the same per-launch
-        # work by the step time instead of the launch duration
-        step_s = max_elapsed / args.steps
-        agg_valu_rate = work_blocks / step_s
+        instr_rate = work_blocks * INSTR_PER_BLOCK_COLUMN / kern_s
+        peak_instr = SIMDS * PEAK_CLOCK_HZ / 2.0
         line = {
             "metric": "alignments/sec + GCUPS, 10kb x 10kb 5%-error pairs",
             "value": value, "unit": "alignments/s", "gcups": tot_cells * args.steps / max_elapsed / 1e9,
@@ -229,30 +411,37 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": max_elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {args.pairs} pairs/GPU x {args.length} bp @ {args.error:g} error, "
-                                   f"bandwidth {args.bandwidth} %, seeded generator (SURVEY 8d), ASCII resident in HBM",
+            "config": {"workload": f"{args.workload}, DEVICE-RESIDENT inputs: {args.pairs} pairs/GPU x {args.length} bp @ {args.error:g} error, "
+                                   f"bandwidth {args.bandwidth} %, seeded generator (SURVEY 8d), ASCII already in HBM when the clock "
+                                   "starts, scores left in HBM (end-to-end rates: e2e)",
                        "pairs_per_gpu": args.pairs, "length": args.length, "error": args.error,
                        "bandwidth": args.bandwidth, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
-                         "aggregate_achieved": alg_bytes / step_s / 1e9,
-                         "hbm_copy_measured_GBs": measured_copy_bandwidth(),
-                         "note": "score-only BandEd is integer-VALU-bound, not HBM-bound (SURVEY 8d); see valu"},
-            "valu": {"bound": "integer VALU issue", "achieved": valu_rate, "peak": VALU_PEAK_BLOCK_COLUMNS,
-                     "unit": "block-columns/s", "frac": valu_rate / VALU_PEAK_BLOCK_COLUMNS,
-                     "aggregate_achieved": agg_valu_rate, "aggregate_frac": agg_valu_rate / VALU_PEAK_BLOCK_COLUMNS,
-                     "block_columns_per_launch": work_blocks, "issue_cycles_per_block_column": ISSUE_CYCLES_PER_BLOCK_COLUMN,
-                     "instructions_per_block_column": OPS_PER_BLOCK_COLUMN,
-                     "note": "achieved uses the launch duration (launches of consecutive runs overlap); aggregate uses the step time"},
+            "roofline": dict({"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                              "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
+                              "aggregate_achieved": alg_bytes / step_s / 1e9,
+                              "hbm_copy_measured_GBs": measured_copy_bandwidth(),
+                              "note": "the BandEd kernels are integer-VALU-bound, not HBM-bound (SURVEY 8d); see valu"}, **roof_extra),
+            "valu": {"bound": "VALU issue, one wave64 instruction per SIMD per 2 cycles", "unit": "wave-instructions/s",
+                     "achieved": instr_rate, "peak": peak_instr, "frac": instr_rate / peak_instr,
+                     "aggregate_achieved": work_blocks * INSTR_PER_BLOCK_COLUMN / step_s,
+                     "aggregate_frac": work_blocks * INSTR_PER_BLOCK_COLUMN / step_s / peak_instr,
+                     "block_columns_per_launch": work_blocks, "instructions_per_block_column": INSTR_PER_BLOCK_COLUMN,
+                     "issue_cycles_per_block_column": ISSUE_CYCLES_PER_BLOCK_COLUMN,
+                     "instruction_mix_bound_block_columns_per_s": SIMDS * PEAK_CLOCK_HZ * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN,
+                     "note": "achieved uses the launch duration (launches of consecutive runs overlap); aggregate uses the step "
+                             "time; peak assumes the 2.4 GHz peak clock (the chip holds less under this load: DESIGN.md 4.1)"},
             "score_checksum": tot_checksum,
         }
+        if e2e is not None:
+            line["e2e"] = e2e
+        if strong is not None:
+            line["strong"] = strong
         if not args.no_cpu_baseline and world == 1:          # the CPU reference is timed on rank 0 at N = 1 only
-            base, ref_scores = cpu_baseline(batch, {k: v for k, v in kw.items()})
+            base, ref_scores = cpu_baseline(batch, {k: v for k, v in kw.items()}, args.workload)
             n = len(ref_scores)
             base["gpu_scores_identical_on_sample"] = bool((scores[:n].astype(np.int64) == ref_scores).all())
             line["cpu_baseline"] = base
-    rb.close()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -48,6 +48,13 @@ quicked_batch_t* quicked_batch_create(int64_t n,
                                       const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
                                       const char* text_pool, const int64_t* text_off, const int32_t* text_len);
 void quicked_batch_destroy(quicked_batch_t* batch);
+/* Loads n new pairs into an existing batch object: same arguments as quicked_batch_create, but the object's device
+ * arena is kept when it is large enough (no hipMalloc / hipFree, which synchronise the device).  Waits for the runs of
+ * the batch that are still on the device; may be called from another thread than the one that runs the batch -- a
+ * client streams by reloading batch k+1 on an uploader thread while batch k runs (bench.py's end-to-end leg). */
+quicked_status_t quicked_batch_reload(quicked_batch_t* batch, int64_t n,
+                                      const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
+                                      const char* text_pool, const int64_t* text_off, const int32_t* text_len);
 
 /* ---- packed wire format (supersedes sequence_buffer_t, tools/align_benchmark/utils/sequence_buffer.h:30-50)
  * For sequences over upper-case A, C, G, T (and N in PLANES3) -- the symbols whose raw-byte and encoded
@@ -66,19 +73,28 @@ quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
                                              const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
                                              const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len);
 
+quicked_status_t quicked_batch_reload_packed(quicked_batch_t* batch, int64_t n, int wire,
+                                             const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
+                                             const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len);
+
 /* Runs the hot path for every pair with `params` (algo, only_score, ...), from
  * the ASCII bytes resident in HBM to scores (and CIGAR runs) resident in HBM.
  * sync != 0: waits for the run and copies scores / statuses / CIGARs / counters
  * to the host, where the getters below read them.
  * sync == 0: returns once the run is queued (QUICKED / HIRSCHBERG: once their
  * bound stages, which need host decisions, are done); nothing is copied to the
- * host.  Consecutive runs of a thread rotate over up to three sets of stream, device
+ * host until quicked_batch_fetch().  Consecutive runs of a thread rotate over up to three sets of stream, device
  * pool and bit-planes, so the kernels of runs k+1 and k+2 overlap those of run k;
  * the device results of a run stay valid until the next run of that thread starts. */
 quicked_status_t quicked_batch_run(quicked_batch_t* batch, const quicked_params_t* params, int sync);
 quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
+/* Brings the results of the batch's last sync == 0 run to the host: waits for that run (only that one: later runs of
+ * this or other batches keep executing) and copies scores / statuses / CIGARs / counters to where the getters read
+ * them.  A sync == 0 run itself leaves the getters' data untouched.  The device-side results live in the queueing
+ * thread's rotating pools: fetch before that thread has queued two more runs, or QUICKED_ERROR is returned. */
+quicked_status_t quicked_batch_fetch(quicked_batch_t* batch);
 
-/* results of the last sync != 0 run (host copies made by that run) */
+/* results of the last sync != 0 run or of the last quicked_batch_fetch (host copies) */
 quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_out, int32_t* status_out);
 /* total bytes of all CIGAR strings incl. terminators, then the strings themselves
  * (cigar_off[i] = offset of string i in cigar_pool, -1 if none) */

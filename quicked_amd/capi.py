@@ -56,7 +56,8 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters",
            "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free",
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
-           "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed"]
+           "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
+           "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch"]
 
 _LIB = None
 
@@ -106,6 +107,9 @@ def lib():
     L.quicked_wire_pack.argtypes = [C.c_char_p, C.c_int32, C.c_int, C.c_void_p]
     L.quicked_batch_create_packed.restype = C.c_void_p
     L.quicked_batch_create_packed.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.quicked_batch_reload.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.quicked_batch_reload_packed.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.quicked_batch_fetch.argtypes = [C.c_void_p]
     L.quicked_host_alloc.restype = C.c_void_p
     L.quicked_host_alloc.argtypes = [C.c_size_t]
     L.quicked_host_free.argtypes = [C.c_void_p]
@@ -250,6 +254,25 @@ class ResidentBatch:
 
     def sync(self):
         return self._lib.quicked_batch_sync(self._h)
+
+    def fetch(self):
+        """results of the last sync=False run -> host (quicked_batch_fetch)"""
+        return self._lib.quicked_batch_fetch(self._h)
+
+    def reload(self, batch):
+        """new pairs into the same batch object (quicked_batch_reload): the device arena is reused"""
+        self._keep = batch
+        self.n = len(batch)
+        return self._lib.quicked_batch_reload(
+            self._h, self.n, batch.pattern_pool.ctypes.data, batch.pattern_off.ctypes.data, batch.pattern_len.ctypes.data,
+            batch.text_pool.ctypes.data, batch.text_off.ctypes.data, batch.text_len.ctypes.data)
+
+    def reload_wire(self, batch, wire, pw, po, tw, to):
+        self._keep = (batch, pw, po, tw, to)
+        self.n = len(batch)
+        return self._lib.quicked_batch_reload_packed(
+            self._h, self.n, wire, pw.ctypes.data, po.ctypes.data, batch.pattern_len.ctypes.data,
+            tw.ctypes.data, to.ctypes.data, batch.text_len.ctypes.data)
 
     def configure(self, cigar_style=0, check=False):
         """cigar_style 0 = reference RLE "MXID", 1 = SAM "=XID", 2 = SAM "MID"; check = device-side validator"""

@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <unordered_map>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -52,6 +55,7 @@ struct DevicePool {
     struct Chunk { uint8_t* base; size_t cap; };
     std::vector<Chunk> chunks;
     size_t cur = 0, top = 0, cap = 0;            // cap = total bytes over all chunks
+    uint64_t generation = 0;                     // bumped whenever handed-out pointers stop being valid (reset / release_all)
     // out of memory: the thread's other pools are asked to give theirs back (their runs are waited for first) and the
     // allocation is tried once more; set by Context
     static inline bool (*reclaim_fn)(DevicePool* keep) = nullptr;
@@ -74,7 +78,7 @@ struct DevicePool {
             chunks.clear(); cap = 0;
             add_chunk(total);
         }
-        cur = 0; top = 0;
+        cur = 0; top = 0; ++generation;
     }
     struct Mark { size_t cur, top; };
     Mark mark() const { return Mark{cur, top}; }
@@ -102,7 +106,7 @@ struct DevicePool {
     }
     void release_all() {
         for (auto& c : chunks) if (c.base) (void)hipFree(c.base);
-        chunks.clear(); cap = 0; cur = 0; top = 0;
+        chunks.clear(); cap = 0; cur = 0; top = 0; ++generation;
     }
     size_t used_hint() const { return cap; }
     ~DevicePool() { for (auto& c : chunks) if (c.base) (void)hipFree(c.base); }
@@ -206,11 +210,21 @@ static void qe_timer_stop(profiler_timer_t* t);
 static thread_local Context* tl_ctx = nullptr;
 static bool reclaim_pools(DevicePool* keep);
 static thread_local int tl_device = 0;
+// one Context per (host thread, device): a thread that alternates between devices keeps both (streams, pools and
+// pinned stages of the device it left stay where they are)
+static thread_local std::vector<Context*> tl_ctx_all;
+static thread_local int tl_bound_device = -1;
 static Context& ctx() {
     if (!tl_ctx || tl_ctx->device != tl_device) {
-        tl_ctx = new Context();   // lives for the thread; a handful per process
-        tl_ctx->device = tl_device;
+        tl_ctx = nullptr;
+        for (Context* c : tl_ctx_all) if (c->device == tl_device) tl_ctx = c;
+        if (!tl_ctx) {
+            tl_ctx = new Context();   // lives for the thread; one per device it uses
+            tl_ctx->device = tl_device;
+            tl_ctx_all.push_back(tl_ctx);
+        }
     }
+    if (tl_bound_device != tl_device) { HIP_CHECK(hipSetDevice(tl_device)); tl_bound_device = tl_device; }
     tl_ctx->init();
     DevicePool::reclaim_fn = &reclaim_pools;
     return *tl_ctx;
@@ -316,6 +330,10 @@ struct quicked_batch {
     // results of the last run, device side, indexed by task (what a timed run leaves in HBM)
     int32_t* d_score = nullptr;
     bool pending = false;
+    // what quicked_batch_fetch needs to bring the results of the last sync == 0 run to the host (qe::PendingFetch)
+    std::shared_ptr<void> pending_fetch;
+    // wire words of a packed batch (device), kept so that a reload can reuse the arena
+    int wire = 0;
 
     ~quicked_batch() {
         if (arena) (void)hipFree(arena);
@@ -625,18 +643,6 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     return S;
 }
 
-static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
-                             bool fetch, int32_t** d_score_out) {
-    const int G = coop_lanes(L);
-    const ScoreLaunch S = (G >= 2) ? launch_banded_coop(B, C, L, reversed, G, true) : launch_banded_score(B, C, L, reversed, true);
-    if (d_score_out) *d_score_out = S.O.score;
-    if (fetch && R) {
-        if (G >= 2) d2h(R->hew, S.O.hew, S.nt, C.stream);       // abort flags (diagnostics)
-        d2h(R->score, S.O.score, S.nt, C.stream); d2h(R->adv, S.O.adv, S.nt, C.stream);
-        HIP_CHECK(hipStreamSynchronize(C.stream));
-    }
-}
-
 // upper bound of one pair's RLE string incl. terminator: every op its own run
 static size_t cigar_bound(int m, int n) { return (size_t)2 * ((size_t)m + (size_t)n) + 12; }
 
@@ -657,6 +663,42 @@ struct AlignOut {                             // device, per root
     int32_t* ok = nullptr;                    // validator verdicts (null unless the batch asks for them)
     size_t nroots = 0;
 };
+
+// Results of a sync == 0 run, still on the device: what quicked_batch_fetch() copies once the run is over.  The device
+// pointers live in the A pool of the thread that queued the run and stay valid until that pool comes round again in the
+// thread's rotation (`generation` tells): at most two more runs may be queued by that thread before the fetch.
+struct PendingFetch {
+    int kind = 0;                             // 1: one score per task (score-only BandEd / WindowEd); 2: alignments (segments)
+    quicked_status_t ok_status = QUICKED_WIP;
+    bool want_strings = false;
+    // kind 1
+    std::vector<int32_t> task_pair;
+    const int32_t* d_score = nullptr; const u32* d_adv = nullptr; const u32* d_steps = nullptr; const int32_t* d_abort = nullptr;
+    int counter_slot = 0;                     // where sum(adv) / sum(steps) goes in counters[]
+    // kind 2
+    SegList SL; AlignOut AO; std::vector<int32_t> root_status;
+    std::vector<int32_t> leaf_pair; const u32* d_leaf_adv = nullptr; const u32* d_leaf_steps = nullptr;
+    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // what the run's host-side stages already counted
+    bool quicked = false;                     // run_quicked ignores the Hirschberg status (quicked.c:290-291)
+    // validity
+    DevicePool* pool = nullptr; uint64_t generation = 0; int parity = 0;
+};
+
+static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
+                             bool fetch, int32_t** d_score_out, PendingFetch* pf = nullptr) {
+    const int G = coop_lanes(L);
+    const ScoreLaunch S = (G >= 2) ? launch_banded_coop(B, C, L, reversed, G, true) : launch_banded_score(B, C, L, reversed, true);
+    if (d_score_out) *d_score_out = S.O.score;
+    if (pf && !fetch) {
+        pf->kind = 1; pf->task_pair = L.pair; pf->d_score = S.O.score; pf->d_adv = S.O.adv; pf->counter_slot = 0;
+        pf->d_abort = (G >= 2) ? S.O.hew : nullptr;
+    }
+    if (fetch && R) {
+        if (G >= 2) d2h(R->hew, S.O.hew, S.nt, C.stream);       // abort flags (diagnostics)
+        d2h(R->score, S.O.score, S.nt, C.stream); d2h(R->adv, S.O.adv, S.nt, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+    }
+}
 
 static AlignOut format_segments(const quicked_batch& B, Context& C, const SegList& SL, const u32* runs, const int64_t* g_runs_off,
                                 const int32_t* nruns, bool want_strings) {
@@ -725,7 +767,8 @@ static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, co
 
 // WindowEd over a task list (bpm_windowed.c:563-628)
 static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int W, int O_, int hew_threshold,
-                         bool score_only, bool sse, StageResult* R, bool fetch, bool want_cigar, int32_t** d_score_out) {
+                         bool score_only, bool sse, StageResult* R, bool fetch, bool want_cigar, int32_t** d_score_out,
+                         PendingFetch* pf = nullptr) {
     const size_t nt = L.pair.size();
     const int ng = L.ngroups();
     // per group: Pv/Mv [W][64] u64 + tiled history of (64W+3) columns x W blocks
@@ -765,6 +808,12 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
         AO = format_segments(B, C, SL, D.runs, D.runs_off, O.nruns, want_cigar);
         if (d_score_out) *d_score_out = AO.edits;
     }
+    if (pf && !fetch) {
+        pf->task_pair = L.pair; pf->d_score = O.score; pf->d_steps = O.steps; pf->counter_slot = 2;
+        pf->kind = score_only ? 1 : 2;
+        if (!score_only) { pf->SL = std::move(SL); pf->AO = AO; pf->want_strings = want_cigar; pf->ok_status = QUICKED_WIP; }
+        return;
+    }
     if (fetch && R) {
         d2h(R->score, O.score, nt, C.stream); d2h(R->hew, O.hew, nt, C.stream); d2h(R->steps, O.steps, nt, C.stream);
         HIP_CHECK(hipStreamSynchronize(C.stream));
@@ -784,7 +833,8 @@ struct HNode { int32_t pair, p0, m, t0, n, cutoff, left, right, leaf_task; };
 struct AlignStats { uint64_t fill_adv = 0, tb_steps = 0, score_adv = 0, splits = 0, leaves = 0; };
 
 static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool fetch, bool want_cigar,
-                      size_t matrix_budget, uint64_t split_bytes, int32_t ok_status, int32_t** d_score_out, AlignStats* stats) {
+                      size_t matrix_budget, uint64_t split_bytes, int32_t ok_status, int32_t** d_score_out, AlignStats* stats,
+                      PendingFetch* pf = nullptr) {
     std::vector<HNode> nodes;
     std::vector<int32_t> root_node, root_status;
     for (size_t t = 0; t < roots.pair.size(); ++t) {
@@ -958,6 +1008,12 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     }
     const AlignOut AO = format_segments(B, C, SL, d_runs, d_runs_off, O.nruns, want_cigar);
     if (d_score_out) *d_score_out = AO.edits;
+    if (pf && !fetch) {
+        pf->kind = 2; pf->SL = std::move(SL); pf->AO = AO; pf->want_strings = want_cigar;
+        pf->ok_status = (quicked_status_t)ok_status; pf->root_status = std::move(root_status);
+        pf->leaf_pair = LL.pair; pf->d_leaf_adv = O.adv; pf->d_leaf_steps = O.steps;
+        return;
+    }
     if (fetch) {
         if (stats) {
             std::vector<u32> adv, steps;
@@ -1011,6 +1067,14 @@ static uint64_t split_threshold() {
 static bool trace_on() { static int v = -1; if (v < 0) v = getenv("QE_TRACE") ? 1 : 0; return v == 1; }
 #define QE_TRACE_POINT(name) do { if (trace_on()) { double t__ = now_ms(); fprintf(stderr, "[qe] %-22s +%.3f ms\n", name, t__ - tr_last); tr_last = t__; } } while (0)
 
+static void reset_host_results(quicked_batch& B) {
+    B.score.assign((size_t)B.n, -1);
+    B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
+    B.cigar_off.assign((size_t)B.n, -1);
+    B.cigar_pool.clear();
+    B.check_ok.assign((size_t)B.n, -1);
+}
+
 static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
     double tr_last = now_ms();
     tl_device = B.device;
@@ -1053,11 +1117,12 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.stream_w, B.ev_done[par], 0));
     }
     B.only_score_run = p.only_score;
-    B.score.assign((size_t)B.n, -1);
-    B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
-    B.cigar_off.assign((size_t)B.n, -1);
-    B.cigar_pool.clear();
-    B.check_ok.assign((size_t)B.n, -1);
+    // sync == 0 leaves the host-side results of the last fetched run untouched (quicked_batch_fetch brings this run's)
+    B.pending_fetch.reset();
+    std::shared_ptr<PendingFetch> pfp;
+    if (fetch) reset_host_results(B);
+    else pfp = std::make_shared<PendingFetch>();
+    PendingFetch* const pf = pfp.get();
     for (auto& c : B.counters) c = 0;
     if ((unsigned)p.algo > (unsigned)HIRSCHBERG) {
         if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNKNOWN_ALGO);
@@ -1096,7 +1161,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     case BANDED:                                                    // run_banded, quicked.c:58-89
         enter_a();
         if (p.only_score) {
-            run_banded_score(B, C, L, false, &R, fetch, &B.d_score);
+            run_banded_score(B, C, L, false, &R, fetch, &B.d_score, pf);
             if (fetch) {
                 scatter_scores(B, L, R.score, QUICKED_WIP);
                 B.counters[0] = (int64_t)sum_u32(R.adv);
@@ -1104,14 +1169,14 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             }
         } else {
             AlignStats AS;          // run_banded never splits: one fill + traceback whatever the size
-            run_align(B, C, L, fetch, want_cigar, matrix_budget, ~(uint64_t)0, QUICKED_WIP, &B.d_score, &AS);
+            run_align(B, C, L, fetch, want_cigar, matrix_budget, ~(uint64_t)0, QUICKED_WIP, &B.d_score, &AS, pf);
             B.counters[1] = (int64_t)AS.fill_adv; B.counters[3] = (int64_t)AS.tb_steps;
         }
         break;
     case WINDOWED:                                                  // run_windowed, quicked.c:91-123
         enter_a();
         run_windowed(B, C, L, false, (int)p.window_size, (int)p.overlap_size, 0, p.only_score, sse, &R, fetch,
-                     want_cigar, &B.d_score);
+                     want_cigar, &B.d_score, pf);
         if (fetch) { scatter_scores(B, L, R.score, QUICKED_WIP); B.counters[2] = (int64_t)sum_u32(R.steps); }
         break;
     case QUICKED:                                                   // run_quicked, quicked.c:163-306
@@ -1209,7 +1274,8 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         AlignStats AS;
         // run_quicked ignores the Hirschberg status (quicked.c:290-291, A.7(8)); run_hirschberg returns it (149-160)
         run_align(B, C, LA, fetch, want_cigar, matrix_budget, split_threshold(), p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK,
-                  &B.d_score, &AS);
+                  &B.d_score, &AS, pf);
+        if (pf) pf->quicked = p.algo == QUICKED;
         qe_timer_stop(tl_timers.align);
         QE_TRACE_POINT("align launch(+fetch)");
         B.counters[0] += (int64_t)AS.score_adv; B.counters[1] += (int64_t)AS.fill_adv; B.counters[3] += (int64_t)AS.tb_steps;
@@ -1232,6 +1298,11 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     QE_TRACE_POINT("pool mirror");
     B.ev_done_set[par] = true;
+    if (pf && pf->kind != 0) {
+        pf->pool = &C.pa(); pf->generation = C.pa().generation; pf->parity = par;
+        for (int q = 0; q < 8; ++q) pf->counters[q] = B.counters[q];
+        B.pending_fetch = pfp;
+    }
     C.phase_w();
     B.pending = true;
     if (fetch) {
@@ -1243,6 +1314,59 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         B.pending = false;
     }
     return ret;
+}
+
+
+// quicked_batch_fetch: waits for the batch's last sync == 0 run and copies its results to the host-side arrays the
+// getters read -- what a sync != 0 run does at its end, only later (so that further runs can be queued meanwhile)
+static quicked_status_t fetch_pending(quicked_batch& B) {
+    tl_device = B.device;
+    Context& C = ctx();
+    if (!B.pending_fetch) return B.pending ? QUICKED_ERROR : QUICKED_OK;      // nothing queued asynchronously
+    std::shared_ptr<void> hold = B.pending_fetch;
+    PendingFetch& F = *static_cast<PendingFetch*>(hold.get());
+    B.pending_fetch.reset();
+    HIP_CHECK(hipEventSynchronize(B.ev_done[F.parity]));
+    if (F.pool->generation != F.generation) {
+        fprintf(stderr, "[quicked_hip] quicked_batch_fetch: the run's device results were overwritten by later runs of the "
+                        "thread that queued it (fetch before queueing a third run)\n");
+        return QUICKED_ERROR;
+    }
+    C.phase_w();
+    reset_host_results(B);
+    for (int q = 0; q < 8; ++q) B.counters[q] = F.counters[q];
+    if (F.kind == 1) {
+        const size_t nt = F.task_pair.size();
+        std::vector<int32_t> sc, ab; std::vector<u32> w;
+        d2h(sc, F.d_score, nt, C.stream);
+        if (F.d_adv) d2h(w, F.d_adv, nt, C.stream); else if (F.d_steps) d2h(w, F.d_steps, nt, C.stream);
+        if (F.d_abort) d2h(ab, F.d_abort, nt, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        for (size_t t = 0; t < nt; ++t) {
+            const int pr = F.task_pair[t];
+            if (pr < 0) continue;
+            B.score[pr] = sc[t]; B.status[pr] = F.ok_status;
+        }
+        B.counters[F.counter_slot] += (int64_t)sum_u32(w);
+        for (int32_t x : ab) B.counters[6] += (x != 0);
+    } else {
+        if (F.d_leaf_adv) {
+            const size_t nt = F.leaf_pair.size();
+            std::vector<u32> adv, steps;
+            d2h(adv, F.d_leaf_adv, nt, C.stream); d2h(steps, F.d_leaf_steps, nt, C.stream);
+            HIP_CHECK(hipStreamSynchronize(C.stream));
+            for (size_t t = 0; t < nt; ++t) if (F.leaf_pair[t] >= 0) { B.counters[1] += adv[t]; B.counters[3] += steps[t]; }
+        } else if (F.d_steps) {
+            std::vector<u32> steps;
+            d2h(steps, F.d_steps, F.task_pair.size(), C.stream);
+            HIP_CHECK(hipStreamSynchronize(C.stream));
+            B.counters[2] += (int64_t)sum_u32(steps);
+        }
+        fetch_alignments(B, C, F.SL, F.AO, F.want_strings, F.ok_status, F.root_status.empty() ? nullptr : &F.root_status);
+        if (F.quicked) for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+    }
+    B.pending = false;
+    return QUICKED_OK;
 }
 
 }  // namespace qe
@@ -1301,15 +1425,6 @@ static void upload_span(uint8_t* dst, const uint8_t* src, size_t bytes, int devi
 // ===========================================================================
 // C-ABI
 // ===========================================================================
-static quicked_status_t guard(quicked_batch* B, quicked_status_t (*fn)(quicked_batch*, void*), void* arg) {
-    try { return fn(B, arg); }
-    catch (const HipError& e) {
-        fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
-        return QUICKED_ERROR;
-    }
-    catch (const std::bad_alloc&) { fprintf(stderr, "[quicked_hip] out of host memory\n"); return QUICKED_ERROR; }
-}
-
 QE_API void* quicked_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
@@ -1324,78 +1439,146 @@ QE_API quicked_status_t quicked_set_device(int device) {
     return QUICKED_OK;
 }
 
-QE_API quicked_batch_t* quicked_batch_create(int64_t n,
-                                             const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
-                                             const char* text_pool, const int64_t* text_off, const int32_t* text_len) {
-    quicked_batch* B = new quicked_batch();
-    try {
-        Context& C = ctx();
-        B->n = n; B->device = C.device;
-        B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
-        // A pool whose pairs lie (nearly) back to back is uploaded as the byte span it is, offsets kept;
-        // a sparse one is compacted first.
-        B->p_off.resize((size_t)n); B->t_off.resize((size_t)n); B->plp_off.resize((size_t)n); B->plt_off.resize((size_t)n);
-        size_t pb = 0, tb = 0;
-        int64_t p_lo = INT64_MAX, p_hi = 0, t_lo = INT64_MAX, t_hi = 0;
+static quicked_status_t guard(quicked_batch* B, quicked_status_t (*fn)(quicked_batch*, void*), void* arg) {
+    try { return fn(B, arg); }
+    catch (const HipError& e) {
+        fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+        return QUICKED_ERROR;
+    }
+    catch (const std::bad_alloc&) { fprintf(stderr, "[quicked_hip] out of host memory\n"); return QUICKED_ERROR; }
+}
+
+// (re)loads a batch object with n pairs: host-side layout, arena (kept when it is large enough), H2D.  The caller has
+// made sure no run of the batch is still on the device.
+namespace qe {
+static void batch_reset_state(quicked_batch* B) {
+    B->pl_p_words = 0; B->pl_t_words = 0;
+    for (bool& h : B->have_rev) h = false;
+    for (bool& e : B->ev_done_set) e = false;
+    B->parity = 0; B->pending = false; B->pending_fetch.reset(); B->d_score = nullptr;
+    B->score.clear(); B->status.clear(); B->cigar_off.clear(); B->cigar_pool.clear(); B->check_ok.clear();
+}
+static void batch_arena(quicked_batch* B, size_t need) {
+    if (B->arena && B->arena_bytes >= need) return;
+    if (B->arena) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(B->arena)); B->arena = nullptr; B->arena_bytes = 0; }
+    HIP_CHECK(hipMalloc((void**)&B->arena, need));
+    B->arena_bytes = need;
+}
+static void batch_load(quicked_batch* B, Context& C, int64_t n,
+                       const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
+                       const char* text_pool, const int64_t* text_off, const int32_t* text_len) {
+    batch_reset_state(B);
+    B->n = n; B->device = C.device; B->packed = false; B->wire = 0;
+    B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
+    // A pool whose pairs lie (nearly) back to back is uploaded as the byte span it is, offsets kept;
+    // a sparse one is compacted first.
+    B->p_off.resize((size_t)n); B->t_off.resize((size_t)n); B->plp_off.resize((size_t)n); B->plt_off.resize((size_t)n);
+    size_t pb = 0, tb = 0;
+    int64_t p_lo = INT64_MAX, p_hi = 0, t_lo = INT64_MAX, t_hi = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        pb += (size_t)pattern_len[i]; tb += (size_t)text_len[i];
+        if (pattern_len[i]) { p_lo = std::min(p_lo, pattern_off[i]); p_hi = std::max(p_hi, pattern_off[i] + pattern_len[i]); }
+        if (text_len[i]) { t_lo = std::min(t_lo, text_off[i]); t_hi = std::max(t_hi, text_off[i] + text_len[i]); }
+        B->plp_off[i] = (int64_t)B->pl_p_words; B->pl_p_words += (size_t)3 * ((size_t)(pattern_len[i] + 63) / 64 + 2);
+        B->plt_off[i] = (int64_t)B->pl_t_words; B->pl_t_words += (size_t)3 * ((size_t)(text_len[i] + 63) / 64 + 2);
+    }
+    if (p_lo == INT64_MAX) { p_lo = 0; p_hi = 0; }
+    if (t_lo == INT64_MAX) { t_lo = 0; t_hi = 0; }
+    const bool p_dense = (size_t)(p_hi - p_lo) <= pb + pb / 4 + ((size_t)1 << 20);
+    const bool t_dense = (size_t)(t_hi - t_lo) <= tb + tb / 4 + ((size_t)1 << 20);
+    {
+        size_t po = 0, to = 0;
         for (int64_t i = 0; i < n; ++i) {
-            pb += (size_t)pattern_len[i]; tb += (size_t)text_len[i];
-            if (pattern_len[i]) { p_lo = std::min(p_lo, pattern_off[i]); p_hi = std::max(p_hi, pattern_off[i] + pattern_len[i]); }
-            if (text_len[i]) { t_lo = std::min(t_lo, text_off[i]); t_hi = std::max(t_hi, text_off[i] + text_len[i]); }
-            B->plp_off[i] = (int64_t)B->pl_p_words; B->pl_p_words += (size_t)3 * ((size_t)(pattern_len[i] + 63) / 64 + 2);
-            B->plt_off[i] = (int64_t)B->pl_t_words; B->pl_t_words += (size_t)3 * ((size_t)(text_len[i] + 63) / 64 + 2);
+            B->p_off[i] = p_dense ? pattern_off[i] - p_lo : (int64_t)po; po += (size_t)pattern_len[i];
+            B->t_off[i] = t_dense ? text_off[i] - t_lo : (int64_t)to; to += (size_t)text_len[i];
         }
-        if (p_lo == INT64_MAX) { p_lo = 0; p_hi = 0; }
-        if (t_lo == INT64_MAX) { t_lo = 0; t_hi = 0; }
-        const bool p_dense = (size_t)(p_hi - p_lo) <= pb + pb / 4 + ((size_t)1 << 20);
-        const bool t_dense = (size_t)(t_hi - t_lo) <= tb + tb / 4 + ((size_t)1 << 20);
-        {
-            size_t po = 0, to = 0;
-            for (int64_t i = 0; i < n; ++i) {
-                B->p_off[i] = p_dense ? pattern_off[i] - p_lo : (int64_t)po; po += (size_t)pattern_len[i];
-                B->t_off[i] = t_dense ? text_off[i] - t_lo : (int64_t)to; to += (size_t)text_len[i];
-            }
-        }
-        const size_t p_bytes = p_dense ? (size_t)(p_hi - p_lo) : pb, t_bytes = t_dense ? (size_t)(t_hi - t_lo) : tb;
-        B->order.resize((size_t)n);
-        std::iota(B->order.begin(), B->order.end(), 0);
+    }
+    const size_t p_bytes = p_dense ? (size_t)(p_hi - p_lo) : pb, t_bytes = t_dense ? (size_t)(t_hi - t_lo) : tb;
+    B->order.resize((size_t)n);
+    std::iota(B->order.begin(), B->order.end(), 0);
+    bool ragged = false;
+    for (int64_t i = 1; i < n && !ragged; ++i)
+        ragged = std::max(B->p_len[i], B->t_len[i]) > std::max(B->p_len[i - 1], B->t_len[i - 1]);
+    if (ragged)
         std::stable_sort(B->order.begin(), B->order.end(), [&](int a, int b) {
             const int la = std::max(B->p_len[a], B->t_len[a]), lb = std::max(B->p_len[b], B->t_len[b]);
             return la > lb;
         });
-        auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
-        B->arena_bytes = pad(p_bytes + 64) + pad(t_bytes + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
-                         2 * quicked_batch::NP * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + quicked_batch::NP * pad((size_t)n * 4) + 4096;
-        HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
-        qe::ArenaCarver A{B->arena, 0};
-        B->d_asc_p = A.take<uint8_t>(p_bytes + 64); B->d_asc_t = A.take<uint8_t>(t_bytes + 64);
-        B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
-        B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
-        B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
-        for (int q = 0; q < quicked_batch::NP; ++q) {
-            B->d_pl_p[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[q] = A.take<u64>(B->pl_t_words + 8);
-            B->d_pl_pr[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[q] = A.take<u64>(B->pl_t_words + 8);
-            B->d_flags[q] = A.take<u32>((size_t)n);
-            HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
-        }
-        auto send = [&](uint8_t* dst, const char* pool, const int64_t* off, const int32_t* len, const std::vector<int64_t>& doff,
-                        bool dense, int64_t lo, size_t bytes) {
-            if (dense) { upload_span(dst, (const uint8_t*)pool + lo, bytes, C.device); return; }
-            std::vector<uint8_t> h(bytes + 64, 0);
-            for (int64_t i = 0; i < n; ++i) if (len[i]) memcpy(h.data() + doff[(size_t)i], pool + off[i], (size_t)len[i]);
-            upload_span(dst, h.data(), bytes, C.device);
-        };
-        send(B->d_asc_p, pattern_pool, pattern_off, pattern_len, B->p_off, p_dense, p_lo, p_bytes);
-        send(B->d_asc_t, text_pool, text_off, text_len, B->t_off, t_dense, t_lo, t_bytes);
-        h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
-        h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
-        h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
-        HIP_CHECK(hipStreamSynchronize(C.stream));
+    auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    const size_t need = pad(p_bytes + 64) + pad(t_bytes + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
+                        2 * quicked_batch::NP * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + quicked_batch::NP * pad((size_t)n * 4) + 4096;
+    batch_arena(B, need);
+    qe::ArenaCarver A{B->arena, 0};
+    B->d_asc_p = A.take<uint8_t>(p_bytes + 64); B->d_asc_t = A.take<uint8_t>(t_bytes + 64);
+    B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
+    B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
+    B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
+    for (int q = 0; q < quicked_batch::NP; ++q) {
+        B->d_pl_p[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[q] = A.take<u64>(B->pl_t_words + 8);
+        B->d_pl_pr[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[q] = A.take<u64>(B->pl_t_words + 8);
+        B->d_flags[q] = A.take<u32>((size_t)n);
+        if (!B->ev_done[q]) HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
+    }
+    auto send = [&](uint8_t* dst, const char* pool, const int64_t* off, const int32_t* len, const std::vector<int64_t>& doff,
+                    bool dense, int64_t lo, size_t bytes) {
+        if (dense) { upload_span(dst, (const uint8_t*)pool + lo, bytes, C.device); return; }
+        std::vector<uint8_t> h(bytes + 64, 0);
+        for (int64_t i = 0; i < n; ++i) if (len[i]) memcpy(h.data() + doff[(size_t)i], pool + off[i], (size_t)len[i]);
+        upload_span(dst, h.data(), bytes, C.device);
+    };
+    send(B->d_asc_p, pattern_pool, pattern_off, pattern_len, B->p_off, p_dense, p_lo, p_bytes);
+    send(B->d_asc_t, text_pool, text_off, text_len, B->t_off, t_dense, t_lo, t_bytes);
+    h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
+    h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
+    h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+}
+
+// every run of the batch that is still on the device (queued by any thread) is over
+static void batch_quiesce(quicked_batch* B) {
+    for (int q = 0; q < quicked_batch::NP; ++q)
+        if (B->ev_done[q] && B->ev_done_set[q]) HIP_CHECK(hipEventSynchronize(B->ev_done[q]));
+}
+}  // namespace qe
+
+static quicked_batch* guarded_new(const std::function<void(quicked_batch*)>& load) {
+    quicked_batch* B = nullptr;
+    try {
+        B = new quicked_batch();
+        load(B);
         return B;
     } catch (const HipError& e) {
         fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
-        delete B;
-        return nullptr;
+    } catch (const std::bad_alloc&) {
+        fprintf(stderr, "[quicked_hip] out of host memory\n");
     }
+    delete B;
+    return nullptr;
+}
+
+QE_API quicked_batch_t* quicked_batch_create(int64_t n,
+                                             const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
+                                             const char* text_pool, const int64_t* text_off, const int32_t* text_len) {
+    if (n < 0) return nullptr;
+    return guarded_new([&](quicked_batch* B) {
+        batch_load(B, ctx(), n, pattern_pool, pattern_off, pattern_len, text_pool, text_off, text_len);
+    });
+}
+
+QE_API quicked_status_t quicked_batch_reload(quicked_batch_t* batch, int64_t n,
+                                             const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
+                                             const char* text_pool, const int64_t* text_off, const int32_t* text_len) {
+    if (!batch || n < 0) return QUICKED_ERROR;
+    struct Arg { int64_t n; const char* pp; const int64_t* po; const int32_t* pl; const char* tp; const int64_t* to; const int32_t* tl; }
+        arg{n, pattern_pool, pattern_off, pattern_len, text_pool, text_off, text_len};
+    return guard(batch, [](quicked_batch* B, void* a) {
+        Arg* x = (Arg*)a;
+        tl_device = B->device;
+        Context& C = ctx();
+        batch_quiesce(B);
+        batch_load(B, C, x->n, x->pp, x->po, x->pl, x->tp, x->to, x->tl);
+        return QUICKED_OK;
+    }, &arg);
 }
 
 // ---- packed wire format (supersedes sequence_buffer_t, sequence_buffer.h:30-50) ----------------
@@ -1429,80 +1612,114 @@ QE_API quicked_status_t quicked_wire_pack(const char* seq, int32_t len, int wire
     return QUICKED_OK;
 }
 
-QE_API quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
-                                                    const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
-                                                    const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len) {
-    if (wire != QUICKED_WIRE_2BIT && wire != QUICKED_WIRE_PLANES3) return nullptr;
-    quicked_batch* B = new quicked_batch();
-    try {
-        Context& C = ctx();
-        B->n = n; B->device = C.device; B->packed = true;
-        B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
-        B->p_off.assign((size_t)n, 0); B->t_off.assign((size_t)n, 0);
-        B->plp_off.resize((size_t)n); B->plt_off.resize((size_t)n);
-        // the wire pools are uploaded as the word spans they are
-        int64_t p_lo = INT64_MAX, p_hi = 0, t_lo = INT64_MAX, t_hi = 0;
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t pw = quicked_wire_words(pattern_len[i], wire), tw = quicked_wire_words(text_len[i], wire);
-            if (pw > 0) { p_lo = std::min(p_lo, pattern_word_off[i]); p_hi = std::max(p_hi, pattern_word_off[i] + pw); }
-            if (tw > 0) { t_lo = std::min(t_lo, text_word_off[i]); t_hi = std::max(t_hi, text_word_off[i] + tw); }
-            B->plp_off[i] = (int64_t)B->pl_p_words; B->pl_p_words += (size_t)3 * ((size_t)(pattern_len[i] + 63) / 64 + 2);
-            B->plt_off[i] = (int64_t)B->pl_t_words; B->pl_t_words += (size_t)3 * ((size_t)(text_len[i] + 63) / 64 + 2);
-        }
-        if (p_lo == INT64_MAX) { p_lo = 0; p_hi = 0; }
-        if (t_lo == INT64_MAX) { t_lo = 0; t_hi = 0; }
-        const size_t pw_total = (size_t)(p_hi - p_lo), tw_total = (size_t)(t_hi - t_lo);
-        std::vector<int64_t> pwo((size_t)n), two((size_t)n);
-        for (int64_t i = 0; i < n; ++i) { pwo[(size_t)i] = pattern_word_off[i] - p_lo; two[(size_t)i] = text_word_off[i] - t_lo; }
-        B->order.resize((size_t)n);
-        std::iota(B->order.begin(), B->order.end(), 0);
+namespace qe {
+static void batch_load_packed(quicked_batch* B, Context& C, int64_t n, int wire,
+                              const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
+                              const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len) {
+    batch_reset_state(B);
+    B->n = n; B->device = C.device; B->packed = true; B->wire = wire;
+    B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
+    B->p_off.assign((size_t)n, 0); B->t_off.assign((size_t)n, 0);
+    B->plp_off.resize((size_t)n); B->plt_off.resize((size_t)n);
+    // the wire pools are uploaded as the word spans they are
+    int64_t p_lo = INT64_MAX, p_hi = 0, t_lo = INT64_MAX, t_hi = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t pw = quicked_wire_words(pattern_len[i], wire), tw = quicked_wire_words(text_len[i], wire);
+        if (pw > 0) { p_lo = std::min(p_lo, pattern_word_off[i]); p_hi = std::max(p_hi, pattern_word_off[i] + pw); }
+        if (tw > 0) { t_lo = std::min(t_lo, text_word_off[i]); t_hi = std::max(t_hi, text_word_off[i] + tw); }
+        B->plp_off[i] = (int64_t)B->pl_p_words; B->pl_p_words += (size_t)3 * ((size_t)(pattern_len[i] + 63) / 64 + 2);
+        B->plt_off[i] = (int64_t)B->pl_t_words; B->pl_t_words += (size_t)3 * ((size_t)(text_len[i] + 63) / 64 + 2);
+    }
+    if (p_lo == INT64_MAX) { p_lo = 0; p_hi = 0; }
+    if (t_lo == INT64_MAX) { t_lo = 0; t_hi = 0; }
+    const size_t pw_total = (size_t)(p_hi - p_lo), tw_total = (size_t)(t_hi - t_lo);
+    std::vector<int64_t> pwo((size_t)n), two((size_t)n);
+    for (int64_t i = 0; i < n; ++i) { pwo[(size_t)i] = pattern_word_off[i] - p_lo; two[(size_t)i] = text_word_off[i] - t_lo; }
+    B->order.resize((size_t)n);
+    std::iota(B->order.begin(), B->order.end(), 0);
+    bool ragged = false;
+    for (int64_t i = 1; i < n && !ragged; ++i)
+        ragged = std::max(B->p_len[i], B->t_len[i]) > std::max(B->p_len[i - 1], B->t_len[i - 1]);
+    if (ragged)
         std::stable_sort(B->order.begin(), B->order.end(), [&](int a, int b) {
             return std::max(B->p_len[a], B->t_len[a]) > std::max(B->p_len[b], B->t_len[b]);
         });
-        auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
-        B->arena_bytes = pad((pw_total + 8) * 8) + pad((tw_total + 8) * 8) + 6 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
-                         2 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + pad((size_t)n * 4) + 4096;
-        HIP_CHECK(hipMalloc((void**)&B->arena, B->arena_bytes));
-        qe::ArenaCarver A{B->arena, 0};
-        u64* d_pw = A.take<u64>(pw_total + 8); u64* d_tw = A.take<u64>(tw_total + 8);
-        int64_t* d_pwo = A.take<int64_t>((size_t)n); int64_t* d_two = A.take<int64_t>((size_t)n);
-        B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
-        B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
-        B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
-        B->d_pl_p[0] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[0] = A.take<u64>(B->pl_t_words + 8);
-        B->d_pl_pr[0] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[0] = A.take<u64>(B->pl_t_words + 8);
-        B->d_flags[0] = A.take<u32>((size_t)n);
-        for (int q = 0; q < quicked_batch::NP; ++q) {          // every set is the same resident planes
-            B->d_pl_p[q] = B->d_pl_p[0]; B->d_pl_t[q] = B->d_pl_t[0]; B->d_pl_pr[q] = B->d_pl_pr[0]; B->d_pl_tr[q] = B->d_pl_tr[0];
-            B->d_flags[q] = B->d_flags[0];
-            HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
-        }
-        if (pw_total) upload_span((uint8_t*)d_pw, (const uint8_t*)(pattern_words + p_lo), pw_total * 8, C.device);
-        if (tw_total) upload_span((uint8_t*)d_tw, (const uint8_t*)(text_words + t_lo), tw_total * 8, C.device);
-        h2d(d_pwo, pwo, C.stream); h2d(d_two, two, C.stream);
-        h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
-        h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
-        h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
-        HIP_CHECK(hipMemsetAsync(B->d_flags[0], 0, (size_t)n * sizeof(u32), C.stream));
-        const int blocks = (int)((n + 3) / 4);
+    auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    const size_t need = pad((pw_total + 8) * 8) + pad((tw_total + 8) * 8) + 6 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
+                        2 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + pad((size_t)n * 4) + 4096;
+    batch_arena(B, need);
+    qe::ArenaCarver A{B->arena, 0};
+    u64* d_pw = A.take<u64>(pw_total + 8); u64* d_tw = A.take<u64>(tw_total + 8);
+    int64_t* d_pwo = A.take<int64_t>((size_t)n); int64_t* d_two = A.take<int64_t>((size_t)n);
+    B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
+    B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
+    B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
+    B->d_pl_p[0] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[0] = A.take<u64>(B->pl_t_words + 8);
+    B->d_pl_pr[0] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[0] = A.take<u64>(B->pl_t_words + 8);
+    B->d_flags[0] = A.take<u32>((size_t)n);
+    B->d_asc_p = nullptr; B->d_asc_t = nullptr;
+    for (int q = 0; q < quicked_batch::NP; ++q) {          // every set is the same resident planes
+        B->d_pl_p[q] = B->d_pl_p[0]; B->d_pl_t[q] = B->d_pl_t[0]; B->d_pl_pr[q] = B->d_pl_pr[0]; B->d_pl_tr[q] = B->d_pl_tr[0];
+        B->d_flags[q] = B->d_flags[0];
+        if (!B->ev_done[q]) HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
+    }
+    if (pw_total) upload_span((uint8_t*)d_pw, (const uint8_t*)(pattern_words + p_lo), pw_total * 8, C.device);
+    if (tw_total) upload_span((uint8_t*)d_tw, (const uint8_t*)(text_words + t_lo), tw_total * 8, C.device);
+    h2d(d_pwo, pwo, C.stream); h2d(d_two, two, C.stream);
+    h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
+    h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
+    h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
+    HIP_CHECK(hipMemsetAsync(B->d_flags[0], 0, (size_t)n * sizeof(u32), C.stream));
+    const int blocks = (int)((n + 3) / 4);
+    if (n > 0) {
         WireArgs w;
         w.nseq = (int32_t)n; w.wire = wire; w.flags = B->d_flags[0];
         w.words = d_pw; w.w_off = d_pwo; w.len = B->d_p_len; w.planes = B->d_pl_p[0]; w.pl_off = B->d_plp_off;
         hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
         w.words = d_tw; w.w_off = d_two; w.len = B->d_t_len; w.planes = B->d_pl_t[0]; w.pl_off = B->d_plt_off;
         hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
-        HIP_CHECK(hipStreamSynchronize(C.stream));
-        return B;
-    } catch (const HipError& e) {
-        fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
-        delete B;
-        return nullptr;
     }
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+}
+}  // namespace qe
+
+QE_API quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
+                                                    const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
+                                                    const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len) {
+    if (n < 0 || (wire != QUICKED_WIRE_2BIT && wire != QUICKED_WIRE_PLANES3)) return nullptr;
+    return guarded_new([&](quicked_batch* B) {
+        batch_load_packed(B, ctx(), n, wire, pattern_words, pattern_word_off, pattern_len, text_words, text_word_off, text_len);
+    });
+}
+
+QE_API quicked_status_t quicked_batch_reload_packed(quicked_batch_t* batch, int64_t n, int wire,
+                                                    const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
+                                                    const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len) {
+    if (!batch || n < 0 || (wire != QUICKED_WIRE_2BIT && wire != QUICKED_WIRE_PLANES3)) return QUICKED_ERROR;
+    struct Arg { int64_t n; int wire; const uint64_t* pw; const int64_t* po; const int32_t* pl; const uint64_t* tw; const int64_t* to; const int32_t* tl; }
+        arg{n, wire, pattern_words, pattern_word_off, pattern_len, text_words, text_word_off, text_len};
+    return guard(batch, [](quicked_batch* B, void* a) {
+        Arg* x = (Arg*)a;
+        tl_device = B->device;
+        Context& C = ctx();
+        batch_quiesce(B);
+        batch_load_packed(B, C, x->n, x->wire, x->pw, x->po, x->pl, x->tw, x->to, x->tl);
+        return QUICKED_OK;
+    }, &arg);
+}
+
+QE_API quicked_status_t quicked_batch_fetch(quicked_batch_t* batch) {
+    if (!batch) return QUICKED_ERROR;
+    return guard(batch, [](quicked_batch* B, void*) { return fetch_pending(*B); }, nullptr);
 }
 
 QE_API void quicked_batch_destroy(quicked_batch_t* batch) {
     if (!batch) return;
-    (void)hipDeviceSynchronize();
+    try {
+        tl_device = batch->device;
+        (void)ctx();                           // binds the batch's device to this thread
+        batch_quiesce(batch);                  // runs queued by any thread; hipFree then synchronises the device itself
+    } catch (const HipError&) { (void)hipGetLastError(); }
     delete batch;
 }
 
@@ -1669,9 +1886,35 @@ struct AlignerState {
     profiler_timer_t timers[5];
     std::vector<char*> batch_cigars;
     std::vector<char> batch_pool;
+    std::vector<char*> strings;           // every CIGAR quicked_align handed out: valid until quicked_free (quicked.c:48-50, 357-361)
     uint32_t magic;
 };
 static const uint32_t QE_MAGIC = 0x51CEDA11u;
+// the same list for aligners that were given an external allocator (no AlignerState to hang it on)
+static std::mutex g_strings_mu;
+static std::unordered_map<const quicked_aligner_t*, std::vector<char*>> g_strings;
+static AlignerState* own_state(const quicked_aligner_t* aligner) {
+    if (aligner->mm_allocator == nullptr || aligner->params->external_allocator != nullptr) return nullptr;
+    AlignerState* st = (AlignerState*)aligner->mm_allocator;
+    return st->magic == QE_MAGIC ? st : nullptr;
+}
+static void keep_string(quicked_aligner_t* aligner, char* str) {
+    if (AlignerState* st = own_state(aligner)) { st->strings.push_back(str); return; }
+    std::lock_guard<std::mutex> lk(g_strings_mu);
+    g_strings[aligner].push_back(str);
+}
+static void drop_strings(quicked_aligner_t* aligner) {
+    bool listed = false;
+    auto drop = [&](std::vector<char*>& v) { for (char* q : v) { listed |= q == aligner->cigar; free(q); } v.clear(); };
+    if (AlignerState* st = own_state(aligner)) drop(st->strings);
+    {
+        std::lock_guard<std::mutex> lk(g_strings_mu);
+        auto it = g_strings.find(aligner);
+        if (it != g_strings.end()) { drop(it->second); g_strings.erase(it); }
+    }
+    if (aligner->cigar != nullptr && !listed) free(aligner->cigar);
+    aligner->cigar = nullptr;
+}
 
 QE_API quicked_status_t quicked_new(quicked_aligner_t* aligner, quicked_params_t* params) {    // quicked.c:323-352
     aligner->params = params;
@@ -1699,7 +1942,7 @@ QE_API quicked_status_t quicked_new(quicked_aligner_t* aligner, quicked_params_t
 }
 
 QE_API quicked_status_t quicked_free(quicked_aligner_t* aligner) {                             // quicked.c:354-378
-    if (aligner->cigar != nullptr) { free(aligner->cigar); aligner->cigar = nullptr; }
+    drop_strings(aligner);                 // every string quicked_align returned stays valid until here, as in the reference
     const bool own = aligner->mm_allocator != nullptr && aligner->params->external_allocator == nullptr;
     if (!aligner->params->external_timer && !own) free(aligner->timer);       // calloc'ed block of five
     if (own) {
@@ -1723,7 +1966,19 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
         if (tlens[i]) memcpy(tp.data() + to[i], texts[i], (size_t)tlens[i]);
     }
     double tr_last = now_ms();
-    quicked_batch_t* B = quicked_batch_create(n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data());
+    // small calls (quicked_align, small quicked_align_batch) reuse one batch object per thread and device: no hipMalloc /
+    // hipFree (a device-wide synchronisation) per call
+    static thread_local quicked_batch* tl_small = nullptr;
+    const bool small = pb + tb <= ((size_t)8 << 20);
+    quicked_batch_t* B = nullptr;
+    if (small) {
+        if (tl_small && tl_small->device != tl_device) { quicked_batch_destroy(tl_small); tl_small = nullptr; }
+        if (!tl_small) tl_small = quicked_batch_create(n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data());
+        else if (quicked_batch_reload(tl_small, n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data()) < 0) {
+            quicked_batch_destroy(tl_small); tl_small = nullptr;
+        }
+        B = tl_small;
+    } else B = quicked_batch_create(n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data());
     if (!B) return QUICKED_ERROR;
     QE_TRACE_POINT("align_pairs: create");
     const quicked_params_t* p = aligner->params;
@@ -1749,7 +2004,7 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
         for (int i = 0; i < n; ++i)
             cigars_out[i] = (B->cigar_off[(size_t)i] >= 0 && !p->only_score) ? pool_keep->data() + B->cigar_off[(size_t)i] : nullptr;
     }
-    quicked_batch_destroy(B);
+    if (!small) quicked_batch_destroy(B);
     QE_TRACE_POINT("align_pairs: destroy");
     if (any_err) return first_err;
     return st;
@@ -1768,10 +2023,12 @@ QE_API quicked_status_t quicked_align(quicked_aligner_t* aligner, const char* pa
     if (st < 0) return st;
     aligner->score = score;
     if (!aligner->params->only_score && cg) {
-        // a previous align's string stays valid until quicked_free in the reference (arena leak, quicked.c:48-50);
-        // here the previous one is released when it is replaced.
-        if (aligner->cigar) free(aligner->cigar);
-        aligner->cigar = strdup(cg);
+        // a previous align's string stays valid until quicked_free, as in the reference (arena allocation that the
+        // next align does not release, quicked.c:48-50, 357-361)
+        char* dup = strdup(cg);
+        if (!dup) return QUICKED_ERROR;
+        keep_string(aligner, dup);
+        aligner->cigar = dup;
     }
     return st;
 }
