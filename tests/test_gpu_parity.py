@@ -642,3 +642,165 @@ def test_concurrent_host_threads_one_aligner_each():
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+def test_async_run_fetch_and_reload():
+    """sync == 0 leaves the getters' data alone; quicked_batch_fetch brings exactly that run's results (scores,
+    statuses, CIGARs, counters); quicked_batch_reload puts other pairs (other n, other lengths) into the same object"""
+    ba = datagen.generate(count=200, length=1200, error=0.06, seed=721)
+    bb = datagen.generate(count=90, length=2100, error=0.09, seed=722)
+    bc = datagen.generate(count=333, length=600, error=0.04, seed=723)
+    rb = capi.ResidentBatch(ba)
+    p_so = capi.make_params(algo=capi.BANDED, only_score=True, bandwidth=15)
+    p_q = capi.make_params(algo=capi.QUICKED)
+    p_w = capi.make_params(algo=capi.WINDOWED, window_size=2)
+    assert rb.run(p_q, sync=True) >= 0
+    s0, st0 = rb.scores()
+    c0 = rb.cigars()
+    assert rb.run(p_so, sync=False) >= 0
+    s1, st1 = rb.scores()
+    assert (s1 == s0).all() and (st1 == st0).all() and rb.cigars() == c0          # untouched by the async run
+    assert rb.fetch() >= 0
+    s1, st1 = rb.scores()
+    cnt = rb.counters()
+    for i, (p, t) in enumerate(ba.pairs()):
+        st, s, _ = O.oracle_align(p, t, algo=2, only_score=True, bandwidth=15)
+        assert (st1[i], s1[i]) == (st, s), i
+    assert cnt[0] > 0                                                             # block-advances of the fetched run
+    # two async runs in flight (the documented limit), fetched in order
+    for prm, algo_kw in ((p_q, dict(algo=0)), (p_w, dict(algo=1, window_size=2))):
+        assert rb.run(prm, sync=False) >= 0
+        assert rb.fetch() >= 0
+        s, st = rb.scores()
+        cg = rb.cigars()
+        for i, (p, t) in enumerate(ba.pairs()):
+            assert (st[i], s[i], cg[i]) == O.oracle_align(p, t, **algo_kw), (algo_kw, i)
+    # reload: fewer, longer pairs, then more, shorter ones
+    for nb in (bb, bc):
+        assert rb.reload(nb) >= 0
+        assert rb.run(p_q, sync=False) >= 0
+        assert rb.fetch() >= 0
+        s, st = rb.scores()
+        cg = rb.cigars()
+        assert len(s) == len(nb)
+        for i, (p, t) in enumerate(nb.pairs()):
+            assert (st[i], s[i], cg[i]) == O.oracle_align(p, t, algo=0), i
+    # a fetch with nothing pending is a no-op, not an error
+    assert rb.fetch() >= 0
+    rb.close()
+
+
+def test_streaming_reload_from_an_uploader_thread():
+    """bench.py's end-to-end pattern: an uploader thread reloads batch objects while the main thread runs and fetches
+    the others (ASCII and 2-bit input)"""
+    import threading
+    sets = [datagen.generate(count=256, length=900, error=0.05, seed=800 + k) for k in range(6)]
+    expect = [[O.oracle_align(p, t, algo=2, only_score=True)[1] for p, t in b.pairs()] for b in sets]
+    prm = capi.make_params(algo=capi.BANDED, only_score=True)
+    for wire in (None, capi.WIRE_2BIT):
+        slots = 3
+        words = None
+        if wire is None:
+            rbs = [capi.ResidentBatch(sets[0]) for _ in range(slots)]
+        else:
+            words = [capi.wire_pack_pool(b.pattern_pool, b.pattern_off, b.pattern_len, wire) +
+                     capi.wire_pack_pool(b.text_pool, b.text_off, b.text_len, wire) for b in sets]
+            rbs = [capi.ResidentBatch.from_wire(sets[0], wire, *words[0]) for _ in range(slots)]
+        up = [threading.Event() for _ in sets]
+        done = [threading.Event() for _ in sets]
+        errs = []
+
+        def uploader():
+            try:
+                for k, b in enumerate(sets):
+                    if k >= slots:
+                        done[k - slots].wait()
+                    st = rbs[k % slots].reload(b) if wire is None else rbs[k % slots].reload_wire(b, wire, *words[k])
+                    assert st >= 0
+                    up[k].set()
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+                for ev in up:
+                    ev.set()
+
+        th = threading.Thread(target=uploader)
+        th.start()
+        got = {}
+
+        def finish(k):
+            assert rbs[k % slots].fetch() >= 0
+            got[k] = rbs[k % slots].scores()[0].tolist()
+            done[k].set()
+
+        for k in range(len(sets)):
+            up[k].wait()
+            assert not errs, errs
+            assert rbs[k % slots].run(prm, sync=False) >= 0
+            if k >= 1:
+                finish(k - 1)
+        finish(len(sets) - 1)
+        th.join()
+        for k in range(len(sets)):
+            assert got[k] == expect[k], (wire, k)
+        for rb in rbs:
+            rb.close()
+
+
+def test_cigar_strings_stay_valid_until_free():
+    """quicked.c:48-50, 357-361: every string quicked_align returned is owned by the aligner until quicked_free"""
+    import ctypes as C
+    lib = capi.lib()
+    pairs = list(datagen.generate(count=6, length=300, error=0.08, seed=909).pairs())
+    for external in (False, True):
+        prm = capi.make_params(algo=capi.QUICKED)
+        alloc = capi.MMAllocator()
+        if external:
+            prm.external_allocator = C.pointer(alloc)
+        a = capi.Aligner()
+        assert lib.quicked_new(C.byref(a), C.byref(prm)) == capi.QUICKED_WIP
+        kept = []
+        for p, t in pairs:
+            assert lib.quicked_align(C.byref(a), p, len(p), t, len(t)) == capi.QUICKED_WIP
+            kept.append(C.c_void_p.from_buffer(a, capi.Aligner.cigar.offset).value)
+        assert len(set(kept)) == len(kept)
+        for addr, (p, t) in zip(kept, pairs):
+            assert C.string_at(addr).decode() == O.oracle_align(p, t, algo=0)[2]
+        assert lib.quicked_free(C.byref(a)) == capi.QUICKED_WIP
+        assert not a.cigar
+
+
+def test_timers_gain_one_sample_per_align(golden):
+    """the five ABI timers (quicked.h:61-66) are ticked around the stages the reference brackets
+    (quicked.c:184-193, 204-235, 240-275, 283-294), with internal timers and with external_timer = true and the
+    caller's timers patched in after quicked_new (benchmark_edit.c:61-65)"""
+    import ctypes as C
+    lib = capi.lib()
+    plain = list(datagen.generate(count=3, length=800, error=0.05, seed=31).pairs())
+    heavy = list(datagen.generate(**golden["datasets"]["indel_10kb"]["gen"]).pairs())
+    runs = golden["datasets"]["indel_10kb"]["runs"]
+    for external in (False, True):
+        prm = capi.make_params(algo=capi.QUICKED, external_timer=external)
+        a = capi.Aligner()
+        assert lib.quicked_new(C.byref(a), C.byref(prm)) == capi.QUICKED_WIP
+        mine = [capi.ProfilerTimer() for _ in range(5)]
+        if external:
+            assert not a.timer and not a.timer_align
+            for t in mine:
+                C.memset(C.byref(t), 0, C.sizeof(t))
+            a.timer, a.timer_windowed_s, a.timer_windowed_l, a.timer_banded, a.timer_align = [C.pointer(t) for t in mine]
+        tm = lambda: [x.contents.time_ns.samples for x in (a.timer, a.timer_windowed_s, a.timer_windowed_l, a.timer_banded, a.timer_align)]   # noqa: E731
+        for k, (p, t) in enumerate(plain):
+            assert lib.quicked_align(C.byref(a), p, len(p), t, len(t)) == capi.QUICKED_WIP
+            assert tm() == [k + 1, k + 1, 0, 0, k + 1]
+        # pairs with large indels go through WindowEd(L) and, some of them, through the band-doubling stage
+        n0 = len(plain)
+        l_seen = b_seen = 0
+        for k, (p, t) in enumerate(heavy[:8]):
+            assert lib.quicked_align(C.byref(a), p, len(p), t, len(t)) == capi.QUICKED_WIP
+            s = tm()
+            assert s[0] == n0 + k + 1 and s[1] == n0 + k + 1 and s[4] == n0 + k + 1
+            assert s[2] in (l_seen, l_seen + 1) and s[3] >= b_seen
+            l_seen, b_seen = s[2], s[3]
+        assert l_seen > 0 and b_seen > 0, (l_seen, b_seen, list(runs))
+        assert a.timer.contents.time_ns.total > 0
+        lib.quicked_free(C.byref(a))

@@ -1,35 +1,37 @@
 #!/bin/bash
 # Collects what profiles/ holds for one milestone (run on the GPU box through gpurun):
-#   tools/collect_profiles.sh <tag>       -> gpurun_out/<tag>/...
-# kernel-trace/stats and each PMC counter in separate passes, as MI355X_MICROARCH.md prescribes.
-tag=${1:-r01_x}
+#   tools/collect_profiles.sh <tag> [banded_score quicked cfg4]   -> gpurun_out/<tag>/...
+# kernel-trace/stats and every PMC counter set in separate passes, as MI355X_MICROARCH.md prescribes.
+tag=${1:-r02_x}; shift
+wls=${@:-banded_score quicked cfg4}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; mkdir -p $out
-for wl in banded_score quicked; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -- python3 bench.py --workload $wl --no-cpu-baseline --steps 10 --warmup 2 > $out/stats_$wl.log 2>&1
-  cp $out/stats_$wl/*/*kernel_stats.csv $out/${tag}_${wl}_100k_kernel_stats.csv
+for wl in $wls; do
+  case $wl in
+    banded_score) args="--workload banded_score"; steps=10;;
+    quicked)      args="--workload quicked"; steps=10;;
+    cfg4)         args="--workload quicked --pairs 10000 --length 100000 --error 0.1"; steps=3;;
+  esac
+  common="$args --no-cpu-baseline --no-e2e"
+  # overlapped (as benchmarked) and solo (--sync-each-step: a kernel's own duration) kernel stats
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -- python3 bench.py $common --steps $steps --warmup 2 > $out/stats_$wl.log 2>&1
+  cp $out/stats_$wl/*/*kernel_stats.csv $out/${tag}_${wl}_kernel_stats.csv
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/solo_$wl -- python3 bench.py $common --steps $steps --warmup 2 --sync-each-step > $out/solo_$wl.log 2>&1
+  cp $out/solo_$wl/*/*kernel_stats.csv $out/${tag}_${wl}_solo_kernel_stats.csv
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 bench.py --workload $wl --no-cpu-baseline --steps 1 --warmup 0 > $out/pmc_${wl}_$c.log 2>&1
+    rocprofv3 --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 bench.py $common --steps 1 --warmup 0 --sync-each-step > $out/pmc_${wl}_$c.log 2>&1
     cp $out/pmc_${wl}_$c/*/*counter_collection.csv $out/${tag}_${wl}_pmc_$c.csv
   done
-  python3 bench.py --workload $wl > $out/${tag}_bench_$wl.json 2> $out/bench_$wl.err
+  python3 bench.py $args --steps $steps > $out/${tag}_bench_$wl.json 2> $out/bench_$wl.err
 done
-./tools/bin/valu_rate > $out/${tag}_valu_rates.txt 2>&1
-python3 - <<PY
-import csv, glob, json, collections
-out = {}
-for wl in ("banded_score", "quicked"):
-    d = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        for r in csv.DictReader(open(f"$out/${tag}_%s_pmc_%s.csv" % (wl, c))):
-            k = r["Kernel_Name"]
-            if "qe::" not in k: continue
-            k = k.replace("void ", "").replace("qe::", "").split("(")[0]
-            d[k][c] += float(r["Counter_Value"]); n[(k, c)].add(r["Dispatch_Id"])
-    out[wl] = {}
-    for k, v in d.items():
-        f = v["FETCH_SIZE"] / max(len(n[(k, "FETCH_SIZE")]), 1); w = v["WRITE_SIZE"] / max(len(n[(k, "WRITE_SIZE")]), 1)
-        out[wl][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes": (2 * f + w) * 1024, "launches": len(n[(k, "FETCH_SIZE")])}
-json.dump(out, open("$out/${tag}_pmc_traffic_raw.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
-PY
+# SQ / GRBM counters of the BandEd score kernel alone (one pass per slot budget: 8 SQ, 2 GRBM)
+if [[ " $wls " == *" banded_score "* ]]; then
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_sq1 -- python3 bench.py --no-cpu-baseline --no-e2e --steps 1 --warmup 0 --sync-each-step > $out/pmc_sq1.log 2>&1
+  cp $out/pmc_sq1/*/*counter_collection.csv $out/${tag}_banded_score_pmc_sq1.csv
+  rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --output-format csv -d $out/pmc_sq2 -- python3 bench.py --no-cpu-baseline --no-e2e --steps 1 --warmup 0 --sync-each-step > $out/pmc_sq2.log 2>&1
+  cp $out/pmc_sq2/*/*counter_collection.csv $out/${tag}_banded_score_pmc_sq2.csv
+  rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $out/pmc_grbm -- python3 bench.py --no-cpu-baseline --no-e2e --steps 1 --warmup 0 --sync-each-step > $out/pmc_grbm.log 2>&1
+  cp $out/pmc_grbm/*/*counter_collection.csv $out/${tag}_banded_score_pmc_grbm.csv
+fi
+./tools/bin/valu_rate AB > $out/${tag}_valu_rates.txt 2>&1
+python3 tools/summarise_pmc.py $out $tag $wls

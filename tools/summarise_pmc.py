@@ -1,0 +1,57 @@
+"""Folds the rocprofv3 counter CSVs of tools/collect_profiles.sh into one JSON per milestone:
+per workload and kernel the average per-launch FETCH_SIZE / WRITE_SIZE (KiB, as rocprofv3 reports them) and the HBM
+byte estimate; SQ / GRBM counters of the BandEd score kernel when collected.
+FETCH_SIZE on gfx950 counts 64 B per 128-B request for wide streaming reads (MI355X_MICROARCH.md, HBM): the guide's x2
+correction applies to 16 B/lane loads; `fetch_factor` says which factor each kernel's figure uses (tools/pmc_calib.hip
+calibrates the 8 B/lane row pattern of the BandEd kernels)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+wls = sys.argv[3:] or ["banded_score", "quicked", "cfg4"]
+
+
+def rows(path):
+    if not os.path.exists(path):
+        return []
+    with open(path) as f:
+        return list(csv.DictReader(f))
+
+
+def short(k):
+    return k.replace("void ", "").replace("qe::", "").split("(")[0]
+
+
+res = {}
+for wl in wls:
+    d = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(set)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for r in rows(f"{out}/{tag}_{wl}_pmc_{c}.csv"):
+            k = r["Kernel_Name"]
+            if "qe::" not in k:
+                continue
+            k = short(k)
+            d[k][c] += float(r["Counter_Value"])
+            n[(k, c)].add(r["Dispatch_Id"])
+    res[wl] = {}
+    for k, v in d.items():
+        f = v["FETCH_SIZE"] / max(len(n[(k, "FETCH_SIZE")]), 1)
+        w = v["WRITE_SIZE"] / max(len(n[(k, "WRITE_SIZE")]), 1)
+        factor = float(os.environ.get("QE_FETCH_FACTOR", "2.0"))
+        res[wl][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_factor": factor,
+                      "hbm_bytes": (factor * f + w) * 1024, "launches": len(n[(k, "FETCH_SIZE")])}
+sq = {}
+for part in ("sq1", "sq2", "grbm"):
+    for r in rows(f"{out}/{tag}_banded_score_pmc_{part}.csv"):
+        if "k_banded" not in r["Kernel_Name"]:
+            continue
+        sq[r["Counter_Name"]] = sq.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+if sq:
+    res["banded_score_sq"] = sq
+with open(f"{out}/{tag}_pmc_summary.json", "w") as f:
+    json.dump(res, f, indent=1)
+print(json.dumps(res, indent=1))

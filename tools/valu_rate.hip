@@ -1,337 +1,270 @@
-// valu_rate.hip -- measures the issue rate of the integer VALU ops the block step is made of
-// (one gfx950 chip, every SIMD loaded with 8 waves).  Prints lane-ops/s per instruction kind.
-//   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o valu_rate && ./valu_rate
+// valu_rate.hip -- what the VALU of one gfx950 chip really issues, measured in SHADER CYCLES (s_memtime), so that the
+// figures do not depend on the clock the chip happens to hold under load; the clock itself is reported next to them
+// (delta s_memtime / delta s_memrealtime x 100 MHz).
+//
+// Part A  per-instruction issue cost: every instruction is asm volatile (nothing can be folded), the stream consists of
+//         D independent dependency chains (D = 1, 2, 4, 8: instruction i depends on instruction i - D), and exactly
+//         w waves sit on every SIMD (w = 1, 2, 4, 8; 4-wave workgroups, LDS-pinned so that w of them share a CU).
+//         Reported: cycles per instruction as one wave sees it, and per SIMD (= the former / w).
+// Part B  the block-step loops of qe_kernels.hip (the production code, included) on register-resident state, no memory
+//         in the loop: cycles per block-column per SIMD for the 1-, 2- and 4-slot forms and for experimental variants.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o tools/bin/valu_rate && tools/bin/valu_rate [A|B|AB]
 #include <hip/hip_runtime.h>
-#include <cstdio>
-#include <cstdint>
 
-template <int KIND>
-__global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed, int iters) {
-    uint32_t a = seed + threadIdx.x, b = a * 3, c = a * 5, d = a * 7, e = a * 11, f = a * 13, g = a * 17, h = a * 19;
-    float fa = a, fb = b, fc = c, fd = d, fe = e, ff = f, fg = g, fh = h;
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (KIND == 0) { a ^= b; b ^= c; c ^= d; d ^= e; e ^= f; f ^= g; g ^= h; h ^= a; }
-            if (KIND == 1) {
-                a = __builtin_amdgcn_bitop3_b32(a, b, c, 0xB0); b = __builtin_amdgcn_bitop3_b32(b, c, d, 0xF1);
-                c = __builtin_amdgcn_bitop3_b32(c, d, e, 0xB0); d = __builtin_amdgcn_bitop3_b32(d, e, f, 0xF1);
-                e = __builtin_amdgcn_bitop3_b32(e, f, g, 0xB0); f = __builtin_amdgcn_bitop3_b32(f, g, h, 0xF1);
-                g = __builtin_amdgcn_bitop3_b32(g, h, a, 0xB0); h = __builtin_amdgcn_bitop3_b32(h, a, b, 0xF1);
-            }
-            if (KIND == 2) {
-                a = __builtin_amdgcn_alignbit(a, b, 31); b = __builtin_amdgcn_alignbit(b, c, 31);
-                c = __builtin_amdgcn_alignbit(c, d, 31); d = __builtin_amdgcn_alignbit(d, e, 31);
-                e = __builtin_amdgcn_alignbit(e, f, 31); f = __builtin_amdgcn_alignbit(f, g, 31);
-                g = __builtin_amdgcn_alignbit(g, h, 31); h = __builtin_amdgcn_alignbit(h, a, 31);
-            }
-            if (KIND == 3) { fa = fa * fb + fc; fb = fb * fc + fd; fc = fc * fd + fe; fd = fd * fe + ff; fe = fe * ff + fg; ff = ff * fg + fh; fg = fg * fh + fa; fh = fh * fa + fb; }
-            if (KIND == 4) { a += b; b += c; c += d; d += e; e += f; f += g; g += h; h += a; }
-            if (KIND == 8) {   // v_or3_b32
-                asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(b), "v"(c));
-                asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(b) : "v"(b), "v"(c), "v"(d));
-                asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(d), "v"(e));
-                asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(d) : "v"(d), "v"(e), "v"(f));
-                asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(e) : "v"(e), "v"(f), "v"(g));
-                asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(g), "v"(h));
-                asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(g) : "v"(g), "v"(h), "v"(a));
-                asm volatile("v_or3_b32 %0, %1, %2, %3" : "=v"(h) : "v"(h), "v"(a), "v"(b));
-            }
-            if (KIND == 9) {   // v_lshl_or_b32
-                asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(a) : "v"(a), "v"(b));
-                asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(b) : "v"(b), "v"(c));
-                asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(c) : "v"(c), "v"(d));
-                asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(d) : "v"(d), "v"(e));
-                asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(e) : "v"(e), "v"(f));
-                asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(f) : "v"(f), "v"(g));
-                asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(g) : "v"(g), "v"(h));
-                asm volatile("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(h) : "v"(h), "v"(a));
-            }
-            if (KIND == 10) {  // v_add_co_u32 + v_addc_co_u32 (one 64-bit add = 2 instructions, counted as 2 ops)
-                uint64_t x = ((uint64_t)b << 32) | a, y = ((uint64_t)d << 32) | c, z = ((uint64_t)f << 32) | e, w = ((uint64_t)h << 32) | g;
-                x += y; y += z; z += w; w += x;
-                a = (uint32_t)x; b = (uint32_t)(x >> 32); c = (uint32_t)y; d = (uint32_t)(y >> 32); e = (uint32_t)z; f = (uint32_t)(z >> 32); g = (uint32_t)w; h = (uint32_t)(w >> 32);
-            }
-            if (KIND == 11) {  // v_or_b32 via asm (cannot be simplified away)
-                asm volatile("v_or_b32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
-                asm volatile("v_or_b32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
-                asm volatile("v_or_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
-                asm volatile("v_or_b32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
-                asm volatile("v_or_b32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
-                asm volatile("v_or_b32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
-                asm volatile("v_or_b32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
-                asm volatile("v_or_b32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
-            }
-            if (KIND == 12) {   // v_bfe_u32
-                asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(a) : "v"(b));
-                asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(b) : "v"(c));
-                asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(c) : "v"(d));
-                asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(d) : "v"(e));
-                asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(e) : "v"(f));
-                asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(f) : "v"(g));
-                asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(g) : "v"(h));
-                asm volatile("v_bfe_u32 %0, %1, 3, 1" : "=v"(h) : "v"(a));
-            }
-            if (KIND == 13) {   // v_bfe_i32
-                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(a) : "v"(b));
-                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(b) : "v"(c));
-                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(c) : "v"(d));
-                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(d) : "v"(e));
-                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(e) : "v"(f));
-                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(f) : "v"(g));
-                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(g) : "v"(h));
-                asm volatile("v_bfe_i32 %0, %1, 5, 1" : "=v"(h) : "v"(a));
-            }
-            if (KIND == 14) {   // v_lshlrev_b32
-                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(a) : "v"(b));
-                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(b) : "v"(c));
-                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(c) : "v"(d));
-                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(d) : "v"(e));
-                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(e) : "v"(f));
-                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(f) : "v"(g));
-                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(g) : "v"(h));
-                asm volatile("v_lshlrev_b32 %0, 3, %1" : "=v"(h) : "v"(a));
-            }
-            if (KIND == 15) {   // v_ashrrev_i32
-                asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(a) : "v"(b));
-                asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(b) : "v"(c));
-                asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(c) : "v"(d));
-                asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(d) : "v"(e));
-                asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(e) : "v"(f));
-                asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(f) : "v"(g));
-                asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(g) : "v"(h));
-                asm volatile("v_ashrrev_i32 %0, 31, %1" : "=v"(h) : "v"(a));
-            }
-            if (KIND == 16) {   // v_and_or_b32
-                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(b), "v"(c));
-                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(b) : "v"(b), "v"(c), "v"(d));
-                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(d), "v"(e));
-                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(d), "v"(e), "v"(f));
-                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(e) : "v"(e), "v"(f), "v"(g));
-                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(g), "v"(h));
-                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(g) : "v"(g), "v"(h), "v"(a));
-                asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(h) : "v"(h), "v"(a), "v"(b));
-            }
-            if (KIND == 17) {   // v_xad_u32
-                asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(b), "v"(c));
-                asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(b) : "v"(b), "v"(c), "v"(d));
-                asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(d), "v"(e));
-                asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(d), "v"(e), "v"(f));
-                asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(e) : "v"(e), "v"(f), "v"(g));
-                asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(g), "v"(h));
-                asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(g) : "v"(g), "v"(h), "v"(a));
-                asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(h) : "v"(h), "v"(a), "v"(b));
-            }
-            if (KIND == 18) {   // v_bfi_b32
-                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(b), "v"(c));
-                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(b) : "v"(b), "v"(c), "v"(d));
-                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(d), "v"(e));
-                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(d), "v"(e), "v"(f));
-                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(e) : "v"(e), "v"(f), "v"(g));
-                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(g), "v"(h));
-                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(g) : "v"(g), "v"(h), "v"(a));
-                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(h) : "v"(h), "v"(a), "v"(b));
-            }
-            if (KIND == 19) {   // v_perm_b32
-                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(b), "v"(c));
-                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(b) : "v"(b), "v"(c), "v"(d));
-                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(d), "v"(e));
-                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(d), "v"(e), "v"(f));
-                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(e) : "v"(e), "v"(f), "v"(g));
-                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(g), "v"(h));
-                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(g) : "v"(g), "v"(h), "v"(a));
-                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(h) : "v"(h), "v"(a), "v"(b));
-            }
-            if (KIND == 20) {   // v_and_b32
-                asm volatile("v_and_b32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
-                asm volatile("v_and_b32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
-                asm volatile("v_and_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
-                asm volatile("v_and_b32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
-                asm volatile("v_and_b32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
-                asm volatile("v_and_b32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
-                asm volatile("v_and_b32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
-                asm volatile("v_and_b32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
-            }
-            if (KIND == 21) {   // v_cndmask_b32
-                asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a) : "v"(a), "v"(b));
-                asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(b) : "v"(b), "v"(c));
-                asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(c) : "v"(c), "v"(d));
-                asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(d) : "v"(d), "v"(e));
-                asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(e) : "v"(e), "v"(f));
-                asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(f) : "v"(f), "v"(g));
-                asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(g) : "v"(g), "v"(h));
-                asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(h) : "v"(h), "v"(a));
-            }
-            if (KIND == 22) {   // v_bfrev_b32
-                asm volatile("v_bfrev_b32 %0, %1" : "=v"(a) : "v"(b));
-                asm volatile("v_bfrev_b32 %0, %1" : "=v"(b) : "v"(c));
-                asm volatile("v_bfrev_b32 %0, %1" : "=v"(c) : "v"(d));
-                asm volatile("v_bfrev_b32 %0, %1" : "=v"(d) : "v"(e));
-                asm volatile("v_bfrev_b32 %0, %1" : "=v"(e) : "v"(f));
-                asm volatile("v_bfrev_b32 %0, %1" : "=v"(f) : "v"(g));
-                asm volatile("v_bfrev_b32 %0, %1" : "=v"(g) : "v"(h));
-                asm volatile("v_bfrev_b32 %0, %1" : "=v"(h) : "v"(a));
-            }
-            if (KIND == 23) {   // v_add3_u32
-                asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(a) : "v"(a), "v"(b), "v"(c));
-                asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(b) : "v"(b), "v"(c), "v"(d));
-                asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(c) : "v"(c), "v"(d), "v"(e));
-                asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(d), "v"(e), "v"(f));
-                asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(e) : "v"(e), "v"(f), "v"(g));
-                asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "v"(g), "v"(h));
-                asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(g) : "v"(g), "v"(h), "v"(a));
-                asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(h) : "v"(h), "v"(a), "v"(b));
-            }
-            if (KIND == 24) {   // v_xnor_b32
-                asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
-                asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
-                asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
-                asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
-                asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
-                asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
-                asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
-                asm volatile("v_xnor_b32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
-            }
-            if (KIND == 25) {  // v_lshrrev_b64 by a register amount (one 64-bit shift = one op)
-                uint64_t x = ((uint64_t)b << 32) | a, y = ((uint64_t)d << 32) | c, z = ((uint64_t)f << 32) | e, w = ((uint64_t)h << 32) | g;
-                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(x) : "v"(g), "v"(x));
-                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(y) : "v"(g), "v"(y));
-                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(z) : "v"(a), "v"(z));
-                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(w) : "v"(a), "v"(w));
-                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(x) : "v"(c), "v"(x));
-                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(y) : "v"(c), "v"(y));
-                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(z) : "v"(e), "v"(z));
-                asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(w) : "v"(e), "v"(w));
-                a = (uint32_t)x | 1; b = (uint32_t)(x >> 32); c = (uint32_t)y | 1; d = (uint32_t)(y >> 32); e = (uint32_t)z | 1; f = (uint32_t)(z >> 32); g = (uint32_t)w | 1; h = (uint32_t)(w >> 32);
-            }
-            if (KIND == 26) {  // v_lshlrev_b64
-                uint64_t x = ((uint64_t)b << 32) | a, y = ((uint64_t)d << 32) | c, z = ((uint64_t)f << 32) | e, w = ((uint64_t)h << 32) | g;
-                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(x) : "v"(g), "v"(x));
-                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(y) : "v"(g), "v"(y));
-                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(z) : "v"(a), "v"(z));
-                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(w) : "v"(a), "v"(w));
-                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(x) : "v"(c), "v"(x));
-                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(y) : "v"(c), "v"(y));
-                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(z) : "v"(e), "v"(z));
-                asm volatile("v_lshlrev_b64 %0, %1, %2" : "=v"(w) : "v"(e), "v"(w));
-                a = (uint32_t)x | 1; b = (uint32_t)(x >> 32); c = (uint32_t)y | 1; d = (uint32_t)(y >> 32); e = (uint32_t)z | 1; f = (uint32_t)(z >> 32); g = (uint32_t)w | 1; h = (uint32_t)(w >> 32);
-            }
-            if (KIND == 27) {   // v_lshrrev_b32
-                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(a) : "v"(b));
-                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(b) : "v"(c));
-                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(c) : "v"(d));
-                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(d) : "v"(e));
-                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(e) : "v"(f));
-                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(f) : "v"(g));
-                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(g) : "v"(h));
-                asm volatile("v_lshrrev_b32 %0, 3, %1" : "=v"(h) : "v"(a));
-            }
-            if (KIND == 28) {   // v_mov_b32
-                asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(b));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(c));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(d));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(e));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(e) : "v"(f));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "v"(g));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(g) : "v"(h));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(h) : "v"(a));
-            }
-            if (KIND == 29) {   // v_sub_u32
-                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
-                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
-                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
-                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
-                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
-                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
-                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
-                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
-            }
-            if (KIND == 30) {   // v_min_u32
-                asm volatile("v_min_u32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
-                asm volatile("v_min_u32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
-                asm volatile("v_min_u32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
-                asm volatile("v_min_u32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
-                asm volatile("v_min_u32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
-                asm volatile("v_min_u32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
-                asm volatile("v_min_u32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
-                asm volatile("v_min_u32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
-            }
-            if (KIND == 31) {   // v_ffbh_u32
-                asm volatile("v_ffbh_u32 %0, %1" : "=v"(a) : "v"(b));
-                asm volatile("v_ffbh_u32 %0, %1" : "=v"(b) : "v"(c));
-                asm volatile("v_ffbh_u32 %0, %1" : "=v"(c) : "v"(d));
-                asm volatile("v_ffbh_u32 %0, %1" : "=v"(d) : "v"(e));
-                asm volatile("v_ffbh_u32 %0, %1" : "=v"(e) : "v"(f));
-                asm volatile("v_ffbh_u32 %0, %1" : "=v"(f) : "v"(g));
-                asm volatile("v_ffbh_u32 %0, %1" : "=v"(g) : "v"(h));
-                asm volatile("v_ffbh_u32 %0, %1" : "=v"(h) : "v"(a));
-            }
-            if (KIND == 32) {   // v_bcnt_u32_b32
-                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
-                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(b) : "v"(b), "v"(c));
-                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
-                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(e));
-                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(e) : "v"(e), "v"(f));
-                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(f) : "v"(f), "v"(g));
-                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(g) : "v"(g), "v"(h));
-                asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(h), "v"(a));
-            }
-            if (KIND == 5) {     // 64-bit add as one v_lshl_add_u64 (counted as ONE op per 64-bit add)
-                uint64_t x = ((uint64_t)b << 32) | a, y = ((uint64_t)d << 32) | c, z = ((uint64_t)f << 32) | e, w = ((uint64_t)h << 32) | g;
-                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(x) : "v"(x), "v"(y));
-                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(y) : "v"(y), "v"(z));
-                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(z) : "v"(z), "v"(w));
-                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(w) : "v"(w), "v"(x));
-                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(x) : "v"(x), "v"(y));
-                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(y) : "v"(y), "v"(z));
-                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(z) : "v"(z), "v"(w));
-                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(w) : "v"(w), "v"(x));
-                a = (uint32_t)x; b = (uint32_t)(x >> 32); c = (uint32_t)y; d = (uint32_t)(y >> 32); e = (uint32_t)z; f = (uint32_t)(z >> 32); g = (uint32_t)w; h = (uint32_t)(w >> 32);
-            }
-        }
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../quicked_amd/csrc/qe_kernels.hip"
+
+using qe::u32;
+using qe::u64;
+
+enum Op { XOR, OR, AND, ADD, SUB, LSHR, LSHL, ASHR, MOV, BITOP3, ALIGNBIT, BFE_U, BFE_I, LSHL_OR, OR3, AND_OR, ADD3, BCNT, BFREV,
+          PERM, CNDMASK, LSHL_ADD_U64, ADD_CO_PAIR, LSHL_B64, NOPS };
+static const char* const OP_NAME[] = {"v_xor_b32", "v_or_b32", "v_and_b32", "v_add_u32", "v_sub_u32", "v_lshrrev_b32", "v_lshlrev_b32",
+                                      "v_ashrrev_i32", "v_mov_b32", "v_bitop3_b32", "v_alignbit_b32", "v_bfe_u32", "v_bfe_i32",
+                                      "v_lshl_or_b32", "v_or3_b32", "v_and_or_b32", "v_add3_u32", "v_bcnt_u32_b32", "v_bfrev_b32",
+                                      "v_perm_b32", "v_cndmask_b32", "v_lshl_add_u64", "v_add_co+v_addc_co", "v_lshlrev_b64"};
+
+// one instruction of a chain: r = f(r, x, y); x and y are never written (no dependency through them)
+template <int OP> __device__ __forceinline__ void op32(u32& r, u32 x, u32 y) {
+    if (OP == XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r) : "v"(x));
+    if (OP == OR) asm volatile("v_or_b32 %0, %0, %1" : "+v"(r) : "v"(x));
+    if (OP == AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r) : "v"(x));
+    if (OP == ADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(x));
+    if (OP == SUB) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r) : "v"(x));
+    if (OP == LSHR) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(r));
+    if (OP == LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r));
+    if (OP == ASHR) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(r));
+    if (OP == MOV) asm volatile("v_mov_b32 %0, %0" : "+v"(r));
+    if (OP == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r) : "v"(x), "v"(y));
+    if (OP == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(r) : "v"(x));
+    if (OP == BFE_U) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r));
+    if (OP == BFE_I) asm volatile("v_bfe_i32 %0, %0, 3, 29" : "+v"(r));
+    if (OP == LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(r) : "v"(x));
+    if (OP == OR3) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(r) : "v"(x), "v"(y));
+    if (OP == AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r) : "v"(x), "v"(y));
+    if (OP == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r) : "v"(x), "v"(y));
+    if (OP == BCNT) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(r) : "v"(x));
+    if (OP == BFREV) asm volatile("v_bfrev_b32 %0, %0" : "+v"(r));
+    if (OP == PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r) : "v"(x), "v"(y));
+    if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(x));
+}
+template <int OP> __device__ __forceinline__ void op64(u64& r, u64 x) {
+    if (OP == LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(r) : "v"(x));
+    if (OP == ADD_CO_PAIR) {
+        u32 lo = (u32)r, hi = (u32)(r >> 32);
+        asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(lo), "+v"(hi) : "v"((u32)x), "v"((u32)(x >> 32)) : "vcc");
+        r = ((u64)hi << 32) | lo;
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h ^ (uint32_t)(fa + fb + fc + fd + fe + ff + fg + fh);
+    if (OP == LSHL_B64) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(r));
 }
 
-template <int KIND> void run(const char* name, uint32_t* out) {
-    const int blocks = 256 * 8, iters = 4000;
+struct Stamp { uint64_t cyc, real; };
+
+template <int OP, int D>
+__global__ __launch_bounds__(256) void k_rate(u32* out, Stamp* stamps, int iters) {
+    extern __shared__ uint4 pin[];
+    u32 r[8]; u64 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r[j] = threadIdx.x * 2654435761u + j; q[j] = ((u64)r[j] << 32) | (r[j] ^ 0x5bd1e995u); }
+    const u32 x = threadIdx.x | 1u, y = ~threadIdx.x;
+    const u64 x64 = ((u64)y << 32) | x;
+    const uint64_t c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {
+            if (OP < LSHL_ADD_U64) op32<OP>(r[u % D], x, y);
+            else op64<OP>(q[u % D], x64);
+        }
+    }
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    u32 acc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc ^= r[j] ^ (u32)q[j] ^ (u32)(q[j] >> 32);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c1 - c0, t1 - t0};
+}
+
+static u32* g_out; static Stamp* g_stamps;
+static const int CUS = 256;
+
+struct Result { double cyc_wave, clock_ghz, wall_ms; };
+template <typename F> static Result measure(F launch, int wps) {
+    const int blocks = CUS * wps;
+    const size_t lds = (size_t)(160 * 1024 / wps) & ~(size_t)255;      // wps of these workgroups fill a CU's LDS: no CU takes more
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<KIND><<<blocks, 256>>>(out, 1, 10);
+    launch(blocks, lds, true);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<KIND><<<blocks, 256>>>(out, 1, iters);
+    launch(blocks, lds, false);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double ops = (double)blocks * 256 * iters * 16 * 8;
-    printf("%-14s %8.2f Tlane-ops/s  (%.3f ms)\n", name, ops / ms / 1e9, ms);
+    std::vector<Stamp> st((size_t)blocks * 4);
+    hipMemcpy(st.data(), g_stamps, st.size() * sizeof(Stamp), hipMemcpyDeviceToHost);
+    std::vector<double> cyc, clk;
+    for (auto& s : st) { cyc.push_back((double)s.cyc); clk.push_back(s.real ? (double)s.cyc / (double)s.real * 0.1 : 0.0); }
+    std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return Result{cyc[cyc.size() / 2], clk[clk.size() / 2], ms};
 }
 
-int main() {
-    uint32_t* out; hipMalloc(&out, 256 * 8 * 256 * 4);
-    run<0>("v_xor_b32", out); run<1>("v_bitop3_b32", out); run<2>("v_alignbit_b32", out);
-    run<3>("v_fma_f32", out); run<4>("v_add_u32", out); run<5>("v_lshl_add_u64", out);
-    run<8>("v_or3_b32", out); run<9>("v_lshl_or_b32", out); run<10>("add_co+addc", out); run<11>("v_or_b32", out);
-    run<12>("v_bfe_u32", out);
-    run<13>("v_bfe_i32", out);
-    run<14>("v_lshlrev_b32", out);
-    run<15>("v_ashrrev_i32", out);
-    run<16>("v_and_or_b32", out);
-    run<17>("v_xad_u32", out);
-    run<18>("v_bfi_b32", out);
-    run<19>("v_perm_b32", out);
-    run<20>("v_and_b32", out);
-    run<21>("v_cndmask_b32", out);
-    run<22>("v_bfrev_b32", out);
-    run<23>("v_add3_u32", out);
-    run<24>("v_xnor_b32", out);
-    run<25>("v_lshrrev_b64", out);
-    run<26>("v_lshlrev_b64", out);
-    run<27>("v_lshrrev_b32", out);
-    run<28>("v_mov_b32", out);
-    run<29>("v_sub_u32", out);
-    run<30>("v_min_u32", out);
-    run<31>("v_ffbh_u32", out);
-    run<32>("v_bcnt_u32_b32", out);
+template <int OP, int D> static void rate_row(int wps, int iters) {
+    auto launch = [&](int blocks, size_t lds, bool warm) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rate<OP, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((k_rate<OP, D>), dim3(blocks), dim3(256), lds, 0, g_out, g_stamps, warm ? 8 : iters);
+    };
+    const Result r = measure(launch, wps);
+    const double per_wave = r.cyc_wave / ((double)iters * 64 * (OP == ADD_CO_PAIR ? 2 : 1));
+    printf("%-20s D=%d w=%d  wave %6.2f  SIMD %6.2f cyc/instr   clock %.2f GHz  (%.2f ms)\n", OP_NAME[OP], D, wps, per_wave,
+           per_wave / wps, r.clock_ghz, r.wall_ms);
+}
+template <int OP> static void rate_op(bool full) {
+    const int iters = 3000;
+    if (full) {
+        rate_row<OP, 1>(1, iters); rate_row<OP, 2>(1, iters); rate_row<OP, 4>(1, iters); rate_row<OP, 8>(1, iters);
+        rate_row<OP, 1>(2, iters); rate_row<OP, 2>(2, iters); rate_row<OP, 4>(2, iters); rate_row<OP, 8>(2, iters);
+        rate_row<OP, 1>(4, iters); rate_row<OP, 4>(4, iters); rate_row<OP, 8>(8, iters);
+    } else {
+        rate_row<OP, 1>(2, iters); rate_row<OP, 4>(2, iters); rate_row<OP, 8>(8, iters);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Part B: block-step loops on register state.  VAR 0: run64_multi<4> (production 4-slot pass), 1: run64_multi<2>,
+// 2: run64_fast<0, true> (one slot), 3: the 4-slot pass software-skewed (slot k runs k columns behind slot 0, so the
+// four block steps of a pass step are independent), 4: two slots skewed
+// ---------------------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void run64_skew(u64 (&P)[K], u64 (&M)[K], const u64 (&a)[K], const u64 (&b)[K],
+                                           u64 T0, u64 T1, u64 hinP, u64 hinM, u64& houtP, u64& houtM) {
+    using namespace qe;
+    u32 alo[K], ahi[K], blo[K], bhi[K], Plo[K], Phi[K], Mlo[K], Mhi[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        alo[k] = lo32(a[k]); ahi[k] = hi32(a[k]); blo[k] = lo32(b[k]); bhi[k] = hi32(b[k]);
+        Plo[k] = lo32(P[k]); Phi[k] = hi32(P[k]); Mlo[k] = lo32(M[k]); Mhi[k] = hi32(M[k]);
+    }
+    u32 oPlo = 0, oPhi = 0, oMlo = 0, oMhi = 0;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const u32 t0 = half ? hi32(T0) : lo32(T0), t1 = half ? hi32(T1) : lo32(T1);
+        const u32 hp = half ? hi32(hinP) : lo32(hinP), hm = half ? hi32(hinM) : lo32(hinM);
+        u32 gP = 0, gM = 0;
+        u32 m0[32], m1[32], cP[K], cM[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { cP[k] = 0; cM[k] = 0; }
+#pragma unroll
+        for (int s = 0; s < 32 + K - 1; ++s) {
+            if (s < 32) {
+                m0[s] = (u32)__builtin_amdgcn_sbfe((int)t0, s, 1);
+                m1[s] = (u32)__builtin_amdgcn_sbfe((int)t1, s, 1);
+            }
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {           // lower slots first: they consume the carries of the previous step
+                const int c = s - k;
+                if (c < 0 || c >= 32) continue;
+                const u32 elo = bitop3<0x90>(~(alo[k] ^ m0[c]), blo[k], m1[c]), ehi = bitop3<0x90>(~(ahi[k] ^ m0[c]), bhi[k], m1[c]);
+                u32 inP, inM;
+                if (k == 0) { inP = __builtin_amdgcn_ubfe(hp, c, 1); inM = __builtin_amdgcn_ubfe(hm, c, 1); }
+                else { inP = cP[k]; inM = cM[k]; }
+                if (k + 1 < K) {
+                    u32 phhi, mhhi;
+                    block_step_core(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, phhi, mhhi);
+                    cP[k + 1] = phhi >> 31; cM[k + 1] = mhhi >> 31;
+                } else {
+                    block_step_fused(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, gP, gM);
+                }
+            }
+        }
+        const u32 rP = __builtin_bitreverse32(gP), rM = __builtin_bitreverse32(gM);
+        if (half) { oPhi = rP; oMhi = rM; } else { oPlo = rP; oMlo = rM; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { P[k] = mk64(Plo[k], Phi[k]); M[k] = mk64(Mlo[k], Mhi[k]); }
+    houtP = mk64(oPlo, oPhi);
+    houtM = mk64(oMlo, oMhi);
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256) void k_step(u32* out, Stamp* stamps, int iters) {
+    using namespace qe;
+    extern __shared__ uint4 pin[];
+    constexpr int K = (VAR == 0 || VAR == 3) ? 4 : (VAR == 1 || VAR == 4) ? 2 : 1;
+    u64 P[4], M[4], a[4], b[4];
+    const u64 seed = (u64)(blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        P[k] = ~(u64)0; M[k] = 0;
+        a[k] = seed * (2 * k + 3) ^ (seed >> 17); b[k] = seed * (2 * k + 5) ^ (seed >> 13);
+    }
+    u64 T0 = seed ^ 0x0123456789abcdefull, T1 = seed * 7 + 1, hinP = ~(u64)0, hinM = 0, houtP = 0, houtM = 0;
+    const uint64_t c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        if (K == 4) {
+            if (VAR == 0) run64_multi<4>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM);
+            else run64_skew<4>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM);
+        } else if (K == 2) {
+            u64 P2[2] = {P[0], P[1]}, M2[2] = {M[0], M[1]};
+            const u64 a2[2] = {a[0], a[1]}, b2[2] = {b[0], b[1]};
+            if (VAR == 1) run64_multi<2>(P2, M2, a2, b2, T0, T1, hinP, hinM, houtP, houtM);
+            else run64_skew<2>(P2, M2, a2, b2, T0, T1, hinP, hinM, houtP, houtM);
+            P[0] = P2[0]; P[1] = P2[1]; M[0] = M2[0]; M[1] = M2[1];
+        } else {
+            run64_fast<0, true>(P[0], M[0], a[0], b[0], T0, T1, hinP, hinM, houtP, houtM, true, nullptr, 0, nullptr);
+        }
+        T0 = T0 * 6364136223846793005ull + 1442695040888963407ull;      // the next chunk's text
+        T1 ^= T0 >> 7;
+        hinP = houtM | T1; hinM = houtP & ~hinP;                            // any carry words (never both bits set)
+    }
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    u64 acc = houtP ^ houtM;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc ^= P[k] ^ M[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)acc ^ (u32)(acc >> 32);
+    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c1 - c0, t1 - t0};
+}
+
+template <int VAR> static void step_row(const char* name, int K, int wps, int iters) {
+    auto launch = [&](int blocks, size_t lds, bool warm) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((k_step<VAR>), dim3(blocks), dim3(256), lds, 0, g_out, g_stamps, warm ? 4 : iters);
+    };
+    const Result r = measure(launch, wps);
+    const double bc = (double)iters * 64 * K;                          // block-columns per wave
+    const double per_simd = r.cyc_wave / bc / wps;
+    const double rate = (double)CUS * 4 * wps * 64 * bc / (r.wall_ms * 1e-3);   // lane block-columns per second, whole chip
+    printf("%-26s w=%d  %6.1f cyc / block-column / SIMD   chip %.3e block-columns/s   clock %.2f GHz  (%.2f ms)\n", name, wps,
+           per_simd, rate, r.clock_ghz, r.wall_ms);
+}
+
+int main(int argc, char** argv) {
+    const char* what = argc > 1 ? argv[1] : "AB";
+    hipMalloc(&g_out, (size_t)CUS * 8 * 256 * 4);
+    hipMalloc(&g_stamps, (size_t)CUS * 8 * 4 * sizeof(Stamp));
+    if (strchr(what, 'A')) {
+        printf("# Part A: cycles per wave64 instruction (shader cycles, s_memtime); D = independent chains, w = waves per SIMD\n");
+        rate_op<XOR>(true); rate_op<BITOP3>(true); rate_op<LSHL_ADD_U64>(true); rate_op<ADD_CO_PAIR>(true);
+        rate_op<OR>(false); rate_op<AND>(false); rate_op<ADD>(false); rate_op<SUB>(false); rate_op<LSHR>(false); rate_op<LSHL>(false);
+        rate_op<ASHR>(false); rate_op<MOV>(false); rate_op<ALIGNBIT>(false); rate_op<BFE_U>(false); rate_op<BFE_I>(false);
+        rate_op<LSHL_OR>(false); rate_op<OR3>(false); rate_op<AND_OR>(false); rate_op<ADD3>(false); rate_op<BCNT>(false);
+        rate_op<BFREV>(false); rate_op<PERM>(false); rate_op<CNDMASK>(false); rate_op<LSHL_B64>(false);
+    }
+    if (strchr(what, 'B')) {
+        printf("# Part B: block-step loops of qe_kernels.hip on registers (no memory in the loop)\n");
+        const int it = 400;
+        for (int w : {1, 2, 3, 4}) {
+            step_row<0>("run64_multi<4>", 4, w, it);
+            step_row<3>("run64_skew<4> (experimental)", 4, w, it);
+            step_row<1>("run64_multi<2>", 2, w, it);
+            step_row<4>("run64_skew<2> (experimental)", 2, w, it);
+            step_row<2>("run64_fast<WIDE> (1 slot)", 1, w, it);
+        }
+    }
     return 0;
 }
