@@ -201,12 +201,16 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflig
     fetched = [threading.Event() for _ in range(nbatches)]
     err = []
 
+    tm = {"reload": 0.0, "run": 0.0, "fetch": 0.0}
+
     def uploader():
         try:
             for k in range(nbatches):
                 if k >= slots:
                     fetched[k - slots].wait()
+                tu = time.perf_counter()
                 st = reload_(rbs[k % slots])
+                tm["reload"] += time.perf_counter() - tu
                 if st < 0:
                     raise RuntimeError(f"quicked_batch_reload: {st}")
                 uploaded[k].set()
@@ -222,7 +226,9 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflig
 
     def finish(k):
         rb = rbs[k % slots]
+        tf = time.perf_counter()
         assert rb.fetch() >= 0, "quicked_batch_fetch failed"
+        tm["fetch"] += time.perf_counter() - tf
         s, st = rb.scores()
         assert (st >= 0).all()
         checks.append(int(s.astype(np.int64).sum()))
@@ -232,7 +238,9 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflig
         uploaded[k].wait()
         if err:
             break
+        tr = time.perf_counter()
         assert rbs[k % slots].run(params, sync=False) >= 0
+        tm["run"] += time.perf_counter() - tr
         if k >= inflight - 1:
             finish(k - inflight + 1)
     for k in range(max(nbatches - inflight + 1, 0), nbatches):
@@ -250,7 +258,8 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflig
         raise err[0]
     assert all(c == expect_checksum for c in checks), "end-to-end scores differ from the resident run's"
     return {"value": n * nbatches / elapsed, "unit": "alignments/s", "batches": nbatches, "ms_per_batch": elapsed / nbatches * 1e3,
-            "h2d_bytes_per_batch": nbytes, "h2d_GBs": nbytes * nbatches / elapsed / 1e9}
+            "h2d_bytes_per_batch": nbytes, "h2d_GBs": nbytes * nbatches / elapsed / 1e9,
+            "host_ms_per_batch": {k: v / nbatches * 1e3 for k, v in tm.items()}, "slots": slots, "inflight": inflight}
 
 
 def main():

@@ -125,6 +125,11 @@ quicked_status_t quicked_batch_validate(quicked_batch_t* batch, const char* ciga
  *   [6] pairs that went past stage 1   [7] pairs that went past stage 2 */
 quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]);
 
+/* The device-pool planner's view of the calling thread (replaces mm_allocator, quicked_utils/src/mm_allocator.c:141-426):
+ *   [0] bytes its pools hold   [1] out-of-memory reclaim events so far (process-wide; the planner is there to keep this 0)
+ *   [2] pool sets in rotation in the last run   [3] fill sub-batches of the last run   [4] bytes one pool may hold */
+quicked_status_t quicked_pool_stats(int64_t stats_out[8]);
+
 /* Sum of the HIP-event durations (ms) of the dominant kernel (BandEd score /
  * fill) over the runs of this thread since the previous call, and how many
  * launches that was; synchronises the batch's stream. */

@@ -57,7 +57,7 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free",
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
            "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
-           "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch"]
+           "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats"]
 
 _LIB = None
 
@@ -110,12 +110,20 @@ def lib():
     L.quicked_batch_reload.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_reload_packed.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_fetch.argtypes = [C.c_void_p]
+    L.quicked_pool_stats.argtypes = [C.c_void_p]
     L.quicked_host_alloc.restype = C.c_void_p
     L.quicked_host_alloc.argtypes = [C.c_size_t]
     L.quicked_host_free.argtypes = [C.c_void_p]
     L.quicked_host_free.restype = None
     _LIB = L
     return L
+
+
+def pool_stats():
+    """quicked_pool_stats of the calling thread: dict(pool_bytes, reclaim_events, sets, sub_batches, pool_budget)"""
+    v = np.zeros(8, dtype=np.int64)
+    lib().quicked_pool_stats(v.ctypes.data)
+    return dict(pool_bytes=int(v[0]), reclaim_events=int(v[1]), sets=int(v[2]), sub_batches=int(v[3]), pool_budget=int(v[4]))
 
 
 def make_params(**kw):

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -172,6 +173,8 @@ struct Context {
     int si = 0;
     bool staging = false;                    // uploads on the current A stream go through stage[si]
     bool memory_tight = false;               // a pool had to take the others' memory once: no more rotation on this thread
+    int last_na = 0, last_sub_batches = 0;   // what the planner chose for the last run (quicked_pool_stats)
+    size_t pool_budget = 0;                  // bytes one A pool may hold in this run (plan_pools)
     hipStream_t& sa() { return stream_a2[ai]; }
     DevicePool& pa() { return pool_a2[ai]; }
     DevicePool* scratch_p = nullptr;         // the current phase's pool
@@ -231,11 +234,13 @@ static Context& ctx() {
 }
 
 // DevicePool::reclaim_fn: every pool of this thread's context except `keep` is emptied after its stream has drained
+static std::atomic<int64_t> g_reclaim_events{0};
 static bool reclaim_pools(DevicePool* keep) {
     Context* C = tl_ctx;
     if (!C) return false;
     bool freed = false;
     C->memory_tight = true;
+    ++g_reclaim_events;
     for (int q = 0; q < Context::NA; ++q) {
         if (&C->pool_a2[q] == keep || C->pool_a2[q].cap == 0) continue;
         if (hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
@@ -312,7 +317,9 @@ struct quicked_batch {
     u32* d_flags[NP] = {};
     int parity = 0;
     int np_used = 2;                              // plane sets in rotation = stream / pool sets in rotation (run_batch)
-    size_t last_mat_bytes = 0;                    // fill matrices of this batch's last CIGAR run
+    size_t last_mat_bytes = 0;                    // fill matrices of this batch's last CIGAR run (all leaves at once)
+    size_t last_fixed_bytes = 0;                  // everything else its align stage took from the pool (runs, strings, workspaces)
+    int last_groups = 0;                          // 64-task groups of that stage
     hipEvent_t ev_done[NP] = {};    // end of the A phase of the last run that used this parity
     bool ev_done_set[NP] = {};
     size_t pl_p_words = 0, pl_t_words = 0;
@@ -463,7 +470,9 @@ static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs) {
             nr = std::max(nr, nw + nsl + 4);
             nch = std::max(nch, L.n[t] / 64 + 3);
             nmax = std::max(nmax, L.n[t]);
-            cap = std::max(cap, L.m[t] + L.n[t] + 2);
+            // an alignment with e edits has at most 2 e + 1 runs, and inside the parity domain e <= cutoff (k_traceback
+            // reports, instead of storing, a path that has more)
+            cap = std::max(cap, (int)std::min<int64_t>((int64_t)L.m[t] + L.n[t] + 2, (int64_t)2 * G.cutoff + 8));
         }
         B.nslots[g] = ns; B.nrows[g] = nr; B.nch[g] = nch; B.runs_cap[g] = cap;
         B.ws_off[g] = (int64_t)B.ws_bytes;
@@ -645,6 +654,11 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
 
 // upper bound of one pair's RLE string incl. terminator: every op its own run
 static size_t cigar_bound(int m, int n) { return (size_t)2 * ((size_t)m + (size_t)n) + 12; }
+// the same for an alignment made of `leaves` BandEd leaves whose run buffers hold at most `runs` runs in total: a run is
+// "<= 10 digits + op"; never more than the every-op-its-own-run bound
+static size_t cigar_bound_runs(int m, int n, int64_t runs, int leaves) {
+    return std::min(cigar_bound(m, n), (size_t)11 * (size_t)(runs + 2 * leaves + 2) + 12);
+}
 
 // ---------------------------------------------------------------------------
 // CIGAR assembly: per list entry ("root" = one pair's alignment) an ordered list of segments
@@ -756,6 +770,7 @@ static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, co
         const int pr = SL.root_pair[i];
         B.score[pr] = edits[i];
         B.status[pr] = root_status ? (*root_status)[i] : ok_status;
+        if (edits[i] < 0) { B.score[pr] = -1; B.status[pr] = QUICKED_ERROR; }      // run-buffer overflow: cutoff below the distance
         B.counters[4] += nops[i];
         if (A.ok) B.check_ok[pr] = okv[i];
         if (want_strings && len[i] > 0) {
@@ -920,21 +935,24 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     for (size_t i = 0; i < root_node.size(); ++i) {
         stack.clear();
         stack.push_back(root_node[i]);
+        int64_t root_runs = 0; int root_segs = 0;
         while (!stack.empty()) {
             const int32_t id = stack.back(); stack.pop_back();
             HNode& nd = nodes[id];
             if (nd.left >= 0) { stack.push_back(nd.right); stack.push_back(nd.left); continue; }
             if (nd.m == 0 && nd.n == 0) continue;
+            ++root_segs;
             if (nd.m == 0) { SL.kind.push_back(1); SL.a.push_back((int32_t)OP_I); SL.b.push_back(nd.n); continue; }
             if (nd.n == 0) { SL.kind.push_back(1); SL.a.push_back((int32_t)OP_D); SL.b.push_back(nd.m); continue; }
             nd.leaf_task = (int32_t)LL.pair.size();
             LL.push(nd.pair, nd.p0, nd.m, nd.t0, nd.n, nd.cutoff, nd.n);
             SL.kind.push_back(0); SL.a.push_back(nd.leaf_task); SL.b.push_back(0);
+            root_runs += std::min<int64_t>((int64_t)nd.m + nd.n + 2, (int64_t)2 * host_geometry(nd.m, nd.n, nd.cutoff).cutoff + 8);   // band_layout's cap
         }
         SL.off.push_back((int64_t)SL.kind.size());
         const HNode& rt = nodes[root_node[i]];
         SL.root_pair.push_back(rt.pair);
-        SL.bound.push_back(cigar_bound(roots.m.empty() ? rt.m : rt.m, rt.n));
+        SL.bound.push_back(cigar_bound_runs(rt.m, rt.n, root_runs, root_segs));
     }
     LL.pad();
     if (stats) stats->leaves += LL.pair.size();
@@ -943,20 +961,33 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     const int ng = LL.ngroups();
     const BandLayout lay = band_layout(LL, true, true);
     B.last_mat_bytes = lay.mat_u4 * 16;
-    // partition the groups so that each sub-batch's matrices fit the budget; offsets restart per sub-batch
+    // what the stage takes from the pool besides the matrices: run buffers, string pool, per-task arrays, segment lists
+    size_t fixed_bytes = lay.runs_u32 * 4 + (size_t)nt * 160 + SL.kind.size() * 16 + ((size_t)4 << 20);
+    if (want_cigar) for (size_t b : SL.bound) fixed_bytes += b;
+    B.last_fixed_bytes = fixed_bytes + lay.ws_bytes;
+    B.last_groups = ng;
+    // partition the groups so that each sub-batch's matrices (and workspaces) fit what is left of the pool's budget
+    // (matrix_budget = the pool's whole budget, plan_pools in run_batch); sub-batches are made equal so that none is a
+    // sliver; offsets restart per sub-batch
     std::vector<int> sub_start{0};
     std::vector<int64_t> ws_off(ng), mat_off(ng);
     {
+        const size_t room = matrix_budget > fixed_bytes + ((size_t)64 << 20) ? matrix_budget - fixed_bytes : (size_t)64 << 20;
+        const size_t total = lay.mat_u4 * 16 + lay.ws_bytes;
+        const size_t nsub = std::max<size_t>(1, (total + room - 1) / room);
+        const size_t target = (total + nsub - 1) / nsub;                  // bytes per sub-batch when split evenly
         size_t ws = 0, mat = 0;
         for (int g = 0; g < ng; ++g) {
             const size_t gws = (size_t)((g + 1 < ng ? lay.ws_off[g + 1] : (int64_t)lay.ws_bytes) - lay.ws_off[g]);
             const size_t gmat = (size_t)((g + 1 < ng ? lay.mat_off[g + 1] : (int64_t)lay.mat_u4) - lay.mat_off[g]);
-            if (g > sub_start.back() && (mat + gmat) * 16 > matrix_budget) { sub_start.push_back(g); ws = 0; mat = 0; }
+            const size_t after = (mat + gmat) * 16 + ws + gws;
+            if (g > sub_start.back() && (after > room || (nsub > 1 && after > target + target / 16))) { sub_start.push_back(g); ws = 0; mat = 0; }
             ws_off[g] = (int64_t)ws; mat_off[g] = (int64_t)mat;
             ws += gws; mat += gmat;
         }
         sub_start.push_back(ng);
     }
+    C.last_sub_batches = (int)sub_start.size() - 1;
     const DevTasks T = upload_tasks(LL, C);
     const TaskOut O = take_out(C, nt);
     int64_t* d_ws_off = C.scratch_p->take<int64_t>(ng + 1); int64_t* d_mat_off = C.scratch_p->take<int64_t>(ng + 1);
@@ -1001,10 +1032,8 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         tr.runs = d_runs; tr.g_runs_off = d_runs_off + g0; tr.g_runs_cap = d_runs_cap + g0;
         tr.o_nruns = O.nruns + o; tr.o_nops = O.nops + o; tr.o_edits = O.edits + o; tr.o_steps = O.steps + o;
         launch_groups(C, k_traceback, tr, (size_t)(g1 - g0), 8, 0);
-        if (sb + 2 < sub_start.size()) {
-            HIP_CHECK(hipStreamSynchronize(C.stream));       // the next sub-batch reuses this scratch
-            C.scratch_p->release(mark);
-        }
+        // the next sub-batch reuses this scratch: its kernels are behind this sub-batch's in the stream, no host wait
+        if (sb + 2 < sub_start.size()) C.scratch_p->release(mark);
     }
     const AlignOut AO = format_segments(B, C, SL, d_runs, d_runs_off, O.nruns, want_cigar);
     if (d_score_out) *d_score_out = AO.edits;
@@ -1092,8 +1121,36 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     static const int na_env = env_int("QE_NA", 0);
     size_t free0 = 0, total0 = 0;
     HIP_CHECK(hipMemGetInfo(&free0, &total0));
-    const bool roomy = (double)B.last_mat_bytes * 3.3 < 0.6 * (double)total0;
-    const int na = C.memory_tight ? 1 : na_env > 0 ? std::min(na_env, (int)Context::NA) : (roomy ? 3 : 2);
+    // ---- the device-pool planner (replaces mm_allocator's "never fails" arena, mm_allocator.c:251-334, by a budget):
+    // how many {stream, pool, planes} sets rotate, and how many bytes one pool may hold, from what this batch's last
+    // CIGAR run needed (or, first time, from a bandwidth-based estimate).  A run whose fill matrices do not fit its
+    // pool's budget is cut into sub-batches by run_align -- before anything is allocated, not after an out-of-memory.
+    size_t pools_held = 0;
+    for (const auto& q : C.pool_a2) pools_held += q.cap;
+    const size_t avail = (size_t)(0.92 * (double)(free0 + pools_held));                 // what the A pools may hold together
+    size_t need_mat = B.last_mat_bytes, need_fixed = B.last_fixed_bytes;
+    int need_groups = B.last_groups;
+    if (need_groups == 0 && !p.only_score && p.algo != WINDOWED) {
+        // first CIGAR run of this batch: leaves as wide as the bandwidth cutoff allows (QuickEd's bounds are tighter)
+        for (int64_t i = 0; i < B.n; ++i) {
+            const int m = B.p_len[(size_t)i], n = B.t_len[(size_t)i];
+            if (m == 0 || n == 0) continue;
+            const HGeom G = host_geometry(m, n, max_cutoff(p.bandwidth, m, n));
+            const uint64_t full = (uint64_t)9 * (uint64_t)(n / 64 + 3) * (uint64_t)G.ebb * 16;
+            need_mat += (size_t)std::min<uint64_t>(full, (uint64_t)18 << 20);             // per pair; splits cap a leaf at 16 MiB of matrix
+            need_fixed += (size_t)std::min<int64_t>((int64_t)m + n + 2, (int64_t)2 * G.cutoff + 8) * 15 + 512;
+        }
+        need_groups = (int)((B.n + 63) / 64);
+    }
+    // a sub-batch should still fill the chip: >= ~1600 groups (two waves on every SIMD) where the batch has that many
+    const double frac = need_groups > 1600 ? 1600.0 / (double)need_groups : 1.0;
+    const size_t min_set = need_fixed + (size_t)((double)need_mat * frac);
+    int na = 1;
+    for (int k = (int)Context::NA; k >= 1; --k) if ((double)min_set * k <= (double)avail) { na = k; break; }
+    if (na_env > 0) na = std::min(na_env, (int)Context::NA);
+    if (C.memory_tight) na = 1;
+    C.pool_budget = avail / (size_t)na;
+    C.last_na = na;
     B.np_used = na;
     for (int q = na; q < Context::NA; ++q)              // a set that left the rotation gives its memory back
         if (C.pool_a2[q].cap > ((size_t)1 << 30)) { HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_a2[q].release_all(); }
@@ -1143,13 +1200,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     };
     const bool sse = !p.force_scalar;
     const bool want_cigar = !p.only_score;
-    size_t free_b = 0, total_b = 0;
-    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    size_t pools_cap = 0;
-    for (const auto& q : C.pool_a2) pools_cap += q.cap;
-    // a pool's share of what the na pools in rotation can have, but never more than this pool can actually get
-    const size_t matrix_budget = std::max<size_t>(std::min((free_b + pools_cap) / (10 * (size_t)na) * 7,
-                                                           (free_b + C.pool_a2[C.ai].cap) / 10 * 7), (size_t)1 << 28);
+    const size_t matrix_budget = C.pool_budget;      // run_align subtracts what the stage needs besides the matrices
     quicked_status_t ret = QUICKED_WIP;
     QE_TRACE_POINT("setup+pack launch");
     TaskList L = all_pairs(B, p);
@@ -1820,6 +1871,17 @@ QE_API quicked_status_t quicked_batch_validate(quicked_batch_t* batch, const cha
         C.pool_w.release(mk);
         return QUICKED_OK;
     }, &arg);
+}
+
+QE_API quicked_status_t quicked_pool_stats(int64_t stats_out[8]) {
+    for (int q = 0; q < 8; ++q) stats_out[q] = 0;
+    stats_out[1] = g_reclaim_events.load();
+    Context* C = tl_ctx;
+    if (!C) return QUICKED_OK;
+    for (const auto& q : C->pool_a2) stats_out[0] += (int64_t)q.cap;
+    stats_out[0] += (int64_t)C->pool_w.cap;
+    stats_out[2] = C->last_na; stats_out[3] = C->last_sub_batches; stats_out[4] = (int64_t)C->pool_budget;
+    return QUICKED_OK;
 }
 
 QE_API quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]) {

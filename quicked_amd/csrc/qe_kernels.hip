@@ -1240,7 +1240,9 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     R.push_n(OP_I, h + 1);
     R.push_n(OP_D, v + 1);
     R.flush();
-    A.o_nruns[t] = R.nruns;
+    // the run buffer is sized from the cutoff (an alignment inside the parity domain has <= 2 cutoff + 1 runs); a path
+    // with more runs (cutoff below the distance: the reference walks uninitialised memory there) is reported, not stored
+    A.o_nruns[t] = (R.nruns <= R.cap) ? R.nruns : -1;
     A.o_nops[t] = R.nops;
     A.o_edits[t] = R.edits;
     A.o_steps[t] = steps;
@@ -1674,15 +1676,22 @@ __global__ __launch_bounds__(64) void k_format_segs(SegFormatArgs A) {
     if (i >= A.npairs) return;
     RunMerger Mg;
     Mg.style = A.style;
+    bool bad = false;
     if (WRITE) Mg.out = A.pool + A.str_off[i];
     for (int64_t sidx = A.seg_off[i]; sidx < A.seg_off[i + 1]; ++sidx) {
         if (A.seg_kind[sidx] == 1) { Mg.push<WRITE>(A.seg_a[sidx], A.seg_b[sidx]); continue; }
         const int t = A.seg_a[sidx];
         const u32* runs = A.runs + A.g_runs_off[t >> 6] + (t & 63);
-        for (int k = A.nruns[t] - 1; k >= 0; --k) {
+        if (A.nruns[t] < 0) bad = true;                                   // run buffer overflow (see k_traceback)
+        for (int k = A.nruns[t] - 1; k >= 0 && !bad; --k) {
             const u32 r = runs[(int64_t)k * 64];
             Mg.push<WRITE>((int)(r & 3), (int)(r >> 2));
         }
+    }
+    if (bad) {
+        if (WRITE) A.pool[A.str_off[i]] = '\0';
+        else { A.o_len[i] = 0; A.o_edits[i] = -1; A.o_nops[i] = 0; }
+        return;
     }
     Mg.emit<WRITE>();
     if (WRITE) Mg.finish();
@@ -1730,6 +1739,7 @@ __global__ __launch_bounds__(64) void k_check_segs(SegCheckArgs C) {
         if (A.seg_kind[sidx] == 1) { K.apply(A.seg_a[sidx], A.seg_b[sidx]); continue; }
         const int t = A.seg_a[sidx];
         const u32* runs = A.runs + A.g_runs_off[t >> 6] + (t & 63);
+        if (A.nruns[t] < 0) K.ok = false;
         for (int k = A.nruns[t] - 1; k >= 0; --k) {
             const u32 r = runs[(int64_t)k * 64];
             K.apply((int)(r & 3), (int)(r >> 2));

@@ -208,3 +208,47 @@ def ref_align(pattern, text, **kw):
     cigar = a.cigar.decode() if a.cigar else None
     lib.quicked_free(C.byref(a))
     return st, score, cigar
+
+
+# --------------------------------------------------------------------------- #
+# edlib 1.2.6 (the reference's vendored copy, tools/align_benchmark/external/edlib) compiled into oracle/_ref: the
+# independent exact-distance opinion the reference's own `--check score` uses (benchmark_check.c)
+# --------------------------------------------------------------------------- #
+EDLIB_SO = os.path.join(ORACLE_DIR, "_ref", "libedlib_ref.so")
+
+
+class EdlibAlignConfig(C.Structure):
+    """edlib.h: EdlibAlignConfig {k, mode, task, additionalEqualities, additionalEqualitiesLength}"""
+    _fields_ = [("k", C.c_int), ("mode", C.c_int), ("task", C.c_int), ("additionalEqualities", C.c_void_p),
+                ("additionalEqualitiesLength", C.c_int)]
+
+
+class EdlibAlignResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("editDistance", C.c_int), ("endLocations", C.POINTER(C.c_int)),
+                ("startLocations", C.POINTER(C.c_int)), ("numLocations", C.c_int), ("alignment", C.POINTER(C.c_ubyte)),
+                ("alignmentLength", C.c_int), ("alphabetLength", C.c_int)]
+
+
+_edlib = None
+
+
+def have_edlib():
+    return os.path.exists(EDLIB_SO)
+
+
+def edlib_distance(pattern, text):
+    """global (NW) edit distance by edlib; bytes compare as bytes (no N wildcard, no case folding)"""
+    global _edlib
+    if _edlib is None:
+        lib = C.CDLL(EDLIB_SO)
+        lib.edlibAlign.restype = EdlibAlignResult
+        lib.edlibAlign.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, EdlibAlignConfig]
+        lib.edlibFreeAlignResult.argtypes = [EdlibAlignResult]
+        lib.edlibFreeAlignResult.restype = None
+        _edlib = lib
+    cfg = EdlibAlignConfig(-1, 0, 0, None, 0)          # k = -1 (no bound), EDLIB_MODE_NW, EDLIB_TASK_DISTANCE
+    r = _edlib.edlibAlign(pattern, len(pattern), text, len(text), cfg)
+    d = r.editDistance
+    assert r.status == 0
+    _edlib.edlibFreeAlignResult(r)
+    return d

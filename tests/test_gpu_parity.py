@@ -217,6 +217,13 @@ def test_align_benchmark_harness(tmp_path):
             assert line == f"{sc}\t{cg}", algo
         assert "INACCURATE SCORE" not in r.stderr or algo == "edit-windowed"      # WindowEd is a bound, not exact
         assert "Alignments.Correct     100/100" in r.stderr
+    # --verbose: the stage-timer report of align_benchmark.c:116-128 (two batches of 64 / 36 pairs -> two laps)
+    r = subprocess.run([exe, "-a", "quicked", "-i", str(seq), "--batch-size", "64", "--verbose"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for name in ("Windowed Small", "Windowed Large", "Banded", "Align"):
+        assert f"=> Time.{name}" in r.stderr
+    assert [l for l in r.stderr.splitlines() if "Time.Windowed Small" in l][0].rstrip().endswith("(2 calls)")
+    assert [l for l in r.stderr.splitlines() if "Time.Align " in l][0].rstrip().endswith("(2 calls)")
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
@@ -804,3 +811,37 @@ def test_timers_gain_one_sample_per_align(golden):
         assert l_seen > 0 and b_seen > 0, (l_seen, b_seen, list(runs))
         assert a.timer.contents.time_ns.total > 0
         lib.quicked_free(C.byref(a))
+
+
+def test_planner_cuts_a_large_cigar_batch_before_it_runs_out_of_memory():
+    """a21: the device-pool planner.  400 k pairs of 10 kb through QuickEd + CIGAR need ~92 GB of fill checkpoints per
+    run; three pool sets of that do not fit 288 GB.  The planner must pick the rotation depth and the fill sub-batches
+    up front: no out-of-memory reclaim event, results identical to the oracle's, and the rate stays in the millions."""
+    import time
+    n = 400000
+    batch = datagen.generate(count=n, length=10000, error=0.05, seed=0x51CED)
+    before = capi.pool_stats()["reclaim_events"]
+    rb = capi.ResidentBatch(batch)
+    p = capi.make_params(algo=capi.QUICKED)
+    assert rb.run(p, sync=True) >= 0                      # sizes the pools
+    first = capi.pool_stats()
+    t0 = time.perf_counter()
+    steps = 4
+    for _ in range(steps):
+        assert rb.run(p, sync=False) >= 0
+    rb.sync()
+    dt = time.perf_counter() - t0
+    assert rb.run(p, sync=True) >= 0
+    s, st = rb.scores()
+    cg = rb.cigars()
+    stats = capi.pool_stats()
+    rb.close()
+    rate = n * steps / dt
+    print(f"planner: {rate / 1e6:.2f} M pairs/s, sets {stats['sets']}, fill sub-batches {stats['sub_batches']}, "
+          f"pools {stats['pool_bytes'] / 2**30:.1f} GiB, first run {first}")
+    assert stats["reclaim_events"] == before, stats
+    assert (st == capi.QUICKED_WIP).all()
+    for i in list(range(0, 48)) + list(range(n - 16, n)):
+        pt, tt = batch.pattern(i), batch.text(i)
+        assert (st[i], s[i], cg[i]) == O.oracle_align(pt, tt, algo=0), i
+    assert rate > 3.0e6, rate

@@ -75,3 +75,17 @@ def test_stage3_zero_cutoff_is_defined():
     st, sc, cg = O.oracle_align(p, t, trace=True, algo=0, bandwidth=1, window_size=2, overlap_size=1,
                                 hew_threshold=(10, 10), hew_percentage=(15, 15))[:3]
     assert st == 1 and sc == 31 and O.cigar_is_valid(p, t, cg)
+
+
+def test_oracle_and_generator_are_clean_under_asan_ubsan():
+    """`make -C oracle asan`: the oracle restatement + the seeded generator under AddressSanitizer / UBSan on the CPU
+    (the reference's build has the same switches, CMakeLists.txt:43-49; GPU sanitizers are unavailable on the pool)"""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "all checks passed under ASAN + UBSAN" in r.stdout

@@ -73,3 +73,59 @@ def test_sam_cigar_restatement_matches_the_reference_printer():
             buf = C.create_string_buffer(2 * len(ops) + 16)
             O.oracle().qo_cigar_sam(ops, len(ops), int(show), buf)
             assert buf.value.decode() == O.ref_sam_cigar(ops, show), (ops[:40], show)
+
+
+ONT_FILE = "/root/reference/tests/test_data/ONT.MiniION.1.seq"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(ONT_FILE), reason="the reference's real-data fixture is not on this machine")
+def test_ont_miniion_real_data_fixture(golden):
+    """the reference's one real-data test (tests/CMakeLists.txt:32): 508 596 x 505 792 bases.  The file itself is
+    reference data and stays out of this repository; golden.json holds hashes and the compiled reference's result."""
+    import hashlib
+    g = golden["ont_miniion_1"]
+    with open(ONT_FILE, "rb") as f:
+        l1, l2 = f.read().split(b"\n")[:2]
+    pat, txt = (l1[1:], l2[1:]) if l1[:1] == b">" else (l2[1:], l1[1:])
+    assert (len(pat), len(txt)) == (g["plen"], g["tlen"])
+    assert hashlib.sha256(pat).hexdigest() == g["pattern_sha256"] and hashlib.sha256(txt).hexdigest() == g["text_sha256"]
+    st, sc, cg = O.oracle_align(pat, txt, algo=0)
+    assert (st, sc) == (g["status"], g["score"])
+    assert len(cg) == g["cigar_len"] and hashlib.sha256(cg.encode()).hexdigest() == g["cigar_sha256"]
+    if O.have_edlib():
+        assert O.edlib_distance(pat, txt) == g["score"]          # tests/CMakeLists.txt:23-33: score == edlib
+
+
+@pytest.mark.skipif(not O.have_edlib(), reason="edlib (oracle/_ref/libedlib_ref.so) not built")
+def test_edlib_is_the_independent_exact_distance():
+    """edlib 1.2.6 as the third opinion -- against the oracle's own full-height DP and against the QuickEd
+    score of the oracle and of the compiled reference (upper-case ACGT input: edlib compares bytes)"""
+    for gen in (dict(count=30, length=1000, error=0.05, seed=401), dict(count=6, length=10000, error=0.05, seed=402),
+                dict(count=20, length=300, error=0.3, seed=403), dict(count=8, length=10000, error=0.05, seed=404, indels_num=4, indels_len=800)):
+        for p, t in datagen.generate(**gen).pairs():
+            d = O.edlib_distance(p, t)
+            assert O.oracle().qo_exact_distance(p, len(p), t, len(t)) == d
+            assert O.oracle_align(p, t, algo=0)[1] == d
+            assert O.ref_align(p, t, algo=0)[1] == d
+
+
+def test_hirschberg_real_splits_against_the_compiled_reference():
+    """the join is re-derived, so parity with the compiled reference on alignments
+    that REALLY split (bpm_hirschberg.c:63-65: ebb x tlen x 16 > 2^24) is pinned on more than two pairs: HIRSCHBERG at
+    bandwidth 15 with 25-50 kb reads, QUICKED at 100 kb, and indel-heavy pairs.  Score, status and CIGAR bytes."""
+    sets = [
+        (dict(algo=3, bandwidth=15), dict(count=6, length=25000, error=0.05, seed=501)),
+        (dict(algo=3, bandwidth=15), dict(count=5, length=40000, error=0.08, seed=502)),
+        (dict(algo=3, bandwidth=15), dict(count=4, length=50000, error=0.03, seed=503)),
+        (dict(algo=0), dict(count=4, length=100000, error=0.10, seed=504)),
+        (dict(algo=0), dict(count=4, length=60000, error=0.05, seed=505, indels_num=6, indels_len=1500)),
+        (dict(algo=3, bandwidth=15), dict(count=4, length=30000, error=0.04, seed=506, indels_num=3, indels_len=700)),
+    ]
+    splits = 0
+    for kw, gen in sets:
+        for p, t in datagen.generate(**gen).pairs():
+            st, sc, cg, tr = O.oracle_align(p, t, trace=True, **kw)
+            splits += tr["hirschberg_splits"]
+            assert tr["hirschberg_splits"] > 0, (kw, gen)
+            assert (st, sc, cg) == O.ref_align(p, t, **kw), (kw, gen, len(p), len(t))
+    assert splits >= 30

@@ -209,15 +209,27 @@ int main(int argc, char** argv) {
     }
     flush();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    quicked_free(&aligner);
     if (out) fclose(out);
     fprintf(stderr, "[Benchmark]\n=> Total.reads              %ld\n=> Time.Benchmark           %.3f s\n  => Time.Alignment         %.3f s (%.1f seq/s)\n",
             total, wall, align_s, align_s > 0 ? total / align_s : 0.0);
+    if (params.algo == QUICKED && verbose) {
+        // the stage timers of the aligner, as align_benchmark.c:116-128 prints them with --verbose (a batch is one lap
+        // of each stage timer: calls = batches that went through the stage)
+        auto line = [&](const char* name, const profiler_timer_t* t) {
+            const double s = t ? (double)t->time_ns.total * 1e-9 : 0.0;
+            fprintf(stderr, "  => Time.%-15s %9.3f s  (%6.2f %%) (%llu calls)\n", name, s, wall > 0 ? 100.0 * s / wall : 0.0,
+                    (unsigned long long)(t ? t->time_ns.samples : 0));
+        };
+        line("Windowed Small", aligner.timer_windowed_s);
+        line("Windowed Large", aligner.timer_windowed_l);
+        line("Banded", aligner.timer_banded);
+        line("Align", aligner.timer_align);
+    }
+    quicked_free(&aligner);
     if (!check.empty()) {
         fprintf(stderr, "[Accuracy]\n => Alignments.Correct     %ld/%ld (%.2f %%)\n", ok_cigar, checked, checked ? 100.0 * ok_cigar / checked : 0.0);
         if (check != "correct")
             fprintf(stderr, " => Score.Correct          %ld/%ld (%.2f %%)\n", ok_score, checked, checked ? 100.0 * ok_score / checked : 0.0);
     }
-    (void)verbose;
     return 0;
 }
