@@ -170,11 +170,12 @@ def cpu_baseline(batch, params_kw, workload, budget_s=15.0):
 # ---------------------------------------------------------------------------------------------------------------
 # end to end: host buffers -> HBM (H2D) -> run -> scores on the host (D2H), batch after batch
 # ---------------------------------------------------------------------------------------------------------------
-def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflight=2):
-    """`nbatches` batches of the same host data through `slots` resident batch objects: an uploader thread reloads
-    (quicked_batch_reload*, H2D) batch k+1.. while the main thread queues run k (sync = 0) and fetches the scores of run
-    k - inflight + 1 (quicked_batch_fetch, D2H).  Returns alignments/s over everything between the first reload and
-    the last fetch; batch creation (hipMalloc) and the first upload are warm-up."""
+def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflight=2, uploaders=2):
+    """`nbatches` batches of the same host data through `slots` resident batch objects: `uploaders` uploader threads
+    reload (quicked_batch_reload*, H2D) batches k+1.. (uploader u takes the batches with k % uploaders == u) while the main
+    thread queues run k (sync = 0) and fetches the scores of run k - inflight + 1 (quicked_batch_fetch, D2H).  Returns
+    alignments/s over everything between the first reload and the last fetch; batch creation (hipMalloc) and the first
+    upload are warm-up."""
     L = capi.lib()
     n = len(batch)
     frees = []
@@ -202,15 +203,17 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflig
     err = []
 
     tm = {"reload": 0.0, "run": 0.0, "fetch": 0.0}
+    lock = threading.Lock()
 
-    def uploader():
+    def uploader(u):
         try:
-            for k in range(nbatches):
+            for k in range(u, nbatches, uploaders):
                 if k >= slots:
                     fetched[k - slots].wait()
                 tu = time.perf_counter()
                 st = reload_(rbs[k % slots])
-                tm["reload"] += time.perf_counter() - tu
+                with lock:
+                    tm["reload"] += time.perf_counter() - tu
                 if st < 0:
                     raise RuntimeError(f"quicked_batch_reload: {st}")
                 uploaded[k].set()
@@ -221,8 +224,9 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflig
 
     checks = []
     t0 = time.perf_counter()
-    th = threading.Thread(target=uploader)
-    th.start()
+    ths = [threading.Thread(target=uploader, args=(u,)) for u in range(uploaders)]
+    for th in ths:
+        th.start()
 
     def finish(k):
         rb = rbs[k % slots]
@@ -247,7 +251,8 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflig
         if not err:
             finish(k)
     elapsed = time.perf_counter() - t0
-    th.join()
+    for th in ths:
+        th.join()
     for rb in rbs:
         rb.close()
     if src is not None:
@@ -259,7 +264,8 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=3, inflig
     assert all(c == expect_checksum for c in checks), "end-to-end scores differ from the resident run's"
     return {"value": n * nbatches / elapsed, "unit": "alignments/s", "batches": nbatches, "ms_per_batch": elapsed / nbatches * 1e3,
             "h2d_bytes_per_batch": nbytes, "h2d_GBs": nbytes * nbatches / elapsed / 1e9,
-            "host_ms_per_batch": {k: v / nbatches * 1e3 for k, v in tm.items()}, "slots": slots, "inflight": inflight}
+            "host_ms_per_batch": {k: v / nbatches * 1e3 for k, v in tm.items()}, "slots": slots, "inflight": inflight,
+            "uploader_threads": uploaders}
 
 
 def main():
@@ -275,7 +281,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--e2e-batches", type=int, default=12)
-    ap.add_argument("--e2e-slots", type=int, default=3)
+    ap.add_argument("--e2e-slots", type=int, default=4)
+    ap.add_argument("--e2e-uploaders", type=int, default=2)
     ap.add_argument("--e2e-inflight", type=int, default=2)
     ap.add_argument("--no-strong", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true",
@@ -365,7 +372,7 @@ def main():
     if not args.no_e2e and args.workload == "banded_score":
         e2e = {}
         for fmt in ("ascii_pinned", "2bit_pinned"):
-            r = e2e_leg(capi, batch, params, fmt, args.e2e_batches, checksum, slots=args.e2e_slots, inflight=args.e2e_inflight)
+            r = e2e_leg(capi, batch, params, fmt, args.e2e_batches, checksum, slots=args.e2e_slots, inflight=args.e2e_inflight, uploaders=args.e2e_uploaders)
             _, _, _, _, ext = shard.reduce_totals(dist, torch, device, 0, 0, 0, 0.0, extra_sum=(r["value"], r["h2d_GBs"]))
             r["value"], r["h2d_GBs"] = ext[0], ext[1]
             e2e[fmt] = r

@@ -453,7 +453,7 @@ struct BandLayout {
     std::vector<int32_t> nslots, nrows, nch, runs_cap;
     size_t ws_bytes = 0, mat_u4 = 0, runs_u32 = 0;
 };
-static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs) {
+static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs, bool tight_runs = false) {
     BandLayout B;
     const int ng = L.ngroups();
     B.ws_off.resize(ng); B.mat_off.resize(ng); B.runs_off.resize(ng);
@@ -470,9 +470,12 @@ static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs) {
             nr = std::max(nr, nw + nsl + 4);
             nch = std::max(nch, L.n[t] / 64 + 3);
             nmax = std::max(nmax, L.n[t]);
-            // an alignment with e edits has at most 2 e + 1 runs, and inside the parity domain e <= cutoff (k_traceback
-            // reports, instead of storing, a path that has more)
-            cap = std::max(cap, (int)std::min<int64_t>((int64_t)L.m[t] + L.n[t] + 2, (int64_t)2 * G.cutoff + 8));
+            // an alignment with e edits has at most 2 e + 1 runs.  tight_runs: the cutoff is known to be >= the distance
+            // (QuickEd's bound, Hirschberg's exact child distances), so e <= cutoff; k_traceback reports, instead of
+            // storing, a path that has more.  A user-chosen bandwidth promises nothing (a 35 %-error pair aligns at
+            // bandwidth 15 with 499 edits against a cutoff of 300): every op may be its own run
+            const int64_t every = (int64_t)L.m[t] + L.n[t] + 2;
+            cap = std::max(cap, (int)(tight_runs ? std::min<int64_t>(every, (int64_t)2 * G.cutoff + 8) : every));
         }
         B.nslots[g] = ns; B.nrows[g] = nr; B.nch[g] = nch; B.runs_cap[g] = cap;
         B.ws_off[g] = (int64_t)B.ws_bytes;
@@ -843,13 +846,34 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
 // all levels are then filled and traced back in sub-batches that fit the pool, and every
 // pair's leaves are stitched into one CIGAR in text order.
 // ---------------------------------------------------------------------------
+static double now_ms() {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+// BUFFER_SIZE_16M of bpm_hirschberg.c:65; QE_SPLIT_BYTES lowers it so tests can force many split levels on small inputs
+static uint64_t split_threshold() {
+    const char* e = getenv("QE_SPLIT_BYTES");
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 24);
+}
+static bool trace_on() { static int v = -1; if (v < 0) v = getenv("QE_TRACE") ? 1 : 0; return v == 1; }
+#define QE_TRACE_POINT(name) do { if (trace_on()) { double t__ = now_ms(); fprintf(stderr, "[qe] %-22s +%.3f ms\n", name, t__ - tr_last); tr_last = t__; } } while (0)
+
+static void reset_host_results(quicked_batch& B) {
+    B.score.assign((size_t)B.n, -1);
+    B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
+    B.cigar_off.assign((size_t)B.n, -1);
+    B.cigar_pool.clear();
+    B.check_ok.assign((size_t)B.n, -1);
+}
+
 struct HNode { int32_t pair, p0, m, t0, n, cutoff, left, right, leaf_task; };
 
 struct AlignStats { uint64_t fill_adv = 0, tb_steps = 0, score_adv = 0, splits = 0, leaves = 0; };
 
 static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool fetch, bool want_cigar,
                       size_t matrix_budget, uint64_t split_bytes, int32_t ok_status, int32_t** d_score_out, AlignStats* stats,
-                      PendingFetch* pf = nullptr) {
+                      PendingFetch* pf = nullptr, bool tight_runs = false) {
+    double tr_last = now_ms();
     std::vector<HNode> nodes;
     std::vector<int32_t> root_node, root_status;
     for (size_t t = 0; t < roots.pair.size(); ++t) {
@@ -906,7 +930,9 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         std::vector<int32_t> best, sl, sr, ok; std::vector<u32> advf, advv;
         d2h(best, J.o_best, ns, C.stream); d2h(sl, J.o_score_l, ns, C.stream); d2h(sr, J.o_score_r, ns, C.stream);
         d2h(ok, J.o_ok, ns, C.stream); d2h(advf, SF.O.adv, ns, C.stream); d2h(advv, SV.O.adv, ns, C.stream);
+        QE_TRACE_POINT("  level: queued");
         HIP_CHECK(hipStreamSynchronize(C.stream));
+        QE_TRACE_POINT("  level: half passes+join");
         C.scratch_p->release(mark);
         if (stats) { stats->score_adv += sum_u32(advf) + sum_u32(advv); stats->splits += ns; }
         frontier.clear();
@@ -947,7 +973,8 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             nd.leaf_task = (int32_t)LL.pair.size();
             LL.push(nd.pair, nd.p0, nd.m, nd.t0, nd.n, nd.cutoff, nd.n);
             SL.kind.push_back(0); SL.a.push_back(nd.leaf_task); SL.b.push_back(0);
-            root_runs += std::min<int64_t>((int64_t)nd.m + nd.n + 2, (int64_t)2 * host_geometry(nd.m, nd.n, nd.cutoff).cutoff + 8);   // band_layout's cap
+            root_runs += tight_runs ? std::min<int64_t>((int64_t)nd.m + nd.n + 2, (int64_t)2 * host_geometry(nd.m, nd.n, nd.cutoff).cutoff + 8)
+                                    : (int64_t)nd.m + nd.n + 2;                                                        // band_layout's cap
         }
         SL.off.push_back((int64_t)SL.kind.size());
         const HNode& rt = nodes[root_node[i]];
@@ -955,11 +982,12 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         SL.bound.push_back(cigar_bound_runs(rt.m, rt.n, root_runs, root_segs));
     }
     LL.pad();
+    QE_TRACE_POINT("  leaves listed");
     if (stats) stats->leaves += LL.pair.size();
     // ---- leaves: fill + traceback in sub-batches; runs and per-leaf outputs persist
     const size_t nt = LL.pair.size();
     const int ng = LL.ngroups();
-    const BandLayout lay = band_layout(LL, true, true);
+    const BandLayout lay = band_layout(LL, true, true, tight_runs);
     B.last_mat_bytes = lay.mat_u4 * 16;
     // what the stage takes from the pool besides the matrices: run buffers, string pool, per-task arrays, segment lists
     size_t fixed_bytes = lay.runs_u32 * 4 + (size_t)nt * 160 + SL.kind.size() * 16 + ((size_t)4 << 20);
@@ -1035,7 +1063,9 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         // the next sub-batch reuses this scratch: its kernels are behind this sub-batch's in the stream, no host wait
         if (sb + 2 < sub_start.size()) C.scratch_p->release(mark);
     }
+    QE_TRACE_POINT("  fill+traceback queued");
     const AlignOut AO = format_segments(B, C, SL, d_runs, d_runs_off, O.nruns, want_cigar);
+    QE_TRACE_POINT("  format queued");
     if (d_score_out) *d_score_out = AO.edits;
     if (pf && !fetch) {
         pf->kind = 2; pf->SL = std::move(SL); pf->AO = AO; pf->want_strings = want_cigar;
@@ -1084,26 +1114,6 @@ static void scatter_scores(quicked_batch& B, const TaskList& L, const std::vecto
 // ---------------------------------------------------------------------------
 // The batch entry point: dispatch on params->algo (quicked_align, quicked.c:405-437)
 // ---------------------------------------------------------------------------
-static double now_ms() {
-    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-}
-// BUFFER_SIZE_16M of bpm_hirschberg.c:65; QE_SPLIT_BYTES lowers it so tests can force many split levels on small inputs
-static uint64_t split_threshold() {
-    const char* e = getenv("QE_SPLIT_BYTES");
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 24);
-}
-static bool trace_on() { static int v = -1; if (v < 0) v = getenv("QE_TRACE") ? 1 : 0; return v == 1; }
-#define QE_TRACE_POINT(name) do { if (trace_on()) { double t__ = now_ms(); fprintf(stderr, "[qe] %-22s +%.3f ms\n", name, t__ - tr_last); tr_last = t__; } } while (0)
-
-static void reset_host_results(quicked_batch& B) {
-    B.score.assign((size_t)B.n, -1);
-    B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
-    B.cigar_off.assign((size_t)B.n, -1);
-    B.cigar_pool.clear();
-    B.check_ok.assign((size_t)B.n, -1);
-}
-
 static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
     double tr_last = now_ms();
     tl_device = B.device;
@@ -1138,7 +1148,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             const HGeom G = host_geometry(m, n, max_cutoff(p.bandwidth, m, n));
             const uint64_t full = (uint64_t)9 * (uint64_t)(n / 64 + 3) * (uint64_t)G.ebb * 16;
             need_mat += (size_t)std::min<uint64_t>(full, (uint64_t)18 << 20);             // per pair; splits cap a leaf at 16 MiB of matrix
-            need_fixed += (size_t)std::min<int64_t>((int64_t)m + n + 2, (int64_t)2 * G.cutoff + 8) * 15 + 512;
+            need_fixed += (size_t)(p.algo == QUICKED ? std::min<int64_t>((int64_t)m + n + 2, (int64_t)2 * G.cutoff + 8) : (int64_t)m + n + 2) * 15 + 512;
         }
         need_groups = (int)((B.n + 63) / 64);
     }
@@ -1325,7 +1335,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         AlignStats AS;
         // run_quicked ignores the Hirschberg status (quicked.c:290-291, A.7(8)); run_hirschberg returns it (149-160)
         run_align(B, C, LA, fetch, want_cigar, matrix_budget, split_threshold(), p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK,
-                  &B.d_score, &AS, pf);
+                  &B.d_score, &AS, pf, /* the bound is an upper bound of the distance */ p.algo == QUICKED);
         if (pf) pf->quicked = p.algo == QUICKED;
         qe_timer_stop(tl_timers.align);
         QE_TRACE_POINT("align launch(+fetch)");
