@@ -745,10 +745,16 @@ static AlignOut format_segments(const quicked_batch& B, Context& C, const SegLis
         ck.F = f; ck.P = pair_view(B, false); ck.root_pair = d_rootpair; ck.o_ok = A.ok;
         hipLaunchKernelGGL(k_check_segs, dim3(blocks), dim3(64), 0, C.stream, ck);
     }
-    hipLaunchKernelGGL(k_format_segs<false>, dim3(blocks), dim3(64), 0, C.stream, f);
+    // few alignments with many runs each (long reads): one wave per alignment; else one lane per alignment
+    const int wave_env = env_int("QE_FORMAT_WAVE", -1);      // tests force either form
+    const bool wave = B.cigar_style != 2 && nr > 0 &&
+                      (wave_env >= 0 ? wave_env != 0 : (nr <= 32768 && nseg > 0 && pool_bytes / nr >= 16384));
+    if (wave) hipLaunchKernelGGL(k_format_segs_wave<false>, dim3((unsigned)nr), dim3(64), 0, C.stream, f);
+    else hipLaunchKernelGGL(k_format_segs<false>, dim3(blocks), dim3(64), 0, C.stream, f);
     if (want_strings) {
         hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, C.stream, A.len, d_rootpair, A.str_off, A.total, (int)nr);
-        hipLaunchKernelGGL(k_format_segs<true>, dim3(blocks), dim3(64), 0, C.stream, f);
+        if (wave) hipLaunchKernelGGL(k_format_segs_wave<true>, dim3((unsigned)nr), dim3(64), 0, C.stream, f);
+        else hipLaunchKernelGGL(k_format_segs<true>, dim3(blocks), dim3(64), 0, C.stream, f);
     }
     return A;
 }
@@ -926,7 +932,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         J.F = (Gf >= 2) ? coop_state(SF) : J.Ffb; J.R = (Gf >= 2) ? coop_state(SV) : J.Rfb;
         J.o_best = C.scratch_p->take<int32_t>(ns); J.o_score_l = C.scratch_p->take<int32_t>(ns);
         J.o_score_r = C.scratch_p->take<int32_t>(ns); J.o_ok = C.scratch_p->take<int32_t>(ns);
-        hipLaunchKernelGGL(k_join, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, C.stream, J);
+        hipLaunchKernelGGL(k_join, dim3((unsigned)ns), dim3(64), 0, C.stream, J);       // one wave per node
         std::vector<int32_t> best, sl, sr, ok; std::vector<u32> advf, advv;
         d2h(best, J.o_best, ns, C.stream); d2h(sl, J.o_score_l, ns, C.stream); d2h(sr, J.o_score_r, ns, C.stream);
         d2h(ok, J.o_ok, ns, C.stream); d2h(advf, SF.O.adv, ns, C.stream); d2h(advv, SV.O.adv, ns, C.stream);

@@ -1588,26 +1588,38 @@ struct ColDist {
     }
 };
 
+// One wave per node: lane l scans the prefix lengths [l c, (l + 1) c) and the wave keeps the lexicographic minimum of
+// (sum, i) -- the FIRST minimising i, as a single scan would
 __global__ __launch_bounds__(64) void k_join(JoinArgs A) {
-    const int g = blockIdx.x, lane = threadIdx.x, j = g * 64 + lane;
+    const int j = blockIdx.x, lane = threadIdx.x;
     if (j >= A.nnodes) return;
     const int m = A.m[j];
     ColDist F, R;
     F.init((A.F.G > 1 && A.F.abort[j]) ? A.Ffb : A.F, j, m, A.n1[j]);
     R.init((A.R.G > 1 && A.R.abort[j]) ? A.Rfb : A.R, j, m, A.n2[j]);
-    int best = -1, best_i = -1, sl = 0, sr = 0;
-    for (int i = 0; i <= m; ++i) {
+    const int per = (m + 64) / 64;                              // ceil((m + 1) / 64)
+    const int lo = lane * per, hi = min(lo + per - 1, m);
+    int best = 0x7fffffff, best_i = 0x7fffffff, sl = 0, sr = 0;
+    for (int i = lo; i <= hi; ++i) {
         const int df = F.get(i);
         if (df < 0) continue;
         const int dr = R.get(m - i);
         if (dr < 0) continue;
         const int s = df + dr;
-        if (best < 0 || s < best) { best = s; best_i = i; sl = df; sr = dr; }
+        if (s < best) { best = s; best_i = i; sl = df; sr = dr; }
     }
-    A.o_best[j] = best_i;
-    A.o_score_l[j] = sl;
-    A.o_score_r[j] = sr;
-    A.o_ok[j] = best_i >= 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ob = __shfl_xor(best, o), oi = __shfl_xor(best_i, o), ol = __shfl_xor(sl, o), orr = __shfl_xor(sr, o);
+        if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; sl = ol; sr = orr; }
+    }
+    if (lane == 0) {
+        const bool ok = best != 0x7fffffff;
+        A.o_best[j] = ok ? best_i : -1;
+        A.o_score_l[j] = ok ? sl : 0;
+        A.o_score_r[j] = ok ? sr : 0;
+        A.o_ok[j] = ok ? 1 : 0;
+    }
 }
 
 // ===========================================================================
@@ -1699,6 +1711,99 @@ __global__ __launch_bounds__(64) void k_format_segs(SegFormatArgs A) {
 }
 template __global__ void k_format_segs<false>(SegFormatArgs);
 template __global__ void k_format_segs<true>(SegFormatArgs);
+
+// ---------------------------------------------------------------------------
+// The same formatter with one WAVE per alignment (few, long alignments: a 100 kb pair has ~30 k runs, and one lane
+// walking them twice is a 15 ms launch).  The alignment's runs in string order are one sequence (segment after segment,
+// a leaf's runs back to front); lane l takes an equal slice of it.  Inside a leaf neighbouring runs differ, so runs only
+// merge across segment borders: a slice's leading runs that continue the previous slice's last run belong to that
+// slice's owner, who reads on past its end.  Styles 0 and 1 only (style 2 folds X into M, which merges inside leaves).
+// ---------------------------------------------------------------------------
+struct SegCursor {
+    const SegFormatArgs* A; int64_t s0, s1;      // segments of this alignment
+    int64_t seg; int k;                          // current segment; runs left in it (counting down) / 1 for a literal
+    __device__ __forceinline__ int seg_runs(int64_t sg) const { return A->seg_kind[sg] == 1 ? (A->seg_b[sg] > 0 ? 1 : 0) : max(A->nruns[A->seg_a[sg]], 0); }
+    __device__ __forceinline__ void seek(int64_t idx) {      // position on run `idx` of the sequence (or past the end)
+        seg = s0;
+        while (seg < s1) { const int n = seg_runs(seg); if (idx < n) break; idx -= n; ++seg; }
+        k = (int)idx;
+    }
+    __device__ __forceinline__ bool valid() const { return seg < s1; }
+    __device__ __forceinline__ void get(int& op, int& len) const {
+        if (A->seg_kind[seg] == 1) { op = A->seg_a[seg]; len = A->seg_b[seg]; return; }
+        const int t = A->seg_a[seg];
+        const u32 r = A->runs[A->g_runs_off[t >> 6] + (t & 63) + (int64_t)(A->nruns[t] - 1 - k) * 64];
+        op = (int)(r & 3); len = (int)(r >> 2);
+    }
+    __device__ __forceinline__ void next() {
+        ++k;
+        while (seg < s1 && k >= seg_runs(seg)) { ++seg; k = 0; }
+    }
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_format_segs_wave(SegFormatArgs A) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= A.npairs) return;
+    SegCursor C; C.A = &A; C.s0 = A.seg_off[i]; C.s1 = A.seg_off[i + 1];
+    int64_t total_runs = 0; bool bad = false;
+    for (int64_t sg = C.s0 + lane; sg < C.s1; sg += 64) {
+        if (A.seg_kind[sg] != 1 && A.nruns[A.seg_a[sg]] < 0) bad = true;
+        total_runs += C.seg_runs(sg);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total_runs += __shfl_xor(total_runs, o);
+    if (__any(bad)) {
+        if (lane == 0) { if (WRITE) A.pool[A.str_off[i]] = '\0'; else { A.o_len[i] = 0; A.o_edits[i] = -1; A.o_nops[i] = 0; } }
+        return;
+    }
+    const int64_t per = (total_runs + 63) / 64, lo = min((int64_t)lane * per, total_runs), hi = min(lo + per, total_runs);
+    // my groups: start at the first run of my slice that does not continue the run before it; end past my slice while the
+    // following runs still continue my last group
+    RunMerger Mg; Mg.style = A.style;
+    auto walk = [&](auto&& sink) {
+        if (lo >= hi) return;
+        C.seek(lo);
+        int64_t idx = lo;
+        int prev_op = -1;
+        if (lo > 0) { SegCursor P = C; P.seek(lo - 1); int l; P.get(prev_op, l); }
+        bool started = false;
+        int cur_op = -1;
+        while (C.valid()) {
+            int op, len; C.get(op, len);
+            if (!started) {
+                if (idx >= hi) break;
+                if (op == prev_op) { ++idx; C.next(); continue; }                     // belongs to the previous slice's last group
+                started = true;
+            } else if (idx >= hi && op != cur_op) break;                              // past my slice and no longer my group
+            sink(op, len);
+            cur_op = op;
+            ++idx; C.next();
+        }
+    };
+    // pass A: my string length
+    walk([&](int op, int len) { Mg.template push<false>(op, len); });
+    Mg.template emit<false>();
+    int mine = Mg.total, edits = Mg.edits, nops = Mg.nops;
+    int off = mine;                                                   // inclusive scan -> exclusive offset
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(off, d); if (lane >= d) off += y; }
+    const int total = __shfl(off, 63);
+    off -= mine;
+    if (!WRITE) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { edits += __shfl_xor(edits, o); nops += __shfl_xor(nops, o); }
+        if (lane == 0) { A.o_len[i] = total; A.o_edits[i] = edits; A.o_nops[i] = nops; }
+        return;
+    }
+    RunMerger Wr; Wr.style = A.style; Wr.out = A.pool + A.str_off[i] + off;
+    walk([&](int op, int len) { Wr.template push<true>(op, len); });
+    Wr.template emit<true>();
+    for (int k = 0; k < Wr.nb; ++k) Wr.out[k] = (char)(Wr.buf >> (8 * k));       // the waiting characters, no terminator
+    if (lane == 0) A.pool[A.str_off[i] + total] = '\0';
+}
+template __global__ void k_format_segs_wave<false>(SegFormatArgs);
+template __global__ void k_format_segs_wave<true>(SegFormatArgs);
 
 // ===========================================================================
 // Validator (cigar_check_alignment, cigar.c:363-434): one lane per alignment walks its operations front

@@ -845,3 +845,53 @@ def test_planner_cuts_a_large_cigar_batch_before_it_runs_out_of_memory():
         pt, tt = batch.pattern(i), batch.text(i)
         assert (st[i], s[i], cg[i]) == O.oracle_align(pt, tt, algo=0), i
     assert rate > 3.0e6, rate
+
+
+@pytest.mark.parametrize("force", ["1", "0"])
+def test_wave_formatter_and_wave_join_forced(force, monkeypatch):
+    """the one-wave-per-alignment CIGAR formatter (long reads) against the one-lane form and the oracle: forced on
+    every CIGAR-producing path, through deep Hirschberg splits (many segments per alignment, runs merging across segment
+    borders), ragged / empty / non-ACGT pairs, and the SAM '=XID' style"""
+    import ctypes as C
+    monkeypatch.setenv("QE_FORMAT_WAVE", force)
+    monkeypatch.setenv("QE_SPLIT_BYTES", str(1 << 14))
+    lib = O.oracle()
+    for gen in (dict(count=90, length=2500, error=0.07, seed=931), dict(count=70, length=300, error=0.25, seed=932),
+                dict(count=20, length=9000, error=0.03, seed=933, indels_num=3, indels_len=400)):
+        batch = datagen.generate(**gen)
+        scores, status, cig, _ = gpu_batch(batch, algo=0)
+        for i, (p, t) in enumerate(batch.pairs()):
+            st, sc, cg, tr = O.oracle_align(p, t, trace=True, algo=0)      # the bound of the reference's stages
+            ops = C.create_string_buffer(len(p) + len(t) + 1)
+            n = C.c_int64()
+            hst = lib.qo_hirschberg(p, len(p), t, len(t), tr["bound"], 1 << 14, ops, C.byref(n), None)
+            if hst != O.OK:
+                continue        # a split that does not converge at this artificial threshold: partial results are unspecified (DESIGN.md 5)
+            buf = C.create_string_buffer(2 * n.value + 16)
+            lib.qo_cigar_rle(ops, n.value, buf)
+            assert cig[i] == buf.value.decode(), (gen, i)
+    monkeypatch.delenv("QE_SPLIT_BYTES")
+    for gen in (dict(count=70, length=2500, error=0.07, seed=935), dict(count=12, length=9000, error=0.03, seed=936, indels_num=3, indels_len=400)):
+        batch = datagen.generate(**gen)
+        for kw in (dict(algo=0), dict(algo=3, bandwidth=20), dict(algo=2, bandwidth=20), dict(algo=1, window_size=2), dict(algo=1)):
+            scores, status, cig, _ = gpu_batch(batch, **kw)
+            for i, (p, t) in enumerate(batch.pairs()):
+                assert (status[i], scores[i], cig[i]) == O.oracle_align(p, t, **kw), (gen, kw, i)
+    # byte identity with the oracle (same split threshold: the reference's) on ragged / empty / non-ACGT pairs
+    pairs = mixed_batch()
+    for kw in (dict(algo=0), dict(algo=2), dict(algo=1), dict(algo=3)):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            est, esc, ecg = O.oracle_align(p, t, **kw)
+            assert out[i][0] == est and (est < 0 or (out[i][1], out[i][2]) == (esc, ecg)), (kw, i)
+    rb = capi.ResidentBatch(datagen.generate(count=64, length=1200, error=0.1, seed=934))
+    rb.configure(cigar_style=1, check=True)
+    assert rb.run(capi.make_params(algo=0), sync=True) >= 0
+    got = rb.cigars()
+    assert (rb.check_results() == 1).all()
+    rb.close()
+    for (p, t), c in zip(datagen.generate(count=64, length=1200, error=0.1, seed=934).pairs(), got):
+        assert c == O.sam_cigar(O.oracle_align(p, t, algo=0)[2], True)
