@@ -519,6 +519,9 @@ static TaskOut take_out(Context& C, size_t nt) {
     o.nops = C.scratch_p->take<int32_t>(nt); o.edits = C.scratch_p->take<int32_t>(nt); o.len = C.scratch_p->take<int32_t>(nt);
     o.adv = C.scratch_p->take<u32>(nt); o.steps = C.scratch_p->take<u32>(nt);
     o.str_off = C.scratch_p->take<int64_t>(nt + 1);
+    // the work counters are summed over every slot of the list: padding slots (and tasks a kernel skips) count 0
+    HIP_CHECK(hipMemsetAsync(o.adv, 0, nt * sizeof(u32), C.stream));
+    HIP_CHECK(hipMemsetAsync(o.steps, 0, nt * sizeof(u32), C.stream));
     return o;
 }
 
@@ -701,10 +704,49 @@ struct PendingFetch {
     DevicePool* pool = nullptr; uint64_t generation = 0; int parity = 0;
 };
 
+// One wavefront per alignment (k_banded_wave) is for few, long alignments: up to ~1000 tasks every task gets a wave of its
+// own at once and the run takes one alignment's latency (measured, 10 kb reads: 4.2 ms against 5.1 ms for the
+// cooperative form; beyond ~2000 tasks, or for 1 kb reads, the other forms win: tools/small_n_probe.py).  Needs whole
+// passes (tfin == n: no stopped band to export) and a band that fits the wave.  QE_WAVE = 0 / 1 switches the form off /
+// forces it wherever it is eligible (tests).
+static bool wave_form_wanted(const TaskList& L) {
+    static const int max_env = env_int("QE_WAVE_MAX", 1024);
+    const int force = env_int("QE_WAVE", -1);
+    if (force == 0) return false;
+    size_t live = 0;
+    int n_max = 0;
+    for (size_t t = 0; t < L.pair.size(); ++t) {
+        if (L.pair[t] < 0) continue;
+        ++live;
+        n_max = std::max(n_max, L.n[t]);
+        if (L.tfin[t] != L.n[t] || host_geometry(L.m[t], L.n[t], L.cutoff[t]).ebb_local > 62) return false;
+    }
+    return live > 0 && (force == 1 || (live <= (size_t)max_env && n_max >= 4096));
+}
+
+static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskList& L, bool reversed, bool timed) {
+    ScoreLaunch S;
+    S.nt = L.pair.size();
+    S.T = upload_tasks(L, C);
+    S.O = take_out(C, S.nt);
+    BandedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P = pair_view(B, reversed); a.T = S.T.v;
+    a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
+    a.o_maxrow = S.O.len;
+    auto* ke = timed ? C.kernel_events() : nullptr;
+    if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
+    launch_groups(C, k_banded_wave, a, S.nt, 16, 0);                    // one wave per task
+    if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
+    return S;
+}
+
 static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
                              bool fetch, int32_t** d_score_out, PendingFetch* pf = nullptr) {
-    const int G = coop_lanes(L);
-    const ScoreLaunch S = (G >= 2) ? launch_banded_coop(B, C, L, reversed, G, true) : launch_banded_score(B, C, L, reversed, true);
+    const bool wave = wave_form_wanted(L);
+    const int G = wave ? 1 : coop_lanes(L);
+    const ScoreLaunch S = wave ? launch_banded_wave(B, C, L, reversed, true)
+                               : ((G >= 2) ? launch_banded_coop(B, C, L, reversed, G, true) : launch_banded_score(B, C, L, reversed, true));
     if (d_score_out) *d_score_out = S.O.score;
     if (pf && !fetch) {
         pf->kind = 1; pf->task_pair = L.pair; pf->d_score = S.O.score; pf->d_adv = S.O.adv; pf->counter_slot = 0;

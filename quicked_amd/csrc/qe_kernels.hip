@@ -1007,6 +1007,223 @@ __global__ __launch_bounds__(1024) void k_banded_coop(CoopArgs A) {
     }
 }
 
+// ===========================================================================
+// BandEd score-only, ONE WAVEFRONT PER ALIGNMENT (BASELINE.json's form; for few alignments: a single pair, a
+// handful of long reads -- where one lane per alignment leaves the chip empty and the latency of one lane is the run
+// time).  Lane j owns the block rows r = j (mod 64); row r works on text column c = step - r, so the rows of the band
+// are a systolic array skewed by one column per row: (r, c) needs (r - 1, c) -- the neighbour lane's carry bits of
+// the previous step, one v_mov_dpp wave_ror:1 each -- and (r, c - 1), the lane's own registers.  State never leaves
+// the registers: a row's Pv / Mv / scores[] entry / pattern planes live in its lane from the chunk it enters the band
+// (the reference's "new bottom block", bpm_banded.c:903-912) until the band leaves it behind.
+// The 64-column band bookkeeping (bpm_banded.c:889-922) is scalar code that runs when its inputs are complete: the top
+// rule of chunk k once row first+1 has finished the chunk (one step later than the old top row would start chunk k+1: that
+// row speculates "no cut" while the prologue lasts, which is harmless -- a cut drops it and the row below takes the
+// boundary carry), the bottom rule once row `last` has.  scores[] entries the rules read come by v_readlane.
+// Same cells, same values as k_banded<false>; needs the band to fit the wave (<= 62 slots).
+// ===========================================================================
+__device__ __forceinline__ int dpp_ror1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x13C, 0xf, 0xf, false); }   // lane i <- lane i-1, wraps
+// a ring of four band-edge values (slot numbers, < 256) packed into one register: an indexed private array -- and a
+// select chain, which the compiler turns into one -- would live in scratch memory
+struct Ring4 {
+    u32 v;
+    __device__ __forceinline__ int get(int k) const { return (int)((v >> (8 * (k & 3))) & 0xffu); }
+    __device__ __forceinline__ void set(int k, int x) { const int sh = 8 * (k & 3); v = (v & ~(0xffu << sh)) | ((u32)x << sh); }
+};
+
+__global__ __launch_bounds__(256) void k_banded_wave(BandedArgs A) {
+    const int t = __builtin_amdgcn_readfirstlane(QE_GROUP_INDEX()), lane = threadIdx.x & 63;     // one task per wave: uniform
+    if (t >= A.T.ntasks) return;
+    const int pair = A.T.pair[t];
+    if (pair < 0) return;
+    const int m = A.T.m[t], n = A.T.n[t], p0 = A.T.p0[t], t0 = A.T.t0[t], cut_in = A.T.cutoff[t], tfin = A.T.tfin[t];
+    const u64* __restrict__ pp = A.P.pl_p + A.P.pl_p_off[pair];
+    const u64* __restrict__ tp = A.P.pl_t + A.P.pl_t_off[pair];
+    (void)n;
+    const Geom G0 = band_geometry(m, A.T.n[t], cut_in);
+    const int g_cutoff = G0.cutoff, g_fin = G0.fin, prolog = G0.prolog;      // scalars, not a struct the lambda below would keep in memory
+    const int nw = (m + 63) >> 6, nsl = ((g_cutoff + 63) >> 6) + 1, lvl_last = (m - 1) & 63;
+    const int nfull = tfin >> 6;
+    // band edges (slot numbers first / last, as in the reference) of chunk k at index k & 3: at most two chunks are alive
+    // among the rows of the band and decisions run one chunk ahead
+    Ring4 fr{(u32)prolog}, lr{(u32)(nsl - 1)};
+    int dec_top = 1, dec_bot = 1;              // edges are decided for chunks < dec_top / < dec_bot
+    int maxrow = nsl - 1;
+    // lane state: the row I hold
+    int my_row = lane;
+    bool created = lane <= nsl - 1 - prolog;   // bpm_reset_search: slots prolog .. nsl-1 are rows 0 .. nsl-1-prolog
+    u64 P = QE_ONES, M = 0;
+    int sc = 64 * (lane + 1);                  // scores[r] = 64 (r + 1) (bpm_banded.c:180-197)
+    int sc_end = sc;                           // ... as it stood at the end of my row's last completed chunk: the rows above the
+                                               // deciding row are already a few columns into the next chunk when a rule reads them
+    u64 a = 0, b = 0, nn = 0, an = 0, bn = 0, nnn = 0;     // pattern planes of my row / of the row I will hold next
+    if (created && my_row < nw) load_planes(pp, p0 + 64 * my_row, a, b, nn);
+    if (lane == ((nsl - prolog) & 63) && nsl - prolog < nw) load_planes(pp, p0 + 64 * (nsl - prolog), an, bn, nnn);
+    int hP = 0, hM = 0;                        // my carry-out bits of the previous step
+    int sym = 0;                               // my text symbol of the previous step: code bit 0, code bit 1, not-ACGT
+    u32 adv = 0;
+    bool in_band = false, is_top = false;
+    // the text is read by ONE row, the top of the band (scalar loads of its chunk's plane words, the next chunk's
+    // prefetched); every other row takes its symbol from the row above, one step later, like its carries
+    int kq = -2;                               // chunk whose words Tc holds (-2: none, and not the predecessor of chunk 0)
+    u64 Tc0 = 0, Tc1 = 0, TcN = 0, Tn0 = 0, Tn1 = 0, TnN = 0;
+    auto text_words = [&](int k, u64& w0, u64& w1, u64& wn) {          // uniform k: the planes of text chunk k
+        w0 = 0; w1 = 0; wn = 0;
+        if (64 * k < tfin) {
+            const int bitpos = t0 + 64 * k, w = bitpos >> 6, sh = bitpos & 63;
+            const u64* q = tp + 3 * (int64_t)w;
+            w0 = q[0]; w1 = q[1]; wn = q[2];
+            if (sh) { w0 = (w0 >> sh) | (q[3] << (64 - sh)); w1 = (w1 >> sh) | (q[4] << (64 - sh)); wn = (wn >> sh) | (q[5] << (64 - sh)); }
+        }
+    };
+
+    auto decide = [&](int step) {
+        for (;;) {
+            bool did = false;
+            {   // top rule of chunk k -> first of chunk k + 1 (bpm_banded.c:889-901)
+                const int k = dec_top - 1;
+                if (k < nfull && dec_bot > k) {
+                    const int f = fr.get(k), l = lr.get(k), rlo = f + k - prolog;
+                    if (step >= 64 * k + 65 + rlo) {
+                        bool cut_lo = false;
+                        if ((f + 2 < l) && (g_fin > 64 * (f + 1)))
+                            cut_lo = __builtin_amdgcn_readlane(sc_end, (rlo + 1) & 63) + (g_fin - 64 * (f + 1)) > g_cutoff;
+                        int fnew = f;
+                        if (cut_lo && k >= prolog) fnew = f + 1;
+                        else if (!cut_lo && k < prolog) fnew = f - 1;
+                        fr.set(k + 1, fnew);
+                        ++dec_top;
+                        did = true;
+                    }
+                }
+            }
+            {   // bottom rule of chunk k -> the new bottom row, last of chunk k + 1 (bpm_banded.c:903-921)
+                const int k = dec_bot - 1;
+                if (k < nfull && dec_top > k + 1) {
+                    const int l = lr.get(k), pos_v = k - prolog, pos = l + pos_v;
+                    if (step >= 64 * k + 64 + pos) {
+                        const int spos = __builtin_amdgcn_readlane(sc_end, pos & 63);
+                        const int rb = pos + 1;
+                        if (lane == (rb & 63)) {
+                            my_row = rb; created = true; P = QE_ONES; M = 0; sc = spos + 64; sc_end = sc; in_band = false;
+                            a = an; b = bn; nn = nnn;
+                        }
+                        if (lane == ((rb + 1) & 63)) { an = 0; bn = 0; nnn = 0; if (rb + 1 < nw) load_planes(pp, p0 + 64 * (rb + 1), an, bn, nnn); }
+                        maxrow = max(maxrow, rb);
+                        const int fnew = fr.get(k + 1);
+                        bool cut_hi = false;
+                        if ((fnew + 2 < l) && (64 * (l - 1) > g_fin))
+                            cut_hi = __builtin_amdgcn_readlane(sc_end, (pos - 1) & 63) + (64 * (l - 1) - g_fin) > g_cutoff;
+                        lr.set(k + 1, (cut_hi || (pos_v + l >= nw)) ? l - 1 : l);
+                        ++dec_bot;
+                        did = true;
+                    }
+                }
+            }
+            if (!did) break;
+        }
+    };
+    // the step at which the next rule falls due (one of the two is always eligible while any is pending)
+    auto next_due = [&]() {
+        int due = 0x7fffffff;
+        const int k1 = dec_top - 1, k2 = dec_bot - 1;
+        if (k1 < nfull && dec_bot > k1) due = min(due, 64 * k1 + 65 + fr.get(k1) + k1 - prolog);
+        if (k2 < nfull && dec_top > k2 + 1) due = min(due, 64 * k2 + 64 + lr.get(k2) + k2 - prolog);
+        return __builtin_amdgcn_readfirstlane(due);
+    };
+
+    const bool hasN = (A.P.flags[pair] & FLAG_HAS_N) != 0;               // uniform: N / IUPAC symbols take the general Eq
+    int due = next_due();
+    const int steps = tfin + nw;               // row r runs column tfin - 1 at step tfin - 1 + r, r <= nw - 1
+    for (int step = 0; step < steps; ++step) {
+        if (step >= due) { decide(step); due = next_due(); }
+        const int inP = dpp_ror1(hP), inM = dpp_ror1(hM), relay = dpp_ror1(sym);
+        const int c = step - my_row;
+        const bool valid = created && my_row < nw && (u32)c < (u32)tfin;
+        const int bit = c & 63;
+        if (__any(valid && bit <= 1)) {
+            // entering a chunk (and the step after, when the one decision a row can be ahead of has landed): am I still in
+            // the band, am I its top row
+            const int kk = max(c >> 6, 0);
+            const int f = (kk < dec_top) ? fr.get(kk) : ((kk - 1 < prolog) ? fr.get(kk - 1) - 1 : fr.get(kk - 1));   // undecided: only the old top row
+            const int rlo = f + kk - prolog;
+            // bottom edge: only the row the bookkeeping has just created can lie below it (cut_hi / the stop rule keep
+            // the band from growing, bpm_banded.c:913-919), and that row enters its first chunk after the decision
+            const bool below = kk < dec_bot && my_row > lr.get(kk) + kk - prolog;
+            const bool ent = valid && bit <= 1;
+            in_band = ent ? (my_row >= rlo && !below) : in_band;
+            is_top = ent ? (my_row == rlo) : is_top;
+        }
+        const bool work = valid && in_band;
+        const u64 topmask = __ballot(work && is_top);
+        int fresh = 0;
+        if (topmask != 0) {                                            // uniform
+            const int tl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)topmask) - 1);
+            const int ctop = step - __builtin_amdgcn_readlane(my_row, tl);
+            const int ka = __builtin_amdgcn_readfirstlane(ctop >> 6), tb = __builtin_amdgcn_readfirstlane(ctop & 63);
+            if (ka != kq) {
+                if (ka == kq + 1) { Tc0 = Tn0; Tc1 = Tn1; TcN = TnN; }
+                else text_words(ka, Tc0, Tc1, TcN);
+                kq = ka;
+                text_words(ka + 1, Tn0, Tn1, TnN);                       // needed 64 steps from now
+            }
+            fresh = (int)((Tc0 >> tb) & 1) | ((int)((Tc1 >> tb) & 1) << 1) | ((int)((TcN >> tb) & 1) << 2);
+        }
+        sym = (work && is_top) ? fresh : relay;
+        hP = 0; hM = 0;
+        if (work) {
+            const u32 PHin = is_top ? 1u : (u32)inP, MHin = is_top ? 0u : (u32)inM;
+            u32 Plo = lo32(P), Phi = hi32(P), Mlo = lo32(M), Mhi = hi32(M), phhi, mhhi, phlo_bit = 0, mhlo_bit = 0;
+            const bool lastrow = my_row == nw - 1;                       // level_mask of the last block (bpm_banded.c:88-102)
+            if (!hasN) {
+                const u32 m0 = (u32)__builtin_amdgcn_sbfe(sym, 0, 1), m1 = (u32)__builtin_amdgcn_sbfe(sym, 1, 1);
+                const u32 elo = bitop3<0x90>(~(lo32(a) ^ m0), lo32(b), m1), ehi = bitop3<0x90>(~(hi32(a) ^ m0), hi32(b), m1);
+                if (__any(lastrow && lvl_last != 63)) {
+                    // the row whose exported bit is not bit 63 needs the whole horizontal delta words
+                    u64 Ph, Mh;
+                    block_step(mk64(elo, ehi), P, M, PHin, MHin, Ph, Mh);
+                    Plo = lo32(P); Phi = hi32(P); Mlo = lo32(M); Mhi = hi32(M);
+                    phhi = hi32(Ph); mhhi = hi32(Mh);
+                    const int lv = lastrow ? lvl_last : 63;
+                    phlo_bit = (u32)((Ph >> lv) & 1); mhlo_bit = (u32)((Mh >> lv) & 1);
+                } else {
+                    block_step_core(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, phhi, mhhi);
+                    phlo_bit = phhi >> 31; mhlo_bit = mhhi >> 31;
+                }
+            } else {
+                const u64 m0 = (u64)0 - (u64)(sym & 1), m1 = (u64)0 - (u64)((sym >> 1) & 1);
+                const u64 Eq = (sym & 4) ? nn : (~(a ^ m0) & ~(b ^ m1) & ~nn);
+                u64 Ph, Mh;
+                block_step(Eq, P, M, PHin, MHin, Ph, Mh);
+                Plo = lo32(P); Phi = hi32(P); Mlo = lo32(M); Mhi = hi32(M);
+                phhi = hi32(Ph); mhhi = hi32(Mh);
+                const int lv = lastrow ? lvl_last : 63;
+                phlo_bit = (u32)((Ph >> lv) & 1); mhlo_bit = (u32)((Mh >> lv) & 1);
+            }
+            P = mk64(Plo, Phi); M = mk64(Mlo, Mhi);
+            sc += (int)phlo_bit - (int)mhlo_bit;
+            hP = (int)(phhi >> 31); hM = (int)(mhhi >> 31);
+            if (bit == 63 || c == tfin - 1) { adv += (u32)(bit + 1); sc_end = sc; }      // a completed chunk: its block-advances, its score
+        }
+    }
+    decide(0x7fffffff);                        // the bookkeeping after the last full chunk (its new row counts for the read-out)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) adv += __shfl_xor(adv, o);
+    const int row = nw - 1;
+    int score = -1;
+    if (row <= maxrow) {
+        score = __builtin_amdgcn_readlane(sc, row & 63);
+        if (m & 63) score -= 64 - (m & 63);
+    }
+    if (lane == 0) {
+        A.o_score[t] = score;
+        A.o_first[t] = fr.get(nfull);
+        A.o_last[t] = lr.get(nfull);
+        A.o_posv[t] = nfull - prolog;
+        A.o_maxrow[t] = maxrow;
+        A.o_adv[t] = adv;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // RLE emitter shared by the tracebacks: ops arrive back to front
 // ---------------------------------------------------------------------------

@@ -895,3 +895,39 @@ def test_wave_formatter_and_wave_join_forced(force, monkeypatch):
     rb.close()
     for (p, t), c in zip(datagen.generate(count=64, length=1200, error=0.1, seed=934).pairs(), got):
         assert c == O.sam_cigar(O.oracle_align(p, t, algo=0)[2], True)
+
+
+def test_wave_per_alignment_kernel_forced(golden, monkeypatch):
+    """k_banded_wave (one wavefront per alignment, rows of the band as a systolic array) forced on every score-only
+    BandEd pass it is eligible for: golden vectors (incl. the geometry-dependent bandwidth-1 scores), random shapes and
+    bandwidths, ragged / N / lower-case input, the block-advance counters, and QuickEd's stage 3 (band doubling)"""
+    monkeypatch.setenv("QE_WAVE", "1")
+    for name in ("cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len50", "len63", "len64", "len65", "len128", "len130", "len1024", "err35_2kb"):
+        entry = golden["datasets"][name]
+        batch = datagen.generate(**entry["gen"])
+        for label, run in entry["runs"].items():
+            if not (run["params"].get("algo") == 2 and run["params"].get("only_score")) and run["params"].get("algo") != 0:
+                continue
+            scores, status, cig, _ = gpu_batch(batch, **run["params"])
+            assert status.tolist() == run["status"] and scores.tolist() == run["score"], (name, label)
+    for gen in (dict(count=130, length=1000, error=0.05, seed=301), dict(count=30, length=10000, error=0.05, seed=302),
+                dict(count=100, length=200, error=0.15, seed=303), dict(count=100, length=70, error=0.2, seed=304),
+                dict(count=40, length=3000, error=0.3, seed=305), dict(count=70, length=1, error=0, seed=306),
+                dict(count=70, length=5, error=2, seed=307), dict(count=20, length=4000, error=0.05, seed=308, indels_num=3, indels_len=300)):
+        batch = datagen.generate(**gen)
+        pairs = list(batch.pairs())
+        for bw in (1, 4, 15, 30):
+            scores, status, _, cnt = gpu_batch(batch, algo=2, only_score=True, bandwidth=bw)
+            adv = 0
+            for i, (p, t) in enumerate(pairs):
+                st, sc, _, tr = O.oracle_align(p, t, trace=True, algo=2, only_score=True, bandwidth=bw)
+                assert (status[i], scores[i]) == (st, sc), (gen, bw, i)
+                adv += tr["score_block_advances"]
+            assert cnt[0] == adv, (gen, bw)
+    pairs = mixed_batch()
+    al = capi.QuickedAligner()
+    al.setAlgorithm(capi.BANDED); al.setOnlyScore(True)
+    st, out = al.alignBatch(pairs)
+    for i, (p, t) in enumerate(pairs):
+        est, esc, _ = O.oracle_align(p, t, algo=2, only_score=True)
+        assert out[i][0] == est and (est < 0 or out[i][1] == esc), i

@@ -243,8 +243,56 @@ template <int VAR> static void step_row(const char* name, int K, int wps, int it
            per_simd, rate, r.clock_ghz, r.wall_ms);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Part C: does the VGPR bank of the three sources of a v_bitop3 matter?  Eight independent chains on physical
+// registers; SAME: the three sources of every instruction are congruent mod 4 (v40 v44 v48 ...), DIFF: they differ.
+// ---------------------------------------------------------------------------------------------------------------
+#define BK_SAME(d, a, b) "v_bitop3_b32 v" #d ", v" #d ", v" #a ", v" #b " bitop3:0x96\n\t"
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bank(u32* out, Stamp* stamps, int iters) {
+    extern __shared__ uint4 pin[];
+    const uint64_t c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 0) {          // dst/src0 v40..v47, src1 / src2 in the SAME bank as src0
+            asm volatile(BK_SAME(40, 48, 56) BK_SAME(41, 49, 57) BK_SAME(42, 50, 58) BK_SAME(43, 51, 59)
+                         BK_SAME(44, 52, 60) BK_SAME(45, 53, 61) BK_SAME(46, 54, 62) BK_SAME(47, 55, 63)
+                         BK_SAME(40, 52, 60) BK_SAME(41, 53, 61) BK_SAME(42, 54, 62) BK_SAME(43, 55, 63)
+                         BK_SAME(44, 48, 56) BK_SAME(45, 49, 57) BK_SAME(46, 50, 58) BK_SAME(47, 51, 59)
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                             "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+        } else if (MODE == 1) {   // src1 / src2 in two OTHER banks
+            asm volatile(BK_SAME(40, 49, 58) BK_SAME(41, 50, 59) BK_SAME(42, 51, 56) BK_SAME(43, 48, 57)
+                         BK_SAME(44, 53, 62) BK_SAME(45, 54, 63) BK_SAME(46, 55, 60) BK_SAME(47, 52, 61)
+                         BK_SAME(40, 53, 62) BK_SAME(41, 54, 63) BK_SAME(42, 55, 60) BK_SAME(43, 52, 61)
+                         BK_SAME(44, 49, 58) BK_SAME(45, 50, 59) BK_SAME(46, 51, 56) BK_SAME(47, 48, 57)
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                             "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+        } else {                  // two sources only (v_xor_b32 e32 encoding), same bank / -- reference
+            asm volatile("v_xor_b32 v40, v40, v48\n\tv_xor_b32 v41, v41, v49\n\tv_xor_b32 v42, v42, v50\n\tv_xor_b32 v43, v43, v51\n\t"
+                         "v_xor_b32 v44, v44, v52\n\tv_xor_b32 v45, v45, v53\n\tv_xor_b32 v46, v46, v54\n\tv_xor_b32 v47, v47, v55\n\t"
+                         "v_xor_b32 v40, v40, v52\n\tv_xor_b32 v41, v41, v53\n\tv_xor_b32 v42, v42, v54\n\tv_xor_b32 v43, v43, v55\n\t"
+                         "v_xor_b32 v44, v44, v48\n\tv_xor_b32 v45, v45, v49\n\tv_xor_b32 v46, v46, v50\n\tv_xor_b32 v47, v47, v51\n\t"
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        }
+    }
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)c1;
+    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c1 - c0, t1 - t0};
+}
+template <int MODE> static void bank_row(const char* name, int wps) {
+    const int iters = 12000;
+    auto launch = [&](int blocks, size_t lds, bool warm) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bank<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((k_bank<MODE>), dim3(blocks), dim3(256), lds, 0, g_out, g_stamps, warm ? 8 : iters);
+    };
+    const Result r = measure(launch, wps);
+    const double instr = (double)iters * 16;
+    printf("%-44s w=%d  wave %6.2f cyc/instr   chip-wall %6.2f cyc/instr/SIMD   clock %.2f GHz\n", name, wps, r.cyc_wave / instr,
+           r.wall_ms * 1e-3 * r.clock_ghz * 1e9 / (instr * wps), r.clock_ghz);
+}
+
 int main(int argc, char** argv) {
-    const char* what = argc > 1 ? argv[1] : "AB";
+    const char* what = argc > 1 ? argv[1] : "ABC";
     hipMalloc(&g_out, (size_t)CUS * 8 * 256 * 4);
     hipMalloc(&g_stamps, (size_t)CUS * 8 * 4 * sizeof(Stamp));
     if (strchr(what, 'A')) {
@@ -254,6 +302,14 @@ int main(int argc, char** argv) {
         rate_op<ASHR>(false); rate_op<MOV>(false); rate_op<ALIGNBIT>(false); rate_op<BFE_U>(false); rate_op<BFE_I>(false);
         rate_op<LSHL_OR>(false); rate_op<OR3>(false); rate_op<AND_OR>(false); rate_op<ADD3>(false); rate_op<BCNT>(false);
         rate_op<BFREV>(false); rate_op<PERM>(false); rate_op<CNDMASK>(false); rate_op<LSHL_B64>(false);
+    }
+    if (strchr(what, 'C')) {
+        printf("# Part C: VGPR banks of the sources (8 independent chains, physical registers)\n");
+        for (int w : {1, 2, 4}) {
+            bank_row<0>("v_bitop3_b32, 3 sources in ONE bank", w);
+            bank_row<1>("v_bitop3_b32, 3 sources in THREE banks", w);
+            bank_row<2>("v_xor_b32 (2 sources, 32-bit encoding)", w);
+        }
     }
     if (strchr(what, 'B')) {
         printf("# Part B: block-step loops of qe_kernels.hip on registers (no memory in the loop)\n");
