@@ -308,14 +308,23 @@ def main():
     dist = None
     torch = None
     device = None
+    # test hooks (tests/test_gpu_parity.py runs the whole N = 2 path on a 1-GPU box): QE_BENCH_SHARE_GPU=1 puts every rank
+    # on device 0, QE_BENCH_BACKEND=gloo reduces over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    share = os.environ.get("QE_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("QE_BENCH_BACKEND", "nccl")
+    if share:
+        local_rank = 0
     if world > 1 or os.environ.get("QE_FORCE_DIST"):
         import torch
         import torch.distributed as dist
         if torch.cuda.device_count() <= local_rank:
             sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, this node exposes {torch.cuda.device_count()}")
         torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            device = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)                    # reductions on host tensors (device = None)
 
     from quicked_amd import capi, datagen
     if capi.lib().quicked_set_device(local_rank) < 0:
@@ -332,6 +341,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         rb.sync()
+    parallelism = f"pairs sharded over {world} GPU(s), no data-path collective" + (" [test: ranks share device 0]" if share else "")
 
     def timed_resident(first, count, steps, warmup):
         """the contract's loop: `warmup` untimed steps, then exactly `steps` steps between two barrier + synchronize"""
@@ -435,7 +445,7 @@ def main():
                                    f"bandwidth {args.bandwidth} %, seeded generator (SURVEY 8d), ASCII already in HBM when the clock "
                                    "starts, scores left in HBM (end-to-end rates: e2e)",
                        "pairs_per_gpu": args.pairs, "length": args.length, "error": args.error,
-                       "bandwidth": args.bandwidth, "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
+                       "bandwidth": args.bandwidth, "parallelism": parallelism},
             "roofline": dict({"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,

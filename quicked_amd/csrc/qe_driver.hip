@@ -175,6 +175,7 @@ struct Context {
     bool memory_tight = false;               // a pool had to take the others' memory once: no more rotation on this thread
     int last_na = 0, last_sub_batches = 0;   // what the planner chose for the last run (quicked_pool_stats)
     size_t pool_budget = 0;                  // bytes one A pool may hold in this run (plan_pools)
+    size_t seen_free = 0, seen_total = 0;    // last hipMemGetInfo reading of this device
     hipStream_t& sa() { return stream_a2[ai]; }
     DevicePool& pa() { return pool_a2[ai]; }
     DevicePool* scratch_p = nullptr;         // the current phase's pool
@@ -434,14 +435,29 @@ struct DevTasks {
     TaskView v;
     int32_t *pair, *p0, *m, *t0, *n, *cutoff, *tfin;
 };
+// one upload of raw bytes through the pinned stage of the run (or a plain async copy when staging is off)
+static void h2d_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    Context* C = tl_ctx;
+    if (C && C->staging && s == C->sa()) {
+        uint8_t* st = C->stage[C->si].take(bytes);
+        memcpy(st, src, bytes);
+        HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+}
+// the seven arrays of a task list in ONE device block and ONE copy (a copy costs ~5-10 us of host time whatever its size)
 static DevTasks upload_tasks(const TaskList& L, Context& C) {
     DevTasks d;
     const size_t nt = L.pair.size();
-    d.pair = C.scratch_p->take<int32_t>(nt); d.p0 = C.scratch_p->take<int32_t>(nt); d.m = C.scratch_p->take<int32_t>(nt);
-    d.t0 = C.scratch_p->take<int32_t>(nt); d.n = C.scratch_p->take<int32_t>(nt); d.cutoff = C.scratch_p->take<int32_t>(nt);
-    d.tfin = C.scratch_p->take<int32_t>(nt);
-    h2d(d.pair, L.pair, C.stream); h2d(d.p0, L.p0, C.stream); h2d(d.m, L.m, C.stream); h2d(d.t0, L.t0, C.stream);
-    h2d(d.n, L.n, C.stream); h2d(d.cutoff, L.cutoff, C.stream); h2d(d.tfin, L.tfin, C.stream);
+    int32_t* blk = C.scratch_p->take<int32_t>(7 * nt);
+    d.pair = blk; d.p0 = blk + nt; d.m = blk + 2 * nt; d.t0 = blk + 3 * nt; d.n = blk + 4 * nt; d.cutoff = blk + 5 * nt; d.tfin = blk + 6 * nt;
+    static thread_local std::vector<int32_t> host;
+    host.resize(7 * nt);
+    const std::vector<int32_t>* src[7] = {&L.pair, &L.p0, &L.m, &L.t0, &L.n, &L.cutoff, &L.tfin};
+    for (int q = 0; q < 7; ++q) memcpy(host.data() + q * nt, src[q]->data(), nt * sizeof(int32_t));
+    h2d_bytes(blk, host.data(), 7 * nt * sizeof(int32_t), C.stream);
     d.v.ntasks = (int32_t)nt; d.v.pair = d.pair; d.v.p0 = d.p0; d.v.m = d.m; d.v.t0 = d.t0; d.v.n = d.n;
     d.v.cutoff = d.cutoff; d.v.tfin = d.tfin;
     return d;
@@ -477,6 +493,9 @@ static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs, bool
             const int64_t every = (int64_t)L.m[t] + L.n[t] + 2;
             cap = std::max(cap, (int)(tight_runs ? std::min<int64_t>(every, (int64_t)2 * G.cutoff + 8) : every));
         }
+        // the fill records the band edges of every chunk as int16 (cf / cl): a band of more than 32 k blocks (a leaf of
+        // ~14 Mb at 15 % bandwidth -- Hirschberg splits long before that) is refused, not silently truncated
+        if (fill && ns > 32760) throw HipError{hipErrorInvalidValue, "band of more than 32760 blocks: not supported", __LINE__};
         B.nslots[g] = ns; B.nrows[g] = nr; B.nch[g] = nch; B.runs_cap[g] = cap;
         B.ws_off[g] = (int64_t)B.ws_bytes;
         size_t bytes = (size_t)2 * (ns + 1) * 64 * 8 + (size_t)nr * 64 * 4 + (size_t)2 * nch * 64 * 2;
@@ -498,12 +517,19 @@ static DevLayout upload_layout(const BandLayout& B, Context& C) {
     d.ws = C.scratch_p->take<uint8_t>(B.ws_bytes);
     d.mat = C.scratch_p->take<uint4>(B.mat_u4);
     d.runs = C.scratch_p->take<u32>(B.runs_u32);
-    d.ws_off = C.scratch_p->take<int64_t>(ng); d.mat_off = C.scratch_p->take<int64_t>(ng); d.runs_off = C.scratch_p->take<int64_t>(ng);
-    d.nslots = C.scratch_p->take<int32_t>(ng); d.nrows = C.scratch_p->take<int32_t>(ng); d.nch = C.scratch_p->take<int32_t>(ng);
-    d.runs_cap = C.scratch_p->take<int32_t>(ng);
-    h2d(d.ws_off, B.ws_off, C.stream); h2d(d.mat_off, B.mat_off, C.stream); h2d(d.runs_off, B.runs_off, C.stream);
-    h2d(d.nslots, B.nslots, C.stream); h2d(d.nrows, B.nrows, C.stream); h2d(d.nch, B.nch, C.stream);
-    h2d(d.runs_cap, B.runs_cap, C.stream);
+    // three int64 + four int32 arrays per group: one device block, one copy
+    uint8_t* blk = C.scratch_p->take<uint8_t>(ng * 40);
+    d.ws_off = (int64_t*)blk; d.mat_off = d.ws_off + ng; d.runs_off = d.mat_off + ng;
+    d.nslots = (int32_t*)(d.runs_off + ng); d.nrows = d.nslots + ng; d.nch = d.nrows + ng; d.runs_cap = d.nch + ng;
+    static thread_local std::vector<uint8_t> host;
+    host.resize(ng * 40);
+    if (ng) {
+        uint8_t* h = host.data();
+        memcpy(h, B.ws_off.data(), ng * 8); memcpy(h + ng * 8, B.mat_off.data(), ng * 8); memcpy(h + ng * 16, B.runs_off.data(), ng * 8);
+        memcpy(h + ng * 24, B.nslots.data(), ng * 4); memcpy(h + ng * 28, B.nrows.data(), ng * 4);
+        memcpy(h + ng * 32, B.nch.data(), ng * 4); memcpy(h + ng * 36, B.runs_cap.data(), ng * 4);
+        h2d_bytes(blk, h, ng * 40, C.stream);
+    }
     return d;
 }
 
@@ -1177,8 +1203,12 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // BandEd, 4.70 -> 5.31 M/s QuickEd + CIGAR against two; four are slower again).  Two when three fill matrices of the
     // size this batch needed last time would not fit (config 4: 94 GB each): sub-batching the fill costs more.
     static const int na_env = env_int("QE_NA", 0);
-    size_t free0 = 0, total0 = 0;
-    HIP_CHECK(hipMemGetInfo(&free0, &total0));
+    // small batches (single quicked_align calls) plan with the last reading: the query costs tens of microseconds
+    size_t free0 = C.seen_free, total0 = C.seen_total;
+    if (C.seen_total == 0 || B.arena_bytes > ((size_t)64 << 20)) {
+        HIP_CHECK(hipMemGetInfo(&free0, &total0));
+        C.seen_free = free0; C.seen_total = total0;
+    }
     // ---- the device-pool planner (replaces mm_allocator's "never fails" arena, mm_allocator.c:251-334, by a budget):
     // how many {stream, pool, planes} sets rotate, and how many bytes one pool may hold, from what this batch's last
     // CIGAR run needed (or, first time, from a bandwidth-based estimate).  A run whose fill matrices do not fit its

@@ -931,3 +931,33 @@ def test_wave_per_alignment_kernel_forced(golden, monkeypatch):
     for i, (p, t) in enumerate(pairs):
         est, esc, _ = O.oracle_align(p, t, algo=2, only_score=True)
         assert out[i][0] == est and (est < 0 or out[i][1] == esc), i
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path for real: two ranks started by torch.distributed.run exactly as the driver starts them,
+    sharing this box's one GPU (test hooks QE_BENCH_SHARE_GPU / QE_BENCH_BACKEND=gloo; RCCL refuses two ranks on one
+    device).  The shards must add up: the 2-rank weak run sees pairs [0, 2 n) and its checksum equals a 1-rank run over
+    the same 2 n pairs; the strong leg splits n pairs over the ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 3000
+    common = ["--steps", "2", "--warmup", "1", "--length", "2000", "--no-cpu-baseline", "--e2e-batches", "3"]
+    env = dict(os.environ, QE_BENCH_SHARE_GPU="1", QE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", str(n)] + common,
+                        capture_output=True, text=True, env=env, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--pairs", str(2 * n), "--no-e2e"] + common,
+                        capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["value"] > 0
+    assert two["score_checksum"] == one["score_checksum"]                       # shard-of-2 == whole
+    assert abs(two["gcups"] / two["value"] - one["gcups"] / one["value"]) < 1e-6 * one["gcups"] / one["value"]
+    assert two["strong"]["total_pairs"] == n and two["strong"]["pairs_per_gpu"] == n // 2 and two["strong"]["value"] > 0
+    assert two["e2e"]["2bit_pinned"]["value"] > 0 and two["e2e"]["ascii_pinned"]["value"] > 0
+    assert "cpu_baseline" not in two

@@ -1,22 +1,52 @@
-"""per-call cost of the drop-in single-pair path (quicked_new / quicked_align / quicked_free per pair,
-as tools/align_benchmark/benchmark/benchmark_edit.c:45-87 does)"""
-import os, sys, time, ctypes as C
+"""per-call cost of the drop-in single-pair path (quicked_new / quicked_align / quicked_free per pair, as
+tools/align_benchmark/benchmark/benchmark_edit.c:45-87 does), and BASELINE config 1 (1000 pairs of 1 kb, BandEd
+score-only) through that per-pair loop and through one batch call.  Median and minimum over the calls after a warm-up."""
+import os, sys, time, ctypes as C, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from quicked_amd import capi, datagen
 lib = capi.lib()
-for length, algo, only in ((1000, capi.QUICKED, False), (1000, capi.BANDED, True), (10000, capi.QUICKED, False), (10000, capi.BANDED, True)):
-    pairs = list(datagen.generate(200, length, 0.05, seed=3).pairs())
+
+
+def once(p, pt):
+    a = capi.Aligner()
+    lib.quicked_new(C.byref(a), C.byref(p))
+    lib.quicked_align(C.byref(a), pt[0], len(pt[0]), pt[1], len(pt[1]))
+    s = a.score
+    lib.quicked_free(C.byref(a))
+    return s
+
+
+for length, algo, only in ((1000, capi.BANDED, True), (1000, capi.QUICKED, False), (10000, capi.BANDED, True), (10000, capi.QUICKED, False)):
+    pairs = list(datagen.generate(300, length, 0.05, seed=3).pairs())
     p = capi.make_params(algo=algo, only_score=only)
-    def once(pt):
-        a = capi.Aligner()
-        lib.quicked_new(C.byref(a), C.byref(p))
-        lib.quicked_align(C.byref(a), pt[0], len(pt[0]), pt[1], len(pt[1]))
-        s = a.score
-        lib.quicked_free(C.byref(a))
-        return s
-    once(pairs[0])
-    t0 = time.perf_counter()
-    for pt in pairs: once(pt)
-    dt = (time.perf_counter() - t0) / len(pairs)
-    print(f"len {length} algo {algo} only_score {only}: {dt*1e3:.3f} ms per new+align+free")
+    for pt in pairs[:40]:
+        once(p, pt)                                       # warm: code objects, pools, clocks
+    ts = []
+    for pt in pairs[40:]:
+        t0 = time.perf_counter(); once(p, pt); ts.append(time.perf_counter() - t0)
+    print(f"len {length:6d} {'BandEd score-only' if only else 'QuickEd + CIGAR  '}: median {statistics.median(ts)*1e3:7.3f} ms  min {min(ts)*1e3:7.3f} ms per new+align+free")
+
+# BASELINE config 1: 1000 pairs of 1 kb at 5 %, BandEd score-only
+b = datagen.generate(1000, 1000, 0.05)
+pairs = list(b.pairs())
+p = capi.make_params(algo=capi.BANDED, only_score=True)
+for pt in pairs[:50]:
+    once(p, pt)
+t0 = time.perf_counter()
+s_loop = [once(p, pt) for pt in pairs]
+t_loop = time.perf_counter() - t0
+al = capi.QuickedAligner(); al.setAlgorithm(capi.BANDED); al.setOnlyScore(True)
+al.alignBatch(pairs)
+t0 = time.perf_counter(); st, out = al.alignBatch(pairs); t_batch = time.perf_counter() - t0
+assert [o[1] for o in out] == s_loop
+rb = capi.ResidentBatch(b)
+for _ in range(4):
+    rb.run(p, sync=True)
+t0 = time.perf_counter()
+for _ in range(20):
+    rb.run(p, sync=True)
+t_res = (time.perf_counter() - t0) / 20
+rb.close()
+print(f"config 1 (1000 x 1 kb, BandEd score-only): per-pair loop {t_loop*1e3:.1f} ms ({1000/t_loop:,.0f} pairs/s), "
+      f"one quicked_align_batch call {t_batch*1e3:.2f} ms ({1000/t_batch:,.0f} pairs/s), resident batch run {t_res*1e3:.3f} ms ({1000/t_res:,.0f} pairs/s)")
