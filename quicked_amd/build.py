@@ -105,9 +105,21 @@ def build_valu_rate(force=False):
     """tools/valu_rate.hip: per-instruction VALU issue rates of gfx950 (the table behind DESIGN.md 4.1)"""
     src = os.path.join(ROOT, "tools", "valu_rate.hip")
     os.makedirs(os.path.dirname(VALU_RATE), exist_ok=True)
-    if force or _newer(VALU_RATE, [src]):
+    if force or _newer(VALU_RATE, [src, os.path.join(CSRC, "qe_kernels.hip"), os.path.join(CSRC, "qe_types.h")]):
         _run(["hipcc", "--offload-arch=gfx950", "-O3", "-w", src, "-o", VALU_RATE])
     return VALU_RATE
+
+
+PMC_CALIB = os.path.join(ROOT, "tools", "bin", "pmc_calib")
+
+
+def build_pmc_calib(force=False):
+    """tools/pmc_calib.hip: known-byte-count streams that calibrate FETCH_SIZE / WRITE_SIZE per access width"""
+    src = os.path.join(ROOT, "tools", "pmc_calib.hip")
+    os.makedirs(os.path.dirname(PMC_CALIB), exist_ok=True)
+    if force or _newer(PMC_CALIB, [src]):
+        _run(["hipcc", "--offload-arch=gfx950", "-O3", "-w", src, "-o", PMC_CALIB])
+    return PMC_CALIB
 
 
 def build_all(force=False):
@@ -116,3 +128,4 @@ def build_all(force=False):
     build_harness(force)
     build_ref_callers(force)
     build_valu_rate(force)
+    build_pmc_calib(force)

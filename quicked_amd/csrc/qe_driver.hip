@@ -96,6 +96,14 @@ struct DevicePool {
         top += bytes;
         return p;
     }
+    // One allocation up front for a run whose needs are known (the planner's figures): bump requests then never grow the
+    // pool 4 GB at a time (a 94 GB fill matrix used to cost ~25 hipMallocs and seconds on a batch's first runs)
+    void reserve(size_t bytes) {
+        size_t room = 0;
+        for (size_t i = cur; i < chunks.size(); ++i) room += (i == cur) ? chunks[i].cap - top : chunks[i].cap;
+        if (room >= bytes) return;
+        add_chunk(bytes - room + ((size_t)64 << 20));
+    }
     // Grow to the chunk list of a pool that serves the same request sequence (the other A pool), so that the run
     // which first uses this one does not pay for its allocations; skipped when memory is short.
     void mirror(const DevicePool& o) {
@@ -1090,6 +1098,17 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         sub_start.push_back(ng);
     }
     C.last_sub_batches = (int)sub_start.size() - 1;
+    {   // what is still to be taken from the pool: per-task arrays, run buffers, strings, one sub-batch of matrices
+        size_t sub_max = 0;
+        for (size_t sb = 0; sb + 1 < sub_start.size(); ++sb) {
+            size_t b = 0;
+            for (int g = sub_start[sb]; g < sub_start[sb + 1]; ++g)
+                b += (size_t)((g + 1 < ng ? lay.ws_off[g + 1] : (int64_t)lay.ws_bytes) - lay.ws_off[g]) +
+                     16 * (size_t)((g + 1 < ng ? lay.mat_off[g + 1] : (int64_t)lay.mat_u4) - lay.mat_off[g]);
+            sub_max = std::max(sub_max, b);
+        }
+        if (fixed_bytes + sub_max > ((size_t)1 << 30)) C.scratch_p->reserve(fixed_bytes + sub_max);
+    }
     const DevTasks T = upload_tasks(LL, C);
     const TaskOut O = take_out(C, nt);
     int64_t* d_ws_off = C.scratch_p->take<int64_t>(ng + 1); int64_t* d_mat_off = C.scratch_p->take<int64_t>(ng + 1);

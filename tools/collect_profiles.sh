@@ -10,19 +10,19 @@ for wl in $wls; do
   case $wl in
     banded_score) args="--workload banded_score"; steps=10;;
     quicked)      args="--workload quicked"; steps=10;;
-    cfg4)         args="--workload quicked --pairs 10000 --length 100000 --error 0.1"; steps=3;;
+    cfg4)         args="--workload quicked --pairs 10000 --length 100000 --error 0.1"; steps=10;;
   esac
   common="$args --no-cpu-baseline --no-e2e"
   # overlapped (as benchmarked) and solo (--sync-each-step: a kernel's own duration) kernel stats
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -- python3 bench.py $common --steps $steps --warmup 2 > $out/stats_$wl.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -- python3 bench.py $common --steps $steps --warmup 3 > $out/stats_$wl.log 2>&1
   cp $out/stats_$wl/*/*kernel_stats.csv $out/${tag}_${wl}_kernel_stats.csv
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/solo_$wl -- python3 bench.py $common --steps $steps --warmup 2 --sync-each-step > $out/solo_$wl.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/solo_$wl -- python3 bench.py $common --steps $steps --warmup 3 --sync-each-step > $out/solo_$wl.log 2>&1
   cp $out/solo_$wl/*/*kernel_stats.csv $out/${tag}_${wl}_solo_kernel_stats.csv
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 bench.py $common --steps 1 --warmup 0 --sync-each-step > $out/pmc_${wl}_$c.log 2>&1
     cp $out/pmc_${wl}_$c/*/*counter_collection.csv $out/${tag}_${wl}_pmc_$c.csv
   done
-  python3 bench.py $args --steps $steps > $out/${tag}_bench_$wl.json 2> $out/bench_$wl.err
+  python3 bench.py $args --steps $steps --warmup 3 > $out/${tag}_bench_$wl.json 2> $out/bench_$wl.err
 done
 # SQ / GRBM counters of the BandEd score kernel alone (one pass per slot budget: 8 SQ, 2 GRBM)
 if [[ " $wls " == *" banded_score "* ]]; then
@@ -33,5 +33,9 @@ if [[ " $wls " == *" banded_score "* ]]; then
   rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $out/pmc_grbm -- python3 bench.py --no-cpu-baseline --no-e2e --steps 1 --warmup 0 --sync-each-step > $out/pmc_grbm.log 2>&1
   cp $out/pmc_grbm/*/*counter_collection.csv $out/${tag}_banded_score_pmc_grbm.csv
 fi
-./tools/bin/valu_rate AB > $out/${tag}_valu_rates.txt 2>&1
+./tools/bin/valu_rate ABC > $out/${tag}_valu_rates.txt 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/calib_$c -- tools/bin/pmc_calib > $out/calib_$c.log 2>&1
+  cp $out/calib_$c/*/*counter_collection.csv $out/${tag}_calib_pmc_$c.csv
+done
 python3 tools/summarise_pmc.py $out $tag $wls

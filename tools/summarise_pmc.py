@@ -44,6 +44,19 @@ for wl in wls:
         factor = float(os.environ.get("QE_FETCH_FACTOR", "2.0"))
         res[wl][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_factor": factor,
                       "hbm_bytes": (factor * f + w) * 1024, "launches": len(n[(k, "FETCH_SIZE")])}
+# calibration: tools/pmc_calib streams 4 GiB per kernel; factor = true bytes / reported bytes
+calib = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for r in rows(f"{out}/{tag}_calib_pmc_{c}.csv"):
+        k = r["Kernel_Name"]
+        if "k_read" not in k and "k_write" not in k:
+            continue
+        name = k.replace("void ", "").split("(")[0]
+        kib = float(r["Counter_Value"])
+        if kib > 0 and (("k_read" in k) == (c == "FETCH_SIZE")):
+            calib[f"{name}:{c}"] = {"reported_KiB": kib, "true_KiB": 4.0 * 1024 * 1024, "factor": 4.0 * 1024 * 1024 / kib}
+if calib:
+    res["calibration"] = calib
 sq = {}
 for part in ("sq1", "sq2", "grbm"):
     for r in rows(f"{out}/{tag}_banded_score_pmc_{part}.csv"):
