@@ -120,9 +120,12 @@ template <int OP, int D> static void rate_row(int wps, int iters) {
         hipLaunchKernelGGL((k_rate<OP, D>), dim3(blocks), dim3(256), lds, 0, g_out, g_stamps, warm ? 8 : iters);
     };
     const Result r = measure(launch, wps);
-    const double per_wave = r.cyc_wave / ((double)iters * 64 * (OP == ADD_CO_PAIR ? 2 : 1));
-    printf("%-20s D=%d w=%d  wave %6.2f  SIMD %6.2f cyc/instr   clock %.2f GHz  (%.2f ms)\n", OP_NAME[OP], D, wps, per_wave,
-           per_wave / wps, r.clock_ghz, r.wall_ms);
+    const double instr = (double)iters * 64 * (OP == ADD_CO_PAIR ? 2 : 1);
+    const double per_wave = r.cyc_wave / instr;
+    // per SIMD: from the wave's own cycles (exact while all w waves are resident together) and from the wall clock of the
+    // whole launch at the measured clock (includes launch ramp and tail; the honest figure when w is large)
+    printf("%-20s D=%d w=%d  wave %6.2f  SIMD %6.2f (wall %6.2f) cyc/instr   clock %.2f GHz  (%.2f ms)\n", OP_NAME[OP], D, wps, per_wave,
+           per_wave / wps, r.wall_ms * 1e-3 * r.clock_ghz * 1e9 / (instr * wps), r.clock_ghz, r.wall_ms);
 }
 template <int OP> static void rate_op(bool full) {
     const int iters = 3000;
@@ -137,59 +140,10 @@ template <int OP> static void rate_op(bool full) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Part B: block-step loops on register state.  VAR 0: run64_multi<4> (production 4-slot pass), 1: run64_multi<2>,
-// 2: run64_fast<0, true> (one slot), 3: the 4-slot pass software-skewed (slot k runs k columns behind slot 0, so the
-// four block steps of a pass step are independent), 4: two slots skewed
+// 2: run64_fast<0, true> (one slot), 3: run64_skew<4>, the 4-slot pass software-skewed (slot k runs k columns behind
+// slot 0, so the four block steps of a pass step are independent: what slots_pass uses), 4: two slots skewed
 // ---------------------------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void run64_skew(u64 (&P)[K], u64 (&M)[K], const u64 (&a)[K], const u64 (&b)[K],
-                                           u64 T0, u64 T1, u64 hinP, u64 hinM, u64& houtP, u64& houtM) {
-    using namespace qe;
-    u32 alo[K], ahi[K], blo[K], bhi[K], Plo[K], Phi[K], Mlo[K], Mhi[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        alo[k] = lo32(a[k]); ahi[k] = hi32(a[k]); blo[k] = lo32(b[k]); bhi[k] = hi32(b[k]);
-        Plo[k] = lo32(P[k]); Phi[k] = hi32(P[k]); Mlo[k] = lo32(M[k]); Mhi[k] = hi32(M[k]);
-    }
-    u32 oPlo = 0, oPhi = 0, oMlo = 0, oMhi = 0;
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const u32 t0 = half ? hi32(T0) : lo32(T0), t1 = half ? hi32(T1) : lo32(T1);
-        const u32 hp = half ? hi32(hinP) : lo32(hinP), hm = half ? hi32(hinM) : lo32(hinM);
-        u32 gP = 0, gM = 0;
-        u32 m0[32], m1[32], cP[K], cM[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) { cP[k] = 0; cM[k] = 0; }
-#pragma unroll
-        for (int s = 0; s < 32 + K - 1; ++s) {
-            if (s < 32) {
-                m0[s] = (u32)__builtin_amdgcn_sbfe((int)t0, s, 1);
-                m1[s] = (u32)__builtin_amdgcn_sbfe((int)t1, s, 1);
-            }
-#pragma unroll
-            for (int k = K - 1; k >= 0; --k) {           // lower slots first: they consume the carries of the previous step
-                const int c = s - k;
-                if (c < 0 || c >= 32) continue;
-                const u32 elo = bitop3<0x90>(~(alo[k] ^ m0[c]), blo[k], m1[c]), ehi = bitop3<0x90>(~(ahi[k] ^ m0[c]), bhi[k], m1[c]);
-                u32 inP, inM;
-                if (k == 0) { inP = __builtin_amdgcn_ubfe(hp, c, 1); inM = __builtin_amdgcn_ubfe(hm, c, 1); }
-                else { inP = cP[k]; inM = cM[k]; }
-                if (k + 1 < K) {
-                    u32 phhi, mhhi;
-                    block_step_core(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, phhi, mhhi);
-                    cP[k + 1] = phhi >> 31; cM[k + 1] = mhhi >> 31;
-                } else {
-                    block_step_fused(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, gP, gM);
-                }
-            }
-        }
-        const u32 rP = __builtin_bitreverse32(gP), rM = __builtin_bitreverse32(gM);
-        if (half) { oPhi = rP; oMhi = rM; } else { oPlo = rP; oMlo = rM; }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) { P[k] = mk64(Plo[k], Phi[k]); M[k] = mk64(Mlo[k], Mhi[k]); }
-    houtP = mk64(oPlo, oPhi);
-    houtM = mk64(oMlo, oMhi);
-}
+using qe::run64_skew;
 
 template <int VAR>
 __global__ __launch_bounds__(256) void k_step(u32* out, Stamp* stamps, int iters) {
@@ -230,6 +184,25 @@ __global__ __launch_bounds__(256) void k_step(u32* out, Stamp* stamps, int iters
     if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c1 - c0, t1 - t0};
 }
 
+// run64_skew against run64_multi on random states, text and carry words: every output word must be identical
+template <int K>
+__global__ void k_verify(u32* bad) {
+    using namespace qe;
+    u64 s = (u64)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 777;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (int it = 0; it < 64; ++it) {
+        u64 P1[K], M1[K], P2[K], M2[K], a[K], b[K];
+        for (int k = 0; k < K; ++k) { const u64 x = rnd(), y = rnd(); P1[k] = P2[k] = x & ~y; M1[k] = M2[k] = y & ~x; a[k] = rnd(); b[k] = rnd(); }
+        const u64 T0 = rnd(), T1 = rnd(), h1 = rnd(), h2 = rnd(), hinP = h1 & ~h2, hinM = h2 & ~h1;
+        u64 o1P, o1M, o2P, o2M;
+        run64_multi<K>(P1, M1, a, b, T0, T1, hinP, hinM, o1P, o1M);
+        run64_skew<K>(P2, M2, a, b, T0, T1, hinP, hinM, o2P, o2M);
+        bool ok = o1P == o2P && o1M == o2M;
+        for (int k = 0; k < K; ++k) ok = ok && P1[k] == P2[k] && M1[k] == M2[k];
+        if (!ok) atomicAdd(bad, 1u);
+    }
+}
+
 template <int VAR> static void step_row(const char* name, int K, int wps, int iters) {
     auto launch = [&](int blocks, size_t lds, bool warm) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -237,10 +210,10 @@ template <int VAR> static void step_row(const char* name, int K, int wps, int it
     };
     const Result r = measure(launch, wps);
     const double bc = (double)iters * 64 * K;                          // block-columns per wave
-    const double per_simd = r.cyc_wave / bc / wps;
+    const double per_simd = r.wall_ms * 1e-3 * r.clock_ghz * 1e9 / (bc * wps);   // from the launch's wall clock at the measured clock
     const double rate = (double)CUS * 4 * wps * 64 * bc / (r.wall_ms * 1e-3);   // lane block-columns per second, whole chip
-    printf("%-26s w=%d  %6.1f cyc / block-column / SIMD   chip %.3e block-columns/s   clock %.2f GHz  (%.2f ms)\n", name, wps,
-           per_simd, rate, r.clock_ghz, r.wall_ms);
+    printf("%-26s w=%d  %6.1f cyc / block-column / SIMD (one wave: %6.1f)   chip %.3e block-columns/s   clock %.2f GHz  (%.2f ms)\n", name, wps,
+           per_simd, r.cyc_wave / bc, rate, r.clock_ghz, r.wall_ms);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -313,12 +286,18 @@ int main(int argc, char** argv) {
     }
     if (strchr(what, 'B')) {
         printf("# Part B: block-step loops of qe_kernels.hip on registers (no memory in the loop)\n");
+        hipMemset(g_out, 0, 8);
+        hipLaunchKernelGGL((k_verify<4>), dim3(256), dim3(256), 0, 0, g_out);
+        hipLaunchKernelGGL((k_verify<2>), dim3(256), dim3(256), 0, 0, g_out + 1);
+        u32 bad[2] = {1, 1};
+        hipMemcpy(bad, g_out, 8, hipMemcpyDeviceToHost);
+        printf("run64_skew<4> / <2> against run64_multi on %d random passes each: %u / %u mismatches\n", 256 * 256 * 64, bad[0], bad[1]);
         const int it = 400;
         for (int w : {1, 2, 3, 4}) {
             step_row<0>("run64_multi<4>", 4, w, it);
-            step_row<3>("run64_skew<4> (experimental)", 4, w, it);
+            step_row<3>("run64_skew<4> (production)", 4, w, it);
             step_row<1>("run64_multi<2>", 2, w, it);
-            step_row<4>("run64_skew<2> (experimental)", 2, w, it);
+            step_row<4>("run64_skew<2> (production)", 2, w, it);
             step_row<2>("run64_fast<WIDE> (1 slot)", 1, w, it);
         }
     }
