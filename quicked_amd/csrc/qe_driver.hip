@@ -677,7 +677,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     HIP_CHECK(hipMemsetAsync(S.O.hew, 0, S.nt * sizeof(int32_t), C.stream));
     auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-    launch_groups(C, k_banded_coop, a, (size_t)nwaves, 16, 0);
+    launch_groups(C, k_banded_coop, a, (size_t)nwaves, 8, 0);
     // fallback pass: one lane per task, only where a band-edge decision could not be resolved in time
     const BandLayout lay = band_layout(L, false, false);
     S.D = upload_layout(lay, C);

@@ -242,8 +242,10 @@ __device__ __forceinline__ void run64_skew(u64 (&P)[K], u64 (&M)[K], const u64 (
 // v = sum of a block's vertical deltas -- exact for any block state, because every cell of the step satisfies
 // v' - v = h - h_above (the step evaluates the min-recurrence cell by cell).
 template <int K>
-__device__ __forceinline__ void slots_pass(bool act, int i, int r, u64* Pv, u64* Mv, int32_t* S, const u64* pp, int p0,
-                                           u64 T0, u64 T1, u64& hinP, u64& hinM, u32& adv) {
+// `stride` = elements between consecutive slots / rows of one lane's state (64 in k_banded's layout, the tasks per wave in
+// k_banded_coop's); scores[] is read from Srd and written to Swr (the cooperative kernel double-buffers it by chunk parity)
+__device__ __forceinline__ void slots_pass(bool act, int i, int r, u64* Pv, u64* Mv, const int32_t* Srd, int32_t* Swr, int64_t stride,
+                                           const u64* pp, int p0, u64 T0, u64 T1, u64& hinP, u64& hinM, u32& adv) {
     u64 P[K], M[K], a[K], b[K];
     int sc[K], v0[K];
 #pragma unroll
@@ -251,7 +253,7 @@ __device__ __forceinline__ void slots_pass(bool act, int i, int r, u64* Pv, u64*
         P[k] = 0; M[k] = 0; a[k] = 0; b[k] = 0; sc[k] = 0;
         if (act) {
             u64 nn;
-            P[k] = Pv[(int64_t)(i + k) * 64]; M[k] = Mv[(int64_t)(i + k) * 64]; sc[k] = S[(int64_t)(r + k) * 64];
+            P[k] = Pv[(int64_t)(i + k) * stride]; M[k] = Mv[(int64_t)(i + k) * stride]; sc[k] = Srd[(int64_t)(r + k) * stride];
             load_planes(pp, p0 + 64 * (r + k), a[k], b[k], nn);
         }
         v0[k] = __popcll(P[k]) - __popcll(M[k]);
@@ -262,9 +264,9 @@ __device__ __forceinline__ void slots_pass(bool act, int i, int r, u64* Pv, u64*
         int d = __popcll(houtP) - __popcll(houtM);          // sum of the bottom-row deltas of slot k, from the lowest up
 #pragma unroll
         for (int k = K - 1; k >= 0; --k) {
-            S[(int64_t)(r + k) * 64] = sc[k] + d;
+            Swr[(int64_t)(r + k) * stride] = sc[k] + d;
             d -= (__popcll(P[k]) - __popcll(M[k])) - v0[k];
-            Pv[(int64_t)(i + k - 1) * 64] = P[k]; Mv[(int64_t)(i + k - 1) * 64] = M[k];   // band shift (bpm_banded.c:903-909)
+            Pv[(int64_t)(i + k - 1) * stride] = P[k]; Mv[(int64_t)(i + k - 1) * stride] = M[k];   // band shift (bpm_banded.c:903-909)
         }
         adv += 64u * K;
     }
@@ -739,8 +741,8 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
                     return !__any(bad);
                 };
                 if (i == first) { hinP = QE_ONES; hinM = 0; }
-                if (i + 3 <= i1 && uniform(4)) { slots_pass<4>(act, i, r, Pv, Mv, S, pp, p0, T0, T1, hinP, hinM, adv); i += 3; continue; }
-                if (i + 1 <= i1 && uniform(2)) { slots_pass<2>(act, i, r, Pv, Mv, S, pp, p0, T0, T1, hinP, hinM, adv); i += 1; continue; }
+                if (i + 3 <= i1 && uniform(4)) { slots_pass<4>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); i += 3; continue; }
+                if (i + 1 <= i1 && uniform(2)) { slots_pass<2>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); i += 1; continue; }
             }
             u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
             int sc = 0;
@@ -843,7 +845,7 @@ template __global__ void k_banded<true>(BandedArgs);
 // Every value is bit-identical to k_banded<false>; a flagged task (o_abort) is
 // simply recomputed by k_banded<false>.
 // ===========================================================================
-__global__ __launch_bounds__(1024) void k_banded_coop(CoopArgs A) {
+__global__ __launch_bounds__(512) void k_banded_coop(CoopArgs A) {
     const int lane = threadIdx.x & 63, w = QE_GROUP_INDEX();
     const int G = A.G, NA = 64 / G;
     if (w * NA >= A.T.ntasks) return;
@@ -938,6 +940,32 @@ __global__ __launch_bounds__(1024) void k_banded_coop(CoopArgs A) {
             const int i = lo + it - off;
             const bool act = cnt > 0 && it >= off && i <= hi;
             const int r = i + pos_v;
+            {
+                // K of my slots in one skewed pass (slots_pass, as in k_banded) when every lane of the wave has K more or
+                // none: full ACGT chunks, not the last block row -- and never my range's last slot shi: lane g+1 hands
+                // its state over during this step's first pass, so it is read in a later one (see `off`)
+                const int hi_m = min(hi, shi - 1);
+                const bool mine = cnt > 0 && it >= off;
+                const bool plainrow = !(on && (ncols != 64 || hasN));
+                auto uniform = [&](int K) {
+                    const bool all = mine && i + K - 1 <= hi_m, none = cnt == 0 || (mine && i > hi);
+                    const bool bad = !(all || none) || (all && (!plainrow || r + K - 1 >= nw - 1));
+                    return !__any(bad);
+                };
+                const bool all4 = mine && i + 3 <= hi_m, all2 = mine && i + 1 <= hi_m;
+                if (it + 3 < maxit && uniform(4)) {
+                    slots_pass<4>(all4, i, r, Pv, Mv, Srd, Swr, NA, pp, p0, T0, T1, hinP, hinM, adv);
+                    if (all4) { lastP = hinP; lastM = hinM; }
+                    it += 3;
+                    continue;
+                }
+                if (it + 1 < maxit && uniform(2)) {
+                    slots_pass<2>(all2, i, r, Pv, Mv, Srd, Swr, NA, pp, p0, T0, T1, hinP, hinM, adv);
+                    if (all2) { lastP = hinP; lastM = hinM; }
+                    it += 1;
+                    continue;
+                }
+            }
             u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
             int sc = 0;
             if (act) {
