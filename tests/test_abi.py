@@ -129,8 +129,8 @@ def test_committed_bench_lines_follow_the_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_i_bench_*.json")))
-    assert len(files) == 2
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_i_bench_*.json")) + glob.glob(os.path.join(root, "profiles", "r02_i_bench_*.json")))
+    assert len(files) == 5
     for f in files:
         d = json.load(open(f))
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -147,3 +147,12 @@ def test_committed_bench_lines_follow_the_contract():
             assert k in c, (f, k)
         assert c["kind"] in ("reference", "port") and c["gpu_scores_identical_on_sample"] is True
         assert abs(d["value"] - d["config"]["pairs_per_gpu"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-6
+        if "r02_" in f:
+            # round 2: a fraction is a fraction; traffic is measured for the profiled sizes; the CPU baseline counts the
+            # CPUs the process really has; the banded line carries the end-to-end leg
+            assert 0 < r["frac"] <= 1 and r["traffic"] is not None and r["traffic"] >= r["algorithmic_bytes_per_launch"]
+            assert c["cores"] <= 64 and "single_thread_value" in c and "suspect" in c
+            assert "DEVICE-RESIDENT" in d["config"]["workload"]
+            assert 0 < d["valu"]["aggregate_frac"] < 1
+            if "banded_score" in f:
+                assert d["e2e"]["2bit_pinned"]["value"] > d["e2e"]["ascii_pinned"]["value"] > 0
