@@ -91,7 +91,8 @@ quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
 /* Brings the results of the batch's last sync == 0 run to the host: waits for that run (only that one: later runs of
  * this or other batches keep executing) and copies scores / statuses / CIGARs / counters to where the getters read
  * them.  A sync == 0 run itself leaves the getters' data untouched.  The device-side results live in the queueing
- * thread's rotating pools: fetch before that thread has queued two more runs, or QUICKED_ERROR is returned. */
+ * thread's rotating pools: fetch before that thread has queued two more runs, or QUICKED_ERROR is returned; call it
+ * from the thread that queued the run. */
 quicked_status_t quicked_batch_fetch(quicked_batch_t* batch);
 
 /* results of the last sync != 0 run or of the last quicked_batch_fetch (host copies) */

@@ -2166,7 +2166,9 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
         const quicked_status_t s = (st < 0 && st != QUICKED_EMPTY_SEQUENCE) ? st : (quicked_status_t)B->status[(size_t)i];
         if (status_out) status_out[i] = s;
         if (s < 0 && !any_err) { any_err = true; first_err = s; }
-        if (scores_out && s >= 0) scores_out[i] = B->score[(size_t)i];
+        // a split that did not converge still has a score and a CIGAR in the reference (run_hirschberg extracts them from the
+        // partial operations buffer before it returns the status, quicked.c:149-160): what the converged leaves gave
+        if (scores_out && (s >= 0 || s == QUICKED_FAIL_NON_CONVERGENCE)) scores_out[i] = B->score[(size_t)i];
     }
     if (cigars_out) {
         pool_keep->assign(B->cigar_pool.begin(), B->cigar_pool.end());
@@ -2189,8 +2191,8 @@ QE_API quicked_status_t quicked_align(quicked_aligner_t* aligner, const char* pa
     quicked_status_t one = QUICKED_OK;
     const quicked_status_t st = align_pairs(aligner, 1, &pattern, &pattern_len, &text, &text_len, &score,
                                             aligner->params->only_score ? nullptr : &cg, &one, &keep);
-    if (st < 0) return st;
-    aligner->score = score;
+    if (st < 0 && st != QUICKED_FAIL_NON_CONVERGENCE) return st;
+    aligner->score = score;                      // also on QUICKED_FAIL_NON_CONVERGENCE, like extract_results (quicked.c:149-160)
     if (!aligner->params->only_score && cg) {
         // a previous align's string stays valid until quicked_free, as in the reference (arena allocation that the
         // next align does not release, quicked.c:48-50, 357-361)
