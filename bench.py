@@ -170,7 +170,7 @@ def cpu_baseline(batch, params_kw, workload, budget_s=15.0, anchored=True):
 # ---------------------------------------------------------------------------------------------------------------
 # end to end: host buffers -> HBM (H2D) -> run -> scores on the host (D2H), batch after batch
 # ---------------------------------------------------------------------------------------------------------------
-def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflight=2, uploaders=2):
+def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflight=2, uploaders=2, expect_cigar_bytes=None):
     """`nbatches` batches of the same host data through `slots` resident batch objects: `uploaders` uploader threads
     reload (quicked_batch_reload*, H2D) batches k+1.. (uploader u takes the batches with k % uploaders == u) while the main
     thread queues run k (sync = 0) and fetches the scores of run k - inflight + 1 (quicked_batch_fetch, D2H).  Returns
@@ -223,10 +223,9 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
                 ev.set()
 
     checks = []
-    t0 = time.perf_counter()
-    ths = [threading.Thread(target=uploader, args=(u,)) for u in range(uploaders)]
-    for th in ths:
-        th.start()
+    d2h_bytes = [0]
+
+    queued = [threading.Event() for _ in range(nbatches)]
 
     def finish(k):
         rb = rbs[k % slots]
@@ -236,20 +235,44 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
         s, st = rb.scores()
         assert (st >= 0).all()
         checks.append(int(s.astype(np.int64).sum()))
+        if expect_cigar_bytes is not None:                 # CIGAR strings arrive with the fetch (one DMA into pinned memory)
+            pool, off = rb.cigar_view()
+            assert pool.nbytes == expect_cigar_bytes and int((off >= 0).sum()) == n, "end-to-end CIGARs differ from the resident run's"
+            d2h_bytes[0] += pool.nbytes
         fetched[k].set()
 
+    def fetcher():
+        # its own thread: waiting for run k and bringing its results over does not keep the main thread from queueing run k+1
+        try:
+            for k in range(nbatches):
+                queued[k].wait()
+                if err:
+                    break
+                finish(k)
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+            for ev in fetched:
+                ev.set()
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=uploader, args=(u,)) for u in range(uploaders)]
+    for th in ths:
+        th.start()
+    fth = threading.Thread(target=fetcher)
+    fth.start()
     for k in range(nbatches):
         uploaded[k].wait()
-        if err:
+        if k >= inflight:
+            fetched[k - inflight].wait()                    # at most `inflight` runs queued and not fetched (their device
+        if err:                                             # results live in the queueing thread's three rotating pools)
             break
         tr = time.perf_counter()
         assert rbs[k % slots].run(params, sync=False) >= 0
         tm["run"] += time.perf_counter() - tr
-        if k >= inflight - 1:
-            finish(k - inflight + 1)
-    for k in range(max(nbatches - inflight + 1, 0), nbatches):
-        if not err:
-            finish(k)
+        queued[k].set()
+    for ev in queued:
+        ev.set()
+    fth.join()
     elapsed = time.perf_counter() - t0
     for th in ths:
         th.join()
@@ -265,7 +288,7 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
     return {"value": n * nbatches / elapsed, "unit": "alignments/s", "batches": nbatches, "ms_per_batch": elapsed / nbatches * 1e3,
             "h2d_bytes_per_batch": nbytes, "h2d_GBs": nbytes * nbatches / elapsed / 1e9,
             "host_ms_per_batch": {k: v / nbatches * 1e3 for k, v in tm.items()}, "slots": slots, "inflight": inflight,
-            "uploader_threads": uploaders}
+            "uploader_threads": uploaders, "d2h_cigar_bytes_per_batch": d2h_bytes[0] // max(nbatches, 1)}
 
 
 def main():
@@ -280,10 +303,11 @@ def main():
     ap.add_argument("--workload", choices=["banded_score", "quicked"], default="banded_score")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-batches", type=int, default=12)
-    ap.add_argument("--e2e-slots", type=int, default=4)
-    ap.add_argument("--e2e-uploaders", type=int, default=2)
-    ap.add_argument("--e2e-inflight", type=int, default=2)
+    ap.add_argument("--e2e-batches", type=int, default=32,
+                    help="batches per end-to-end leg (pipeline fill and drain are inside the clock: ~3 batches' worth)")
+    ap.add_argument("--e2e-slots", type=int, default=0, help="resident batch objects in rotation (0: 4 for score-only BandEd, 6 for QuickEd)")
+    ap.add_argument("--e2e-uploaders", type=int, default=0, help="uploader threads (0: 2 for score-only BandEd, 3 for QuickEd)")
+    ap.add_argument("--e2e-inflight", type=int, default=0, help="runs queued and not yet fetched (0: 2 for score-only BandEd, 3 for QuickEd)")
     ap.add_argument("--no-strong", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="profiling aid: no overlap between consecutive runs, so per-kernel durations are those of a kernel alone")
@@ -366,27 +390,32 @@ def main():
         scores, status = rb.scores()
         assert (status >= 0).all(), "some pairs failed"
         counters = rb.counters()
+        cig = capi.lib().quicked_batch_cigar_bytes(rb._h) if not kw.get("only_score") else None
         rb.kernel_time()
         rb.close()
-        return batch, scores, counters, elapsed, kern_ms, kern_n
+        return batch, scores, counters, elapsed, kern_ms, kern_n, cig
 
     # ---- the headline: weak scaling, `pairs` pairs per GPU, inputs resident in HBM
     first, count, _ = shard.plan(args.pairs, rank, world, "weak")
-    batch, scores, counters, elapsed, kern_ms, kern_n = timed_resident(first, count, args.steps, args.warmup)
+    batch, scores, counters, elapsed, kern_ms, kern_n, cigar_bytes = timed_resident(first, count, args.steps, args.warmup)
     cells = batch.cells()
     checksum = int(scores.astype(np.int64).sum())
     tot_pairs, tot_cells, tot_checksum, max_elapsed, _ = shard.reduce_totals(dist, torch, device, count, cells, checksum, elapsed)
 
     # ---- end to end (PCIe-inclusive), every rank on its own GPU and PCIe link; rates add up
     e2e = None
-    if not args.no_e2e and args.workload == "banded_score":
+    if not args.no_e2e:
         e2e = {}
         for fmt in ("ascii_pinned", "2bit_pinned"):
-            r = e2e_leg(capi, batch, params, fmt, args.e2e_batches, checksum, slots=args.e2e_slots, inflight=args.e2e_inflight, uploaders=args.e2e_uploaders)
+            # QuickEd's run call blocks while its bound stage executes (host decisions): one more run in flight hides it
+            quick = args.workload != "banded_score"
+            r = e2e_leg(capi, batch, params, fmt, args.e2e_batches, checksum, slots=args.e2e_slots or (6 if quick else 4),
+                        inflight=args.e2e_inflight or (3 if quick else 2), uploaders=args.e2e_uploaders or (3 if quick else 2), expect_cigar_bytes=cigar_bytes)
             _, _, _, _, ext = shard.reduce_totals(dist, torch, device, 0, 0, 0, 0.0, extra_sum=(r["value"], r["h2d_GBs"]))
             r["value"], r["h2d_GBs"] = ext[0], ext[1]
             e2e[fmt] = r
-        e2e["note"] = ("create/reload (H2D) of batch k+1 overlapped with the run of batch k, scores fetched (D2H) per batch; "
+        e2e["note"] = ("create/reload (H2D) of batch k+1 overlapped with the run of batch k, scores (and CIGAR strings, where the "
+                       "workload makes them) fetched (D2H) per batch; "
                        "summed over ranks; PCIe Gen5 x16 moves ~47-55 GB/s from pinned memory, which bounds the ASCII form at "
                        "~2.5 M alignments/s per GPU")
 
@@ -394,7 +423,7 @@ def main():
     strong = None
     if world > 1 and not args.no_strong:
         sfirst, scount, stotal = shard.plan(args.pairs, rank, world, "strong")
-        _, s_scores, _, s_elapsed, _, _ = timed_resident(sfirst, scount, args.steps, 1)
+        _, s_scores, _, s_elapsed, _, _, _ = timed_resident(sfirst, scount, args.steps, 1)
         s_pairs, _, s_checksum, s_max, _ = shard.reduce_totals(dist, torch, device, scount, 0, int(s_scores.astype(np.int64).sum()), s_elapsed)
         strong = {"scaling": "strong", "total_pairs": s_pairs, "pairs_per_gpu": scount, "value": s_pairs * args.steps / s_max,
                   "unit": "alignments/s", "ms_per_step": s_max / args.steps * 1e3, "score_checksum": s_checksum}

@@ -101,6 +101,9 @@ quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_ou
  * (cigar_off[i] = offset of string i in cigar_pool, -1 if none) */
 int64_t quicked_batch_cigar_bytes(quicked_batch_t* batch);
 quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar_pool, int64_t* cigar_off);
+/* the same without the copy: pointers into the batch's own (pinned) result buffers, valid until the next sync != 0 run,
+ * fetch, reload or destroy of the batch */
+quicked_status_t quicked_batch_cigar_view(quicked_batch_t* batch, const char** cigar_pool, const int64_t** cigar_off);
 
 /* Output options of the runs to come.
  * cigar_style: 0 = the reference's RLE "MXID" (cigar_sprint, quicked_utils/src/cigar.c:453-488; default),

@@ -57,7 +57,7 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free",
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
            "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
-           "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats"]
+           "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats", "quicked_batch_cigar_view"]
 
 _LIB = None
 
@@ -111,6 +111,7 @@ def lib():
     L.quicked_batch_reload_packed.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_fetch.argtypes = [C.c_void_p]
     L.quicked_pool_stats.argtypes = [C.c_void_p]
+    L.quicked_batch_cigar_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.quicked_host_alloc.restype = C.c_void_p
     L.quicked_host_alloc.argtypes = [C.c_size_t]
     L.quicked_host_free.argtypes = [C.c_void_p]
@@ -325,6 +326,18 @@ class ResidentBatch:
                 e = raw.index(b"\0", o)
                 out.append(raw[o:e].decode())
         return out
+
+    def cigar_view(self):
+        """-> (uint8 view of the batch's pinned string pool, int64 view of the per-pair offsets), no copies; valid until
+        the next synchronous run / fetch / reload of the batch"""
+        pool, off = C.c_void_p(), C.c_void_p()
+        st = self._lib.quicked_batch_cigar_view(self._h, C.byref(pool), C.byref(off))
+        if st < 0:
+            raise QuickedException(st)
+        nb = self._lib.quicked_batch_cigar_bytes(self._h)
+        pv = np.ctypeslib.as_array((C.c_uint8 * max(nb, 1)).from_address(pool.value))[:nb] if (nb and pool.value) else np.zeros(0, np.uint8)
+        ov = np.ctypeslib.as_array((C.c_int64 * self.n).from_address(off.value)) if self.n else np.zeros(0, np.int64)
+        return pv, ov
 
     def counters(self):
         c = np.zeros(8, dtype=np.int64)

@@ -187,7 +187,8 @@ struct Context {
     hipStream_t& sa() { return stream_a2[ai]; }
     DevicePool& pa() { return pool_a2[ai]; }
     DevicePool* scratch_p = nullptr;         // the current phase's pool
-    hipEvent_t ev_pack = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_stage = nullptr, ev_decided = nullptr;
+    bool decided_set = false;                // the last run's k_stage1_decide (stream A) still reads pool_w: the next W phase waits for it
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // HIP-event pairs around the dominant kernel of every run since the last collection (bench.py's roofline leg)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
@@ -209,6 +210,8 @@ struct Context {
         HIP_CHECK(hipStreamCreateWithFlags(&stream_w, hipStreamNonBlocking));
         for (auto& q : stream_a2) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_decided, hipEventDisableTiming));
         phase_w();
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
@@ -329,6 +332,7 @@ struct quicked_batch {
     size_t last_mat_bytes = 0;                    // fill matrices of this batch's last CIGAR run (all leaves at once)
     size_t last_fixed_bytes = 0;                  // everything else its align stage took from the pool (runs, strings, workspaces)
     int last_groups = 0;                          // 64-task groups of that stage
+    int est_bound = 0;                            // QuickEd: the cutoff the next run's align buffers are sized for (0: none yet, < 0: classic flow only)
     hipEvent_t ev_done[NP] = {};    // end of the A phase of the last run that used this parity
     bool ev_done_set[NP] = {};
     size_t pl_p_words = 0, pl_t_words = 0;
@@ -336,7 +340,21 @@ struct quicked_batch {
     // results of the last run, host side, indexed by pair
     std::vector<int32_t> score, status;
     std::vector<int64_t> cigar_off;
-    std::vector<char> cigar_pool;
+    // the CIGAR strings of the last fetched run, in pinned host memory: one DMA from the device's string pool, no per-pair
+    // copies (a 100 k x 10 kb batch has ~400 MB of them)
+    struct PinnedBuf {
+        char* p = nullptr; size_t size = 0, cap = 0;
+        void reserve(size_t n) {
+            if (n <= cap) return;
+            const size_t ncap = std::max(n, cap + cap / 2 + 4096);
+            char* q = nullptr;
+            HIP_CHECK(hipHostMalloc((void**)&q, ncap, hipHostMallocDefault));
+            if (size) memcpy(q, p, size);
+            if (p) (void)hipHostFree(p);
+            p = q; cap = ncap;
+        }
+        ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    } cigar_pool;
     bool only_score_run = true;
     bool packed = false;                          // created from wire words: planes are the resident input, no ASCII, no k_pack
     int cigar_style = 0;                          // SegFormatArgs::style of the runs to come (quicked_batch_configure)
@@ -734,6 +752,10 @@ struct PendingFetch {
     std::vector<int32_t> leaf_pair; const u32* d_leaf_adv = nullptr; const u32* d_leaf_steps = nullptr;
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // what the run's host-side stages already counted
     bool quicked = false;                     // run_quicked ignores the Hirschberg status (quicked.c:290-291)
+    // QuickEd fast path (quicked_fast): what decides which pairs still need the classic flow
+    bool fast = false;
+    const int32_t* d_cut = nullptr; const int32_t* d_skip = nullptr; const u32* d_stage_steps = nullptr;
+    quicked_params_t params; TaskList L; size_t matrix_budget = 0;
     // validity
     DevicePool* pool = nullptr; uint64_t generation = 0; int parity = 0;
 };
@@ -846,10 +868,12 @@ static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, co
     HIP_CHECK(hipStreamSynchronize(C.stream));
     int64_t total = 0;
     if (want_strings) for (size_t i = 0; i < A.nroots; ++i) total = std::max<int64_t>(total, off[i] + len[i] + 1);
-    std::vector<char> tmp((size_t)total);
+    const size_t base = B.cigar_pool.size;
     if (total) {
-        HIP_CHECK(hipMemcpyAsync(tmp.data(), A.pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
+        B.cigar_pool.reserve(base + (size_t)total);
+        HIP_CHECK(hipMemcpyAsync(B.cigar_pool.p + base, A.pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
         HIP_CHECK(hipStreamSynchronize(C.stream));
+        B.cigar_pool.size = base + (size_t)total;
     }
     for (size_t i = 0; i < A.nroots; ++i) {
         const int pr = SL.root_pair[i];
@@ -858,17 +882,14 @@ static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, co
         if (edits[i] < 0) { B.score[pr] = -1; B.status[pr] = QUICKED_ERROR; }      // run-buffer overflow: cutoff below the distance
         B.counters[4] += nops[i];
         if (A.ok) B.check_ok[pr] = okv[i];
-        if (want_strings && len[i] > 0) {
-            B.cigar_off[pr] = (int64_t)B.cigar_pool.size();
-            B.cigar_pool.insert(B.cigar_pool.end(), tmp.begin() + off[i], tmp.begin() + off[i] + len[i] + 1);
-        }
+        if (want_strings && len[i] > 0) B.cigar_off[pr] = (int64_t)base + off[i];      // NUL-terminated in the pool
     }
 }
 
 // WindowEd over a task list (bpm_windowed.c:563-628)
 static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int W, int O_, int hew_threshold,
                          bool score_only, bool sse, StageResult* R, bool fetch, bool want_cigar, int32_t** d_score_out,
-                         PendingFetch* pf = nullptr) {
+                         PendingFetch* pf = nullptr, TaskOut* dev_out = nullptr, DevTasks* dev_tasks = nullptr) {
     const size_t nt = L.pair.size();
     const int ng = L.ngroups();
     // per group: Pv/Mv [W][64] u64 + tiled history of (64W+3) columns x W blocks
@@ -896,6 +917,8 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
     a.o_score = O.score; a.o_hew = O.hew; a.o_nruns = O.nruns; a.o_nops = O.nops; a.o_edits = O.edits; a.o_steps = O.steps;
     launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192);
     if (d_score_out) *d_score_out = O.score;
+    if (dev_out) *dev_out = O;
+    if (dev_tasks) *dev_tasks = T;
     SegList SL; AlignOut AO;
     if (!score_only) {
         SL.off.push_back(0);
@@ -944,7 +967,7 @@ static void reset_host_results(quicked_batch& B) {
     B.score.assign((size_t)B.n, -1);
     B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
     B.cigar_off.assign((size_t)B.n, -1);
-    B.cigar_pool.clear();
+    B.cigar_pool.size = 0;
     B.check_ok.assign((size_t)B.n, -1);
 }
 
@@ -954,7 +977,7 @@ struct AlignStats { uint64_t fill_adv = 0, tb_steps = 0, score_adv = 0, splits =
 
 static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool fetch, bool want_cigar,
                       size_t matrix_budget, uint64_t split_bytes, int32_t ok_status, int32_t** d_score_out, AlignStats* stats,
-                      PendingFetch* pf = nullptr, bool tight_runs = false) {
+                      PendingFetch* pf = nullptr, bool tight_runs = false, const int32_t* d_cut = nullptr, const int32_t* d_skip = nullptr) {
     double tr_last = now_ms();
     std::vector<HNode> nodes;
     std::vector<int32_t> root_node, root_status;
@@ -1063,6 +1086,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         SL.root_pair.push_back(rt.pair);
         SL.bound.push_back(cigar_bound_runs(rt.m, rt.n, root_runs, root_segs));
     }
+    const size_t n_leaves = LL.pair.size();
     LL.pad();
     QE_TRACE_POINT("  leaves listed");
     if (stats) stats->leaves += LL.pair.size();
@@ -1111,6 +1135,14 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     }
     const DevTasks T = upload_tasks(LL, C);
     const TaskOut O = take_out(C, nt);
+    if (d_cut) {
+        // the roots' cutoffs are still being computed on the device (quicked_fast): the host sized everything for the
+        // estimates in roots.cutoff; no root may have split or vanished, so leaf k is root k
+        if (n_leaves != root_node.size() || nodes.size() != root_node.size())
+            throw HipError{hipErrorInvalidValue, "device-side cutoffs need one leaf per root", __LINE__};
+        HIP_CHECK(hipMemsetAsync(O.nruns, 0xFF, nt * sizeof(int32_t), C.stream));      // a task taken out of the list has no runs (-1)
+        hipLaunchKernelGGL(k_apply_cutoffs, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, C.stream, (int)nt, T.cutoff, T.pair, d_cut, d_skip);
+    }
     int64_t* d_ws_off = C.scratch_p->take<int64_t>(ng + 1); int64_t* d_mat_off = C.scratch_p->take<int64_t>(ng + 1);
     int64_t* d_runs_off = C.scratch_p->take<int64_t>(ng + 1);
     int32_t* d_nslots = C.scratch_p->take<int32_t>(ng + 1); int32_t* d_nrows = C.scratch_p->take<int32_t>(ng + 1);
@@ -1207,6 +1239,217 @@ static void scatter_scores(quicked_batch& B, const TaskList& L, const std::vecto
 // ---------------------------------------------------------------------------
 // The batch entry point: dispatch on params->algo (quicked_align, quicked.c:405-437)
 // ---------------------------------------------------------------------------
+// The classic QUICKED / HIRSCHBERG flow over the tasks of L (run_quicked, quicked.c:163-306; run_hirschberg, 125-161):
+// the bound stages are host-synchronous -- stage 1's results regroup the pairs for stages 2 and 3 -- then the align step
+// runs with the bounds as cutoffs.  Called for a whole batch, or (after the fast path below) for the pairs it left.
+// QuickEd sizes the align step's buffers for an ESTIMATE of the bounds that is the same whether the bounds are known on
+// the host (classic flow) or still being computed on the device (fast flow): the pools then see one request sequence.
+static int quicked_estimate(int top) { return top + top / 8 + 16; }
+static int quicked_task_estimate(int est_bound, int cap) { return std::max(1, std::min(est_bound, std::max(cap, 65))); }
+static bool quicked_fast_enabled(const Context& C) { return !C.memory_tight && env_int("QE_QUICKED_FAST", 1) != 0; }
+
+static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t& p, const TaskList& L, bool fetch,
+                            size_t matrix_budget, PendingFetch* pf, const std::function<void()>& enter_a, bool whole_batch = true) {
+    double tr_last = now_ms();
+    const bool sse = !p.force_scalar;
+    const bool want_cigar = !p.only_score;
+    // the bound stages need their results on the host to regroup; the driver is synchronous here
+    std::vector<int32_t> bound(L.pair.size(), 0);
+    if (p.algo == QUICKED) {
+        StageResult S1;
+        qe_timer_start(tl_timers.windowed_s);
+        run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0],
+                     true, sse, &S1, true, false, nullptr);
+        qe_timer_stop(tl_timers.windowed_s);
+        QE_TRACE_POINT("stage 1 windowed");
+        B.counters[2] += (int64_t)sum_u32(S1.steps);
+        bound = S1.score;
+        // stage 2 for the pairs with too many high-error windows (quicked.c:201-202)
+        TaskList L2; std::vector<size_t> idx2;
+        int top = 0;
+        for (size_t t = 0; t < L.pair.size(); ++t) {
+            if (L.pair[t] < 0) continue;
+            const unsigned mx = (unsigned)std::max(L.m[t], L.n[t]);
+            if ((uint64_t)S1.hew[t] * 64u > (uint64_t)(mx * p.hew_percentage[0] / 100u)) {
+                L2.push(L.pair[t], 0, L.m[t], 0, L.n[t], 0, L.n[t]); idx2.push_back(t);
+            } else top = std::max(top, S1.score[t]);
+        }
+        if (whole_batch && B.est_bound >= 0) B.est_bound = quicked_estimate(top);      // what the fast path sizes the next run's align step for
+        B.counters[6] = (int64_t)idx2.size();
+        if (!idx2.empty()) {
+            L2.pad();
+            if (!B.have_rev[B.parity]) { launch_pack(B, C, true); B.have_rev[B.parity] = true; }
+            StageResult F, V;
+            const int W = (int)p.window_size, O = (int)p.overlap_size;
+            qe_timer_start(tl_timers.windowed_l);
+            run_windowed(B, C, L2, false, W, O, (int)p.hew_threshold[1], true, sse, &F, true, false, nullptr);
+            run_windowed(B, C, L2, true, W, O, (int)p.hew_threshold[1], true, sse, &V, true, false, nullptr);
+            qe_timer_stop(tl_timers.windowed_l);
+            B.counters[2] += (int64_t)sum_u32(F.steps) + (int64_t)sum_u32(V.steps);
+            TaskList L3; std::vector<size_t> idx3;
+            for (size_t k = 0; k < idx2.size(); ++k) {
+                const size_t t = idx2[k];
+                const int64_t sf = F.score[k], sr = V.score[k];
+                const int64_t sc = std::min(sf, sr);
+                const uint64_t hw = (sc >= sr) ? (uint64_t)V.hew[k] : (uint64_t)F.hew[k];   // quicked.c:229-230
+                bound[t] = (int32_t)sc;
+                const unsigned mx = (unsigned)std::max(L.m[t], L.n[t]);
+                if (hw * 64u * (uint64_t)(p.window_size - p.overlap_size) > (uint64_t)(mx * p.hew_percentage[1] / 100u)) {
+                    // stage 3: score-only BandEd, cutoff min(bandwidth%, bound) (quicked.c:246)
+                    const int64_t c0 = std::min<int64_t>((int64_t)(mx * p.bandwidth / 100u), sc);
+                    bound[t] = (int32_t)c0;
+                    L3.push(L.pair[t], 0, L.m[t], 0, L.n[t], (int32_t)c0, L.n[t]); idx3.push_back(t);
+                }
+            }
+            B.counters[7] = (int64_t)idx3.size();
+            // band doubling (quicked.c:248-278): relaunch on the subset that has not converged
+            int rounds = 0;
+            while (!idx3.empty()) {
+                if (++rounds > 40) {      // cutoffs double from >= 1: 40 rounds cannot happen for int32 lengths
+                    for (size_t k = 0; k < idx3.size() && k < 8; ++k)
+                        fprintf(stderr, "[quicked_hip] stage 3 does not converge: pair %d m %d n %d cutoff %d\n",
+                                L3.pair[k], L3.m[k], L3.n[k], L3.cutoff[k]);
+                    throw HipError{hipErrorUnknown, "QuickEd stage 3 band doubling", __LINE__};
+                }
+                L3.pad();
+                StageResult S3;
+                qe_timer_start(tl_timers.banded);
+                run_banded_score(B, C, L3, false, &S3, true, nullptr);
+                qe_timer_stop(tl_timers.banded);
+                B.counters[0] += (int64_t)sum_u32(S3.adv);
+                TaskList Ln; std::vector<size_t> idxn;
+                for (size_t k = 0; k < idx3.size(); ++k) {
+                    const size_t t = idx3[k];
+                    const int64_t ns = S3.score[k], sc = L3.cutoff[k];
+                    const int64_t mx = std::max(L.m[t], L.n[t]);
+                    if (trace_on() && rounds > 3) fprintf(stderr, "[qe] stage 3 round %d: pair %d m %d n %d cutoff %lld -> %lld\n", rounds, L.pair[t], L.m[t], L.n[t], (long long)sc, (long long)ns);
+                    if ((ns > mx / 4 && sc * 3 / 2 < ns) || ns < 0) {
+                        // a cutoff of 0 (bandwidth % of a short read rounds to 0) doubles to 0 forever in the reference
+                        // (quicked.c:248-278 never terminates there); defined here and in the oracle: doubling starts from 1
+                        Ln.push(L.pair[t], 0, L.m[t], 0, L.n[t], (int32_t)std::max<int64_t>(sc * 2, 1), L.n[t]); idxn.push_back(t);
+                    } else {
+                        bound[t] = (int32_t)ns;
+                    }
+                }
+                L3 = Ln; idx3 = idxn;
+            }
+        }
+    }
+    QE_TRACE_POINT("stage 2/3 decisions");
+    // align step: bpm_compute_matrix_hirschberg with the bound (quicked.c:283-294)
+    TaskList LA;
+    // sized like the fast flow's align step where that is possible (no task may split): buffers for the estimate, the
+    // bounds themselves handed over as device-side cutoffs
+    bool est_sized = p.algo == QUICKED && whole_batch && quicked_fast_enabled(C) && B.est_bound > 0 && !tl_timers.align;
+    std::vector<int32_t> est_t;
+    if (est_sized) {
+        const uint64_t split = split_threshold();
+        est_t.assign(L.pair.size(), 0);
+        uint64_t mat_bytes = 0;
+        for (size_t t = 0; t < L.pair.size() && est_sized; ++t) {
+            if (L.pair[t] < 0) continue;
+            est_t[t] = std::max(bound[t], quicked_task_estimate(B.est_bound, max_cutoff(p.bandwidth, L.m[t], L.n[t])));
+            const HGeom G = host_geometry(L.m[t], L.n[t], est_t[t]);
+            if ((uint64_t)G.ebb * (uint64_t)L.n[t] * 16u > split) est_sized = false;
+            mat_bytes += (uint64_t)9 * (uint64_t)(L.n[t] / 64 + 3) * (uint64_t)G.ebb * 16u;     // band_layout's checkpoints
+        }
+        // Buffers for the estimate are wider than buffers for the bounds (every group is as wide as the batch's widest
+        // pair, plus the margin): worth it while three pool sets of them fit easily; a batch near the HBM's size keeps
+        // the classic flow (its runs take ~100 ms: one host round trip is nothing there) until it is reloaded
+        if (est_sized && (double)mat_bytes * 3.0 > 0.5 * (double)C.seen_total) { est_sized = false; B.est_bound = -1; }
+    }
+    for (size_t t = 0; t < L.pair.size(); ++t) {
+        if (L.pair[t] < 0) continue;
+        LA.push(L.pair[t], 0, L.m[t], 0, L.n[t], est_sized ? est_t[t] : ((p.algo == QUICKED) ? bound[t] : L.cutoff[t]), L.n[t]);
+    }
+    QE_TRACE_POINT("align task list");
+    enter_a();
+    qe_timer_start(tl_timers.align);
+    AlignStats AS;
+    int32_t* d_cut = nullptr; int32_t* d_skip = nullptr;
+    if (est_sized) {
+        const size_t nt = L.pair.size();
+        d_cut = C.scratch_p->take<int32_t>(nt); d_skip = C.scratch_p->take<int32_t>(nt);
+        h2d(d_cut, bound, C.stream);
+        HIP_CHECK(hipMemsetAsync(d_skip, 0, nt * sizeof(int32_t), C.stream));
+    }
+    // run_quicked ignores the Hirschberg status (quicked.c:290-291, A.7(8)); run_hirschberg returns it (149-160)
+    run_align(B, C, LA, fetch, want_cigar, matrix_budget, split_threshold(), p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK,
+              &B.d_score, &AS, pf, /* the bound is an upper bound of the distance */ p.algo == QUICKED, d_cut, d_skip);
+    if (pf) pf->quicked = p.algo == QUICKED;
+    qe_timer_stop(tl_timers.align);
+    QE_TRACE_POINT("align launch(+fetch)");
+    B.counters[0] += (int64_t)AS.score_adv; B.counters[1] += (int64_t)AS.fill_adv; B.counters[3] += (int64_t)AS.tb_steps;
+    if (fetch && p.algo == QUICKED)
+        for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+}
+
+// ---------------------------------------------------------------------------
+// QuickEd without the host round trip after stage 1.  On data like the benchmark's no pair ever leaves stage 1, yet the
+// classic flow makes the host wait for the WindowEd(2,1) kernel before it can size and queue the align step.  Here the
+// stage-1 rule runs on the device (k_stage1_decide), the align step is queued at once with its buffers sized for an
+// ESTIMATE of the bounds (1.25 x the largest bound of the previous run; the bandwidth cutoff the first time) and reads
+// its cutoffs from the device; pairs that go on to stage 2, or whose bound exceeds the estimate, are taken out of the
+// task list on the device and aligned afterwards through the classic flow -- when the results are fetched.  Results are
+// those of the classic flow bit for bit: the bound IS the stage-1 score, sizes never enter a result.
+// ---------------------------------------------------------------------------
+static bool quicked_fast_wanted(const quicked_batch& B, const Context& C, const quicked_params_t& p, const TaskList& L,
+                                std::vector<int32_t>& est) {
+    if (p.algo != QUICKED || !quicked_fast_enabled(C) || B.est_bound <= 0) return false;   // the first run of a batch is a classic one
+    if (tl_timers.align) return false;          // quicked_align: the aligner's stage timers bracket host-synchronous stages
+    const int forced = env_int("QE_QUICKED_EST", 0);                   // tests: a small estimate sends pairs through the overflow path
+    const uint64_t split = split_threshold();
+    est.assign(L.pair.size(), 0);
+    for (size_t t = 0; t < L.pair.size(); ++t) {
+        if (L.pair[t] < 0) continue;
+        const int cap = max_cutoff(p.bandwidth, L.m[t], L.n[t]);
+        const int e = quicked_task_estimate(forced > 0 ? forced : B.est_bound, cap);
+        est[t] = e;
+        // an align step that might split (bpm_hirschberg.c:63-65) needs its real cutoff on the host
+        const HGeom G = host_geometry(L.m[t], L.n[t], e);
+        if ((uint64_t)G.ebb * (uint64_t)L.n[t] * 16u > split) return false;
+    }
+    return true;
+}
+
+// after a fast run has completed: which pairs still need the classic flow; the next run's estimate
+static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_params_t& p, const TaskList& L, const int32_t* d_cut,
+                                const int32_t* d_skip, const u32* d_steps, size_t matrix_budget, int parity) {
+    const size_t nt = L.pair.size();
+    std::vector<int32_t> cut, skip; std::vector<u32> steps;
+    d2h(cut, d_cut, nt, C.stream); d2h(skip, d_skip, nt, C.stream); d2h(steps, d_steps, nt, C.stream);
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+    TaskList Ls;
+    int top = 0;
+    for (size_t t = 0; t < nt; ++t) {
+        if (L.pair[t] < 0) continue;
+        if (!(skip[t] & 1)) top = std::max(top, cut[t]);
+        if (skip[t]) Ls.push(L.pair[t], 0, L.m[t], 0, L.n[t], L.cutoff[t], L.n[t]);
+        else B.counters[2] += steps[t];            // the classic flow below counts its own pairs' stage 1
+    }
+    B.est_bound = quicked_estimate(top);
+    if (Ls.pair.empty()) return;
+    Ls.pad();
+    // the classic flow for the pairs left, on idle streams, above whatever the pools hold (a later run of this thread
+    // may have its buffers there)
+    HIP_CHECK(hipStreamSynchronize(C.stream_w));
+    for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+    const int keep_parity = B.parity;
+    const bool keep_staging = C.staging;
+    int32_t* const keep_score = B.d_score;
+    B.parity = parity;
+    C.staging = false;
+    C.phase_w();
+    const DevicePool::Mark mw = C.pool_w.mark(), ma = C.pa().mark();
+    auto enter_a = [&]() { C.phase_a(); };
+    quicked_classic(B, C, p, Ls, true, matrix_budget, nullptr, enter_a, false);
+    HIP_CHECK(hipStreamSynchronize(C.stream_w));
+    for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+    C.pool_w.release(mw); C.pa().release(ma);
+    C.phase_w();
+    B.parity = keep_parity; C.staging = keep_staging; B.d_score = keep_score;
+}
+
 static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
     double tr_last = now_ms();
     tl_device = B.device;
@@ -1278,6 +1521,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     else {
         C.phase_w();
         C.pool_w.reset();
+        if (C.decided_set) { HIP_CHECK(hipStreamWaitEvent(C.stream_w, C.ev_decided, 0)); C.decided_set = false; }
         if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.stream_w, B.ev_done[par], 0));
     }
     B.only_score_run = p.only_score;
@@ -1339,106 +1583,49 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         break;
     case QUICKED:                                                   // run_quicked, quicked.c:163-306
     case HIRSCHBERG: {                                              // run_hirschberg, quicked.c:125-161
-        // the bound stages need their results on the host to regroup; the driver is synchronous here
-        std::vector<int32_t> bound(L.pair.size(), 0);
-        if (p.algo == QUICKED) {
-            StageResult S1;
+        std::vector<int32_t> est;
+        if (quicked_fast_wanted(B, C, p, L, est)) {
+            TaskOut W1; DevTasks T1;
             qe_timer_start(tl_timers.windowed_s);
-            run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0],
-                         true, sse, &S1, true, false, nullptr);
+            run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0], true, sse,
+                         nullptr, false, false, nullptr, nullptr, &W1, &T1);
             qe_timer_stop(tl_timers.windowed_s);
-            QE_TRACE_POINT("stage 1 windowed");
-            B.counters[2] += (int64_t)sum_u32(S1.steps);
-            bound = S1.score;
-            // stage 2 for the pairs with too many high-error windows (quicked.c:201-202)
-            TaskList L2; std::vector<size_t> idx2;
-            for (size_t t = 0; t < L.pair.size(); ++t) {
+            HIP_CHECK(hipEventRecord(C.ev_stage, C.stream_w));
+            enter_a();
+            HIP_CHECK(hipStreamWaitEvent(C.sa(), C.ev_stage, 0));
+            const size_t nt = L.pair.size();
+            int32_t* d_cut = C.scratch_p->take<int32_t>(nt); int32_t* d_skip = C.scratch_p->take<int32_t>(nt);
+            u32* d_steps = C.scratch_p->take<u32>(nt); int32_t* d_est = C.scratch_p->take<int32_t>(nt);
+            h2d(d_est, est, C.stream);
+            Stage1Args sa;
+            sa.nt = (int32_t)nt; sa.pair = T1.pair; sa.m = T1.m; sa.n = T1.n; sa.score = W1.score; sa.hew = W1.hew; sa.steps = W1.steps;
+            sa.est = d_est; sa.hew_percentage = p.hew_percentage[0]; sa.o_cut = d_cut; sa.o_skip = d_skip; sa.o_steps = d_steps;
+            hipLaunchKernelGGL(k_stage1_decide, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, C.stream, sa);
+            HIP_CHECK(hipEventRecord(C.ev_decided, C.stream));          // the stage's outputs live in pool_w, which the next run recycles
+            C.decided_set = true;
+            TaskList LA;
+            for (size_t t = 0; t < nt; ++t) {
                 if (L.pair[t] < 0) continue;
-                const unsigned mx = (unsigned)std::max(L.m[t], L.n[t]);
-                if ((uint64_t)S1.hew[t] * 64u > (uint64_t)(mx * p.hew_percentage[0] / 100u)) {
-                    L2.push(L.pair[t], 0, L.m[t], 0, L.n[t], 0, L.n[t]); idx2.push_back(t);
-                }
+                LA.push(L.pair[t], 0, L.m[t], 0, L.n[t], est[t], L.n[t]);
             }
-            B.counters[6] = (int64_t)idx2.size();
-            if (!idx2.empty()) {
-                L2.pad();
-                if (!B.have_rev[B.parity]) { launch_pack(B, C, true); B.have_rev[B.parity] = true; }
-                StageResult F, V;
-                const int W = (int)p.window_size, O = (int)p.overlap_size;
-                qe_timer_start(tl_timers.windowed_l);
-                run_windowed(B, C, L2, false, W, O, (int)p.hew_threshold[1], true, sse, &F, true, false, nullptr);
-                run_windowed(B, C, L2, true, W, O, (int)p.hew_threshold[1], true, sse, &V, true, false, nullptr);
-                qe_timer_stop(tl_timers.windowed_l);
-                B.counters[2] += (int64_t)sum_u32(F.steps) + (int64_t)sum_u32(V.steps);
-                TaskList L3; std::vector<size_t> idx3;
-                for (size_t k = 0; k < idx2.size(); ++k) {
-                    const size_t t = idx2[k];
-                    const int64_t sf = F.score[k], sr = V.score[k];
-                    const int64_t sc = std::min(sf, sr);
-                    const uint64_t hw = (sc >= sr) ? (uint64_t)V.hew[k] : (uint64_t)F.hew[k];   // quicked.c:229-230
-                    bound[t] = (int32_t)sc;
-                    const unsigned mx = (unsigned)std::max(L.m[t], L.n[t]);
-                    if (hw * 64u * (uint64_t)(p.window_size - p.overlap_size) > (uint64_t)(mx * p.hew_percentage[1] / 100u)) {
-                        // stage 3: score-only BandEd, cutoff min(bandwidth%, bound) (quicked.c:246)
-                        const int64_t c0 = std::min<int64_t>((int64_t)(mx * p.bandwidth / 100u), sc);
-                        bound[t] = (int32_t)c0;
-                        L3.push(L.pair[t], 0, L.m[t], 0, L.n[t], (int32_t)c0, L.n[t]); idx3.push_back(t);
-                    }
-                }
-                B.counters[7] = (int64_t)idx3.size();
-                // band doubling (quicked.c:248-278): relaunch on the subset that has not converged
-                int rounds = 0;
-                while (!idx3.empty()) {
-                    if (++rounds > 40) {      // cutoffs double from >= 1: 40 rounds cannot happen for int32 lengths
-                        for (size_t k = 0; k < idx3.size() && k < 8; ++k)
-                            fprintf(stderr, "[quicked_hip] stage 3 does not converge: pair %d m %d n %d cutoff %d\n",
-                                    L3.pair[k], L3.m[k], L3.n[k], L3.cutoff[k]);
-                        throw HipError{hipErrorUnknown, "QuickEd stage 3 band doubling", __LINE__};
-                    }
-                    L3.pad();
-                    StageResult S3;
-                    qe_timer_start(tl_timers.banded);
-                    run_banded_score(B, C, L3, false, &S3, true, nullptr);
-                    qe_timer_stop(tl_timers.banded);
-                    B.counters[0] += (int64_t)sum_u32(S3.adv);
-                    TaskList Ln; std::vector<size_t> idxn;
-                    for (size_t k = 0; k < idx3.size(); ++k) {
-                        const size_t t = idx3[k];
-                        const int64_t ns = S3.score[k], sc = L3.cutoff[k];
-                        const int64_t mx = std::max(L.m[t], L.n[t]);
-                        if (trace_on() && rounds > 3) fprintf(stderr, "[qe] stage 3 round %d: pair %d m %d n %d cutoff %lld -> %lld\n", rounds, L.pair[t], L.m[t], L.n[t], (long long)sc, (long long)ns);
-                        if ((ns > mx / 4 && sc * 3 / 2 < ns) || ns < 0) {
-                            // a cutoff of 0 (bandwidth % of a short read rounds to 0) doubles to 0 forever in the reference
-                            // (quicked.c:248-278 never terminates there); defined here and in the oracle: doubling starts from 1
-                            Ln.push(L.pair[t], 0, L.m[t], 0, L.n[t], (int32_t)std::max<int64_t>(sc * 2, 1), L.n[t]); idxn.push_back(t);
-                        } else {
-                            bound[t] = (int32_t)ns;
-                        }
-                    }
-                    L3 = Ln; idx3 = idxn;
-                }
+            QE_TRACE_POINT("fast: stage 1 + align list queued");
+            qe_timer_start(tl_timers.align);
+            AlignStats AS;
+            run_align(B, C, LA, fetch, want_cigar, matrix_budget, split_threshold(), QUICKED_WIP, &B.d_score, &AS, pf, true, d_cut, d_skip);
+            qe_timer_stop(tl_timers.align);
+            B.counters[1] += (int64_t)AS.fill_adv; B.counters[3] += (int64_t)AS.tb_steps;
+            if (pf) {
+                pf->quicked = true; pf->fast = true; pf->d_cut = d_cut; pf->d_skip = d_skip; pf->d_stage_steps = d_steps;
+                pf->params = p; pf->L = L; pf->matrix_budget = matrix_budget;
             }
-        }
-        QE_TRACE_POINT("stage 2/3 decisions");
-        // align step: bpm_compute_matrix_hirschberg with the bound (quicked.c:283-294)
-        TaskList LA;
-        for (size_t t = 0; t < L.pair.size(); ++t) {
-            if (L.pair[t] < 0) continue;
-            LA.push(L.pair[t], 0, L.m[t], 0, L.n[t], (p.algo == QUICKED) ? bound[t] : L.cutoff[t], L.n[t]);
-        }
-        QE_TRACE_POINT("align task list");
-        enter_a();
-        qe_timer_start(tl_timers.align);
-        AlignStats AS;
-        // run_quicked ignores the Hirschberg status (quicked.c:290-291, A.7(8)); run_hirschberg returns it (149-160)
-        run_align(B, C, LA, fetch, want_cigar, matrix_budget, split_threshold(), p.algo == QUICKED ? QUICKED_WIP : QUICKED_OK,
-                  &B.d_score, &AS, pf, /* the bound is an upper bound of the distance */ p.algo == QUICKED);
-        if (pf) pf->quicked = p.algo == QUICKED;
-        qe_timer_stop(tl_timers.align);
-        QE_TRACE_POINT("align launch(+fetch)");
-        B.counters[0] += (int64_t)AS.score_adv; B.counters[1] += (int64_t)AS.fill_adv; B.counters[3] += (int64_t)AS.tb_steps;
-        if (fetch && p.algo == QUICKED)
-            for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+            if (fetch) {
+                quicked_fast_finish(B, C, p, L, d_cut, d_skip, d_steps, matrix_budget, par);
+                C.phase_a();
+                for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+            }
+            QE_TRACE_POINT("fast: align launched(+fetch)");
+        } else
+            quicked_classic(B, C, p, L, fetch, matrix_budget, pf, enter_a);
         ret = (p.algo == QUICKED) ? QUICKED_WIP : QUICKED_OK;
         break;
     }
@@ -1521,6 +1708,7 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
             B.counters[2] += (int64_t)sum_u32(steps);
         }
         fetch_alignments(B, C, F.SL, F.AO, F.want_strings, F.ok_status, F.root_status.empty() ? nullptr : &F.root_status);
+        if (F.fast) quicked_fast_finish(B, C, F.params, F.L, F.d_cut, F.d_skip, F.d_stage_steps, F.matrix_budget, F.parity);
         if (F.quicked) for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
     }
     B.pending = false;
@@ -1614,7 +1802,8 @@ static void batch_reset_state(quicked_batch* B) {
     for (bool& h : B->have_rev) h = false;
     for (bool& e : B->ev_done_set) e = false;
     B->parity = 0; B->pending = false; B->pending_fetch.reset(); B->d_score = nullptr;
-    B->score.clear(); B->status.clear(); B->cigar_off.clear(); B->cigar_pool.clear(); B->check_ok.clear();
+    if (B->est_bound < 0) B->est_bound = 0;          // other pairs: QuickEd's sizing decision is taken again (a streamed batch keeps its estimate)
+    B->score.clear(); B->status.clear(); B->cigar_off.clear(); B->cigar_pool.size = 0; B->check_ok.clear();
 }
 static void batch_arena(quicked_batch* B, size_t need) {
     if (B->arena && B->arena_bytes >= need) return;
@@ -1927,11 +2116,18 @@ QE_API quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* sc
     return QUICKED_OK;
 }
 
-QE_API int64_t quicked_batch_cigar_bytes(quicked_batch_t* batch) { return (int64_t)batch->cigar_pool.size(); }
+QE_API int64_t quicked_batch_cigar_bytes(quicked_batch_t* batch) { return (int64_t)batch->cigar_pool.size; }
+
+QE_API quicked_status_t quicked_batch_cigar_view(quicked_batch_t* batch, const char** cigar_pool, const int64_t** cigar_off) {
+    if (!batch || batch->cigar_off.size() != (size_t)batch->n) return QUICKED_ERROR;
+    if (cigar_pool) *cigar_pool = batch->cigar_pool.p;
+    if (cigar_off) *cigar_off = batch->cigar_off.data();
+    return QUICKED_OK;
+}
 
 QE_API quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar_pool, int64_t* cigar_off) {
     if (batch->cigar_off.size() != (size_t)batch->n) return QUICKED_ERROR;
-    if (cigar_pool && !batch->cigar_pool.empty()) memcpy(cigar_pool, batch->cigar_pool.data(), batch->cigar_pool.size());
+    if (cigar_pool && batch->cigar_pool.size) memcpy(cigar_pool, batch->cigar_pool.p, batch->cigar_pool.size);
     if (cigar_off) memcpy(cigar_off, batch->cigar_off.data(), (size_t)batch->n * sizeof(int64_t));
     return QUICKED_OK;
 }
@@ -2171,7 +2367,7 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
         if (scores_out && (s >= 0 || s == QUICKED_FAIL_NON_CONVERGENCE)) scores_out[i] = B->score[(size_t)i];
     }
     if (cigars_out) {
-        pool_keep->assign(B->cigar_pool.begin(), B->cigar_pool.end());
+        pool_keep->assign(B->cigar_pool.p, B->cigar_pool.p + B->cigar_pool.size);
         for (int i = 0; i < n; ++i)
             cigars_out[i] = (B->cigar_off[(size_t)i] >= 0 && !p->only_score) ? pool_keep->data() + B->cigar_off[(size_t)i] : nullptr;
     }

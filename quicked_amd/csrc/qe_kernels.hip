@@ -1815,6 +1815,33 @@ __global__ __launch_bounds__(512) void k_windowed(WindowArgs A) {
 }
 
 // ===========================================================================
+// QuickEd without a host round trip after stage 1 (the common case: no pair leaves stage 1).  k_stage1_decide applies
+// the stage-1 rule of run_quicked (quicked.c:201-202) to k_windowed's outputs; k_apply_cutoffs hands the bounds to the
+// align step's task list as cutoffs and takes the pairs that need stages 2 / 3 (or more room than was planned) out
+// of it -- the host aligns those afterwards through the classic flow.
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_stage1_decide(Stage1Args A) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= A.nt) return;
+    int cut = 0, skip = 1;
+    u32 steps = 0;
+    if (A.pair[t] >= 0) {
+        const u32 mx = (u32)max(A.m[t], A.n[t]);
+        const bool stage2 = (u64)(u32)A.hew[t] * 64u > (u64)(mx * A.hew_percentage / 100u);     // unsigned arithmetic as in quicked.c:201
+        cut = A.score[t];
+        skip = (stage2 ? 1 : 0) | ((cut > A.est[t]) ? 2 : 0);
+        steps = A.steps[t];
+    }
+    A.o_cut[t] = cut; A.o_skip[t] = skip; A.o_steps[t] = steps;
+}
+__global__ __launch_bounds__(256) void k_apply_cutoffs(int nt, int32_t* cutoff, int32_t* pair, const int32_t* cut, const int32_t* skip) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    cutoff[t] = cut[t];
+    if (skip[t] != 0) pair[t] = -1;
+}
+
+// ===========================================================================
 // CIGAR formatting (cigar_sprint, cigar.c:453-488): runs are stored back to
 // front, the string goes front to back: "<len><op>" per run.
 // ===========================================================================

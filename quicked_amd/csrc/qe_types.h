@@ -111,6 +111,19 @@ struct WindowArgs {
     int32_t* o_score;  int32_t* o_hew;  int32_t* o_nruns;  int32_t* o_nops;  int32_t* o_edits;  u32* o_steps;
 };
 
+// QuickEd's stage-1 rule on the device (quicked.c:201-202): the WindowEd(2,1) score of a task is its bound unless too many
+// of its windows were high-error ones; est = the cutoff the host sized the align step for
+struct Stage1Args {
+    int32_t nt;
+    const int32_t* pair;  const int32_t* m;  const int32_t* n;
+    const int32_t* score;  const int32_t* hew;  const u32* steps;   // k_windowed's outputs
+    const int32_t* est;
+    u32 hew_percentage;
+    int32_t* o_cut;      // the bound = the align step's cutoff
+    int32_t* o_skip;     // bit 0: the pair goes on to stage 2; bit 1: its bound exceeds the estimate the buffers were sized for
+    u32* o_steps;        // copy of steps (the stage's buffers are recycled before the run is fetched)
+};
+
 // Where a stopped score-only BandEd launch left its band (what the Hirschberg join reads)
 struct BandState {
     int32_t G;     // 1: k_banded<false> layout (per 64-task group, column = lane); >= 2: k_banded_coop layout (per wave of 64/G tasks)

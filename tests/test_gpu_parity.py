@@ -697,6 +697,59 @@ def test_async_run_fetch_and_reload():
     rb.close()
 
 
+def test_quicked_device_side_stage1_equals_the_classic_flow(monkeypatch):
+    """QuickEd's fast path (stage-1 rule on the device, align step queued at once from an estimate, pairs that leave
+    stage 1 or exceed the estimate aligned afterwards) against the oracle and against QE_QUICKED_FAST=0: same scores,
+    statuses, CIGARs and work counters -- synchronously, fetched later, and with two runs of two batches in flight"""
+    pairs = []
+    for k, (length, err, n) in enumerate(((1500, 0.04, 60), (1500, 0.35, 9), (700, 0.10, 40), (2500, 0.22, 7))):
+        pairs += list(datagen.generate(count=n, length=length, error=err, seed=910 + k).pairs())
+    pairs += list(datagen.generate(count=6, length=1800, error=0.02, seed=915, indels_num=2, indels_len=150).pairs())
+    order = np.random.default_rng(5).permutation(len(pairs))
+    pairs = [pairs[i] for i in order]
+    mixed = datagen.PairBatch(*_pools(pairs))
+    other = datagen.generate(count=130, length=1100, error=0.07, seed=917)
+    expect = {id(b): [O.oracle_align(p, t, algo=0) for p, t in b.pairs()] for b in (mixed, other)}
+    prm = capi.make_params(algo=capi.QUICKED)
+
+    def check(rb, b, tag):
+        s, st = rb.scores()
+        cg = rb.cigars()
+        for i, e in enumerate(expect[id(b)]):
+            assert (st[i], s[i], cg[i]) == e, (tag, i)
+
+    monkeypatch.setenv("QE_QUICKED_FAST", "0")
+    rb = capi.ResidentBatch(mixed)
+    assert rb.run(prm, sync=True) >= 0
+    check(rb, mixed, "classic")
+    classic_counters = rb.counters()
+    rb.close()
+    assert classic_counters[6] > 0                                # some pairs do go on to stage 2
+    for est in ("0", "40", "3"):                                  # the estimate: planned / too small for most / for all pairs
+        monkeypatch.setenv("QE_QUICKED_FAST", "1")
+        monkeypatch.setenv("QE_QUICKED_EST", est)
+        rb = capi.ResidentBatch(mixed)
+        for rep in range(3):                                      # the second run plans from the first one's bounds
+            assert rb.run(prm, sync=True) >= 0
+            check(rb, mixed, ("sync", est, rep))
+            cnt = rb.counters()
+            assert list(cnt[:5]) == list(classic_counters[:5]), (est, rep, cnt, classic_counters)
+        assert rb.run(prm, sync=False) >= 0
+        assert rb.fetch() >= 0
+        check(rb, mixed, ("async", est))
+        assert list(rb.counters()[:5]) == list(classic_counters[:5])
+        # two batches, two runs in flight, fetched in order
+        rb2 = capi.ResidentBatch(other)
+        assert rb.run(prm, sync=False) >= 0
+        assert rb2.run(prm, sync=False) >= 0
+        assert rb.fetch() >= 0
+        assert rb2.fetch() >= 0
+        check(rb, mixed, ("two in flight", est))
+        check(rb2, other, ("two in flight", est))
+        rb.close()
+        rb2.close()
+
+
 def test_streaming_reload_from_an_uploader_thread():
     """bench.py's end-to-end pattern: an uploader thread reloads batch objects while the main thread runs and fetches
     the others (ASCII and 2-bit input)"""
