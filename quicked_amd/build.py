@@ -51,6 +51,7 @@ def build_hip(force=False):
                "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
                "-I", os.path.join(ROOT, "include"), "-I", CSRC,
                os.path.join(CSRC, "qe_driver.hip"), "-o", HIP_LIB]
+        cmd += os.environ.get("QE_HIPCC_FLAGS", "").split()      # experiments: -D switches of qe_kernels.hip
         _run(cmd)
     return HIP_LIB
 
