@@ -622,7 +622,7 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     a.mat = nullptr; a.g_mat_off = S.D.mat_off;
     a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
     a.o_maxrow = S.O.len;
-    a.only_if = nullptr; a.multi = 1;
+    a.only_if = nullptr;
     auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     launch_groups(C, k_banded<false>, a, L.ngroups(), 16, 0);
@@ -704,7 +704,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     b.ws = S.D.ws; b.g_ws_off = S.D.ws_off; b.g_nslots = S.D.nslots; b.g_nrows = S.D.nrows; b.g_nch = S.D.nch;
     b.mat = nullptr; b.g_mat_off = S.D.mat_off;
     b.o_score = S.O.score; b.o_first = S.O.first; b.o_last = S.O.last; b.o_posv = S.O.posv; b.o_adv = S.O.adv;
-    b.o_maxrow = S.O.len; b.only_if = S.O.hew; b.multi = 1;
+    b.o_maxrow = S.O.len; b.only_if = S.O.hew;
     launch_groups(C, k_banded<false>, b, L.ngroups(), 16, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
@@ -1174,24 +1174,9 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         a.o_score = O.score + o; a.o_first = O.first + o; a.o_last = O.last + o; a.o_posv = O.posv + o; a.o_adv = O.adv + o;
         a.o_maxrow = O.len + o;
         a.only_if = nullptr;
-        static const int fill_multi = env_int("QE_FILL_MULTI", 1);
-        a.multi = fill_multi;
         auto* ke = C.kernel_events();
         if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-        // narrow bands (QuickEd's bounds on 10 kb reads: <= 13 slots) keep their state in LDS (k_banded_fill_lds)
-        static const int fill_lds = env_int("QE_FILL_LDS", 1);
-        bool narrow = fill_lds != 0;
-        for (int g = g0; g < g1 && narrow; ++g) narrow = lay.nslots[g] <= QE_FILL_LDS_SLOTS;
-        if (narrow) launch_groups(C, k_banded_fill_lds, a, (size_t)(g1 - g0), 8, QE_FILL_LDS_BYTES);
-        else launch_groups(C, k_banded<true>, a, (size_t)(g1 - g0), 8, 0);
-        static const int exp_dummy = env_int("QE_EXP_FILL_DUMMY", 0);      // measurement aid: the same fill again, its stores confined to the cache
-        if (exp_dummy) {
-            BandedArgs d = a;
-            d.mat = C.scratch_p->take<uint4>(mat_u4 + 16);
-            d.multi |= 4;
-            if (narrow) launch_groups(C, k_banded_fill_lds, d, (size_t)(g1 - g0), 8, QE_FILL_LDS_BYTES);
-            else launch_groups(C, k_banded<true>, d, (size_t)(g1 - g0), 8, 0);
-        }
+        launch_groups(C, k_banded<true>, a, (size_t)(g1 - g0), 8, 0);
         if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
         TraceArgs tr;
         tr.P = a.P; tr.T = a.T;

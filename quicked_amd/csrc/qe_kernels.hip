@@ -32,9 +32,6 @@
 namespace qe {
 
 #define QE_ONES (~(u64)0)
-#ifndef QE_FILL_MULTI_PASSES
-#define QE_FILL_MULTI_PASSES 1
-#endif
 // One wave per group of 64 tasks.  A workgroup is 4 waves -- one per SIMD of the CU it lands on -- and
 // claims enough LDS that at most two of them share a CU (launch_groups, qe_driver.hip): the number of
 // waves that share a SIMD sets a lane-per-alignment kernel's duration, so it is not left to the dispatcher.
@@ -274,109 +271,6 @@ __device__ __forceinline__ void slots_pass(bool act, int i, int r, u64* Pv, u64*
         adv += 64u * K;
     }
     hinP = houtP; hinM = houtM;
-}
-
-// The skewed pass for the BandEd FILL: every slot collects its 64 carry-outs (they are the carry-in words of the slot
-// below, which the traceback needs to recompute a tile: hw[chunk][slot]) and stores a checkpoint {Pv, Mv} after every 8th
-// column, as run64_fast<2> does for one slot.  st = this chunk's checkpoint column 0 at slot i (slot k: + 64 k), st_last = the
-// next chunk's column 0 at slot i - 1 (the band shifts by one slot per chunk); top0: slot i is slot 0, whose shifted row
-// does not exist (dropped row, never read).
-template <int K>
-__device__ __forceinline__ void run64_skew_fill(u64 (&P)[K], u64 (&M)[K], const u64 (&a)[K], const u64 (&b)[K],
-                                                u64 T0, u64 T1, u64& hinP, u64& hinM, int (&dsc)[K],
-                                                u32 am, u32 em, uint4* st, int64_t st_stride, uint4* st_last, bool top0, uint4* hwp) {
-    // am bit k: this lane has slot k in its band (stores happen); em bit k (k >= 1): slot k is the TOP of this lane's band,
-    // its carry-in is the constant (1, 0) instead of what the (garbage) slot above puts out
-    u32 ent[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) ent[k] = (em >> k) & 1u;
-    u32 alo[K], ahi[K], blo[K], bhi[K], Plo[K], Phi[K], Mlo[K], Mhi[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        alo[k] = lo32(a[k]); ahi[k] = hi32(a[k]); blo[k] = lo32(b[k]); bhi[k] = hi32(b[k]);
-        Plo[k] = lo32(P[k]); Phi[k] = hi32(P[k]); Mlo[k] = lo32(M[k]); Mhi[k] = hi32(M[k]);
-        dsc[k] = 0;
-    }
-    if (am & 1u) hwp[0] = make_uint4(lo32(hinP), hi32(hinP), lo32(hinM), hi32(hinM));
-    u32 oP0 = 0, oM0 = 0;
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const u32 t0 = half ? hi32(T0) : lo32(T0), t1 = half ? hi32(T1) : lo32(T1);
-        const u32 hp = half ? hi32(hinP) : lo32(hinP), hm = half ? hi32(hinM) : lo32(hinM);
-        uint4* const sth = st + (int64_t)(4 * half) * st_stride;
-        u32 gP[K], gM[K];
-        u32 m0[32], m1[32];
-#pragma unroll
-        for (int k = 0; k < K; ++k) { gP[k] = 0; gM[k] = 0; }
-#pragma unroll
-        for (int s = 0; s < 32 + K - 1; ++s) {
-            if (s < 32) {
-                m0[s] = (u32)__builtin_amdgcn_sbfe((int)t0, s, 1);
-                m1[s] = (u32)__builtin_amdgcn_sbfe((int)t1, s, 1);
-            }
-#pragma unroll
-            for (int k = K - 1; k >= 0; --k) {
-                const int c = s - k;
-                if (c < 0 || c >= 32) continue;
-                const u32 elo = bitop3<0x90>(~(alo[k] ^ m0[c]), blo[k], m1[c]), ehi = bitop3<0x90>(~(ahi[k] ^ m0[c]), bhi[k], m1[c]);
-                u32 inP, inM;
-                if (k == 0) { inP = __builtin_amdgcn_ubfe(hp, c, 1); inM = __builtin_amdgcn_ubfe(hm, c, 1); }
-                else { inP = bitop3<0xA8>(gP[k - 1], ent[k], 1u); inM = bitop3<0x20>(gM[k - 1], ent[k], 1u); }   // (g | e) & 1, g & ~e & 1
-                block_step_fused(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, gP[k], gM[k]);
-                if ((c & 7) == 7 && ((am >> k) & 1u)) {
-                    uint4* q = sth + (int64_t)((c >> 3) + 1) * st_stride + 64 * k;
-                    if (c == 31 && half == 1) q = (k == 0 && top0) ? st + 8 * st_stride : st_last + 64 * k;
-                    *q = make_uint4(Plo[k], Phi[k], Mlo[k], Mhi[k]);
-                }
-            }
-            // the K block steps of a pass step are independent work enough; letting the scheduler pull later steps forward
-            // only costs registers (the kernel's per-lane state then spills around every pass)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // this half's 32 carry-outs of every slot: score deltas, and (as dwords) the carry-in words of the slot below
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const u32 rP = __builtin_bitreverse32(gP[k]), rM = __builtin_bitreverse32(gM[k]);
-            dsc[k] += __popc(rP) - __popc(rM);
-            if (k + 1 < K) {
-                if ((am >> (k + 1)) & 1u) {
-                    const u32 e = 0u - ent[k + 1];
-                    u32* w = (u32*)(hwp + 64 * (k + 1)); w[half] = rP | e; w[2 + half] = rM & ~e;
-                }
-            } else if (half == 0) { oP0 = rP; oM0 = rM; }
-            else { hinP = mk64(oP0, rP); hinM = mk64(oM0, rM); }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) { P[k] = mk64(Plo[k], Phi[k]); M[k] = mk64(Mlo[k], Mhi[k]); }
-}
-
-// K adjacent slots of one chunk of the FILL in one pass (slots_pass's counterpart): loads, carry-in words hw, scores,
-// the in-place band shift
-template <int K>
-__device__ __forceinline__ void slots_pass_fill(u32 am, u32 em, int i, int r, u64* Pv, u64* Mv, int32_t* S, const u64* pp, int p0,
-                                                u64 T0, u64 T1, u64& hinP, u64& hinM, u32& adv,
-                                                uint4* st, int64_t st_stride, uint4* st_last, uint4* hwp) {
-    u64 P[K], M[K], a[K], b[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        P[k] = 0; M[k] = 0; a[k] = 0; b[k] = 0;
-        if ((am >> k) & 1u) {
-            u64 nn;
-            P[k] = Pv[(int64_t)(i + k) * 64]; M[k] = Mv[(int64_t)(i + k) * 64];
-            load_planes(pp, p0 + 64 * (r + k), a[k], b[k], nn);
-        }
-    }
-    int dsc[K];
-    run64_skew_fill<K>(P, M, a, b, T0, T1, hinP, hinM, dsc, am, em, st, st_stride, st_last, i == 0, hwp);
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if ((am >> k) & 1u) {
-            S[(int64_t)(r + k) * 64] += dsc[k];
-            Pv[(int64_t)(i + k - 1) * 64] = P[k]; Mv[(int64_t)(i + k - 1) * 64] = M[k];        // band shift (bpm_banded.c:903-909)
-            adv += 64u;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -807,7 +701,7 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
     // fill: per group  cp[8 nch][ns][64] = {Pv, Mv} after every 8th stored column (in the slot numbering of the
     // chunk that starts at / contains it), then  hw[nch][ns][64] = the carry-in words of every (chunk, slot)
     uint4* const cp = FILL ? A.mat + A.g_mat_off[g] + lane : nullptr;
-    const int64_t cps = (A.multi & 4) ? 0 : (int64_t)gns * 64;     // uint4 units between checkpoint columns (4: measurement aid, every store lands in one cached tile)
+    const int64_t cps = (int64_t)gns * 64;                         // uint4 units between checkpoint columns
     uint4* const hw = FILL ? cp + (int64_t)8 * gnch * cps : nullptr;
 
     // bpm_reset_search (bpm_banded.c:180-197)
@@ -840,11 +734,13 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
         u64 qP = 0, qM = 0, qa0 = 0, qb0 = 0, qa1 = 0, qb1 = 0;
         int qS = 0, qi = -0x7fffffff;
         const int psh = p0 & 63;
+        const bool unaligned = __any(psh != 0);
         auto prefetch = [&](int j) {
             const int jc = min(max(j, 0), gns - 1), rc = min(max(j + pos_v, 0), gnr - 1), rp = min(max(j + pos_v, 0), nw);
             qP = Pv[(int64_t)jc * 64]; qM = Mv[(int64_t)jc * 64]; qS = S[(int64_t)rc * 64];
             const u64* w = pp + 3 * (int64_t)((p0 >> 6) + rp);
-            qa0 = w[0]; qb0 = w[1]; qa1 = w[3]; qb1 = w[4];
+            qa0 = w[0]; qb0 = w[1];
+            if (unaligned) { qa1 = w[3]; qb1 = w[4]; }            // Hirschberg children start anywhere in their pair's pattern
             qi = j;
         };
         if (FILL) prefetch(i0);
@@ -863,29 +759,6 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
                 if (i == first) { hinP = QE_ONES; hinM = 0; }
                 if (i + 3 <= i1 && uniform(4)) { slots_pass<4>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); i += 3; continue; }
                 if (i + 1 <= i1 && uniform(2)) { slots_pass<2>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); i += 1; continue; }
-            } else if (QE_FILL_MULTI_PASSES && (A.multi & 1)) {
-                // the same passes for the fill, at fixed positions from the wave's first slot: every slot also keeps its
-                // carry words and its checkpoints, and a lane takes part with the slots of the pass that are in ITS band
-                // (QuickEd's bounds are tight: the lanes of a wave prune their bands differently all the time)
-                const bool plain = !(on && (ncols != 64 || hasN));
-                auto masks = [&](int K, u32& am, u32& em) {
-                    am = 0; em = 0;
-                    bool bad = false;
-                    for (int k = 0; k < K; ++k) {
-                        const bool ak = on && i + k >= first && i + k <= rhi;
-                        if (ak) am |= 1u << k;
-                        if (ak && k > 0 && i + k == first) em |= 1u << k;
-                        bad |= ak && (!plain || r + k >= nw - 1);
-                    }
-                    return !__any(bad);
-                };
-                if (i == first) { hinP = QE_ONES; hinM = 0; }
-                uint4* const st = cp + (int64_t)(8 * k) * cps + (int64_t)i * 64;
-                uint4* const st_last = cp + (int64_t)(8 * k + 8) * cps + (int64_t)(i - 1) * 64;
-                uint4* const hwp = hw + ((int64_t)k * gns + i) * 64;
-                u32 am, em;
-                if (i + 3 <= i1 && masks(4, am, em)) { slots_pass_fill<4>(am, em, i, r, Pv, Mv, S, pp, p0, T0, T1, hinP, hinM, adv, st, cps, st_last, hwp); i += 3; continue; }
-                if (i + 1 <= i1 && masks(2, am, em)) { slots_pass_fill<2>(am, em, i, r, Pv, Mv, S, pp, p0, T0, T1, hinP, hinM, adv, st, cps, st_last, hwp); i += 1; continue; }
             }
             u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
             int sc = 0;
@@ -975,215 +848,6 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
 
 template __global__ void k_banded<false>(BandedArgs);
 template __global__ void k_banded<true>(BandedArgs);
-
-// ===========================================================================
-// BandEd fill with the band state ON CHIP (k_banded<true> for bands of <= QE_FILL_LDS_SLOTS slots).  k_banded<true>
-// keeps {Pv, Mv} of every slot and scores[] in a global workspace: every pass starts with loads it needs at once and
-// that queue behind the checkpoint stores of the pass before (one in-order vmcnt on gfx9) -- 42 % of the wave's cycles
-// are s_waitcnt (SQ_WAIT_ANY, profiles/README.md), and with 1.5 waves per SIMD nothing else runs meanwhile.  Here the
-// state lives in the wave's slice of the LDS the workgroup claims anyway (launch_groups pins 2 workgroups per CU):
-//   PM[slot + 1][lane] uint4 {Pv, Mv}   slots -1 .. 13        SC[row & 15][lane] int32 (a band covers <= 16 rows)
-// read and written with ds_read/write_b128 (lane-contiguous: conflict-free) under lgkmcnt, which no store delays; the
-// pattern planes of a pass are fetched one pass ahead.  Global traffic left: plane reads, checkpoints, carry words,
-// band edges.  Same arithmetic, same stores, same outputs as k_banded<true>.
-// ===========================================================================
-// the rare path (non-ACGT bases, the tail chunk, the last pattern block) as a real call: inlined it costs the whole kernel
-// registers -- the per-lane state spills around every pass
-__device__ __noinline__ void run64_general_fill_call(u64& P, u64& M, u64 a, u64 b, u64 nn, u64 T0, u64 T1, u64 TN,
-                                                     u64 hinP, u64 hinM, u64& houtP, u64& houtM, u64& sP, u64& sM,
-                                                     int lvl, int ncols, uint4* st, int64_t st_stride, uint4* st_last) {
-    run64_general<2>(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM, lvl, ncols, true, st, st_stride, st_last);
-}
-#define QE_FILL_LDS_SLOTS 14
-#define QE_FILL_LDS_BYTES ((QE_FILL_LDS_SLOTS + 1) * 1024 + 16 * 256)      // per wave: 15 KB of {Pv, Mv} + 4 KB of scores
-
-template <int K>
-__device__ __forceinline__ void lds_pass_fill(u32 am, u32 em, int i, int r, uint4* PM, int32_t* SC, const u64 (&a)[K], const u64 (&b)[K],
-                                              u64 T0, u64 T1, u64& hinP, u64& hinM, u32& adv,
-                                              uint4* st, int64_t st_stride, uint4* st_last, uint4* hwp) {
-    u64 P[K], M[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint4 v = PM[(i + k + 1) * 64];
-        P[k] = mk64(v.x, v.y); M[k] = mk64(v.z, v.w);
-    }
-    int dsc[K];
-    run64_skew_fill<K>(P, M, a, b, T0, T1, hinP, hinM, dsc, am, em, st, st_stride, st_last, i == 0, hwp);
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if ((am >> k) & 1u) {
-            SC[((r + k) & 15) * 64] += dsc[k];
-            PM[(i + k) * 64] = make_uint4(lo32(P[k]), hi32(P[k]), lo32(M[k]), hi32(M[k]));       // band shift: slot i + k -> i + k - 1
-            adv += 64u;
-        }
-    }
-}
-
-__global__ __launch_bounds__(512) void k_banded_fill_lds(BandedArgs A) {
-    const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
-    if (g * 64 >= A.T.ntasks) return;
-    int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
-    const bool valid = pair >= 0;
-    if (!__any(valid)) return;
-    int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0;
-    const u64* pp = A.P.pl_p;
-    const u64* tp = A.P.pl_t;
-    u32 fl = 0;
-    if (valid) {
-        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
-        cut_in = A.T.cutoff[t];
-        pp = A.P.pl_p + A.P.pl_p_off[pair];
-        tp = A.P.pl_t + A.P.pl_t_off[pair];
-        fl = A.P.flags[pair];
-    }
-    const int tfin = n;
-    const bool hasN = (fl & FLAG_HAS_N) != 0;
-    const Geom G = band_geometry(m, n, cut_in);
-    const int nw = (m + 63) >> 6;
-    const int nsl = G.ebb;
-    const int stop_row = nw - 1;                                   // bpm_banded.c:295
-    const int lvl_last = (m - 1) & 63;
-    int first = G.prolog, last = nsl - 1, pos_v = -G.prolog, pos_h = 0;
-    int max_row_init = nsl - 1;
-    u32 adv = 0;
-
-    const int gns = A.g_nslots[g], gnr = A.g_nrows[g], gnch = A.g_nch[g];
-    const GroupWs W = group_ws(A.ws, A.g_ws_off[g], gns, gnr, gnch);
-    uint8_t* const slice = (uint8_t*)qe_dyn_lds + (size_t)QE_WAVE_IN_BLOCK() * QE_FILL_LDS_BYTES;
-    uint4* const PM = (uint4*)slice + lane;                         // slot s at PM[(s + 1) * 64]
-    int32_t* const SC = (int32_t*)(slice + (QE_FILL_LDS_SLOTS + 1) * 1024) + lane;      // row r at SC[(r & 15) * 64]
-    uint4* const cp = A.mat + A.g_mat_off[g] + lane;
-    const int64_t cps = (A.multi & 4) ? 0 : (int64_t)gns * 64;
-    uint4* const hw = cp + (int64_t)8 * gnch * cps;
-
-    // bpm_reset_search (bpm_banded.c:180-197)
-    for (int s = 0; s < gns; ++s) {
-        if (valid && s < nsl) {
-            PM[(s + 1) * 64] = make_uint4(~0u, ~0u, 0u, 0u);
-            SC[(s & 15) * 64] = 64 * (s + 1);
-            cp[(int64_t)s * 64] = make_uint4(~0u, ~0u, 0u, 0u);
-        }
-    }
-    if (valid) { W.cf[lane] = (int16_t)first; W.cl[lane] = (int16_t)last; }
-
-    const int nfull = tfin >> 6, tail = tfin & 63;
-    const int my_chunks = valid ? nfull + (tail ? 1 : 0) : 0;
-    const int wave_chunks = wave_max(my_chunks);
-
-    for (int k = 0; k < wave_chunks; ++k) {
-        const int ncols = (k < nfull) ? 64 : ((k == nfull) ? tail : 0);
-        const bool on = valid && ncols > 0;
-        u64 T0 = 0, T1 = 0, TN = 0;
-        if (on) load_planes(tp, t0 + 64 * k, T0, T1, TN);
-        const int rhi = min(last, nw - 1 - pos_v);                 // rows >= nw are never computed (A.7(2))
-        const int i0 = wave_min(on ? first : 0x7fffffff);
-        const int i1 = wave_max(on ? rhi : -0x7fffffff);
-        const bool plain = !(on && (ncols != 64 || hasN));
-        u64 hinP = QE_ONES, hinM = 0;
-        // the pattern planes of the next pass (up to 4 slots from i) are in flight while this one computes: raw words,
-        // loaded unconditionally (rows clamped into the sequence's padded planes), funnel-shifted when they are used
-        u64 ra0[4], rb0[4], ra1[4], rb1[4];
-        const int psh = p0 & 63;
-        auto fetch = [&](int i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rr = min(max(i + q + pos_v, 0), nw);
-                const u64* w = pp + 3 * (int64_t)((p0 >> 6) + rr);
-                ra0[q] = w[0]; rb0[q] = w[1]; ra1[q] = w[3]; rb1[q] = w[4];
-            }
-        };
-        auto plane_a = [&](int q) { return (ra0[q] >> psh) | ((ra1[q] << 1) << (63 - psh)); };
-        auto plane_b = [&](int q) { return (rb0[q] >> psh) | ((rb1[q] << 1) << (63 - psh)); };
-        fetch(i0);
-        for (int i = i0; i <= i1; ++i) {
-            const bool act = on && i >= first && i <= rhi;
-            const int r = i + pos_v;
-            if (i == first) { hinP = QE_ONES; hinM = 0; }
-            uint4* const st = cp + (int64_t)(8 * k) * cps + (int64_t)i * 64;
-            uint4* st_last = cp + (int64_t)(8 * k + 8) * cps + (int64_t)(i - 1) * 64;
-            uint4* const hwp = hw + ((int64_t)k * gns + i) * 64;
-            auto masks = [&](int K, u32& am, u32& em) {
-                am = 0; em = 0;
-                bool bad = false;
-                for (int q = 0; q < K; ++q) {
-                    const bool aq = on && i + q >= first && i + q <= rhi;
-                    if (aq) am |= 1u << q;
-                    if (aq && q > 0 && i + q == first) em |= 1u << q;
-                    bad |= aq && (!plain || r + q >= nw - 1);
-                }
-                return !__any(bad);
-            };
-            u32 am, em;
-            if ((A.multi & 1) && i + 3 <= i1 && masks(4, am, em)) {
-                const u64 a4[4] = {plane_a(0), plane_a(1), plane_a(2), plane_a(3)}, b4[4] = {plane_b(0), plane_b(1), plane_b(2), plane_b(3)};
-                fetch(i + 4);
-                lds_pass_fill<4>(am, em, i, r, PM, SC, a4, b4, T0, T1, hinP, hinM, adv, st, cps, st_last, hwp);
-                i += 3;
-                continue;
-            }
-            if ((A.multi & 1) && masks(2, am, em)) {                      // also the last slot alone (slot i + 1 masked off)
-                const u64 a2[2] = {plane_a(0), plane_a(1)}, b2[2] = {plane_b(0), plane_b(1)};
-                fetch(i + 2);
-                lds_pass_fill<2>(am, em, i, r, PM, SC, a2, b2, T0, T1, hinP, hinM, adv, st, cps, st_last, hwp);
-                i += 1;
-                continue;
-            }
-            u64 P = 0, M = 0, a = act ? plane_a(0) : 0, b = act ? plane_b(0) : 0, nn = 0;
-            if (act) {
-                const uint4 v = PM[(i + 1) * 64];
-                P = mk64(v.x, v.y); M = mk64(v.z, v.w);
-                if (hasN || r == nw - 1) load_planes(pp, p0 + 64 * r, a, b, nn);
-            }
-            fetch(i + 1);
-            const bool lastblk = (r == nw - 1);
-            if (i == 0) st_last = st + 8 * cps;                    // slot -1 does not exist; dropped row, never read
-            if (act) hw[((int64_t)k * gns + i) * 64] = make_uint4(lo32(hinP), hi32(hinP), lo32(hinM), hi32(hinM));
-            u64 houtP, houtM, sP, sM;
-            run64_general_fill_call(P, M, a, b, nn, T0, T1, TN, hinP, hinM, houtP, houtM, sP, sM,
-                                    lastblk ? lvl_last : 63, act ? ncols : 0, st, cps, st_last);
-            if (act) {
-                SC[(r & 15) * 64] += __popcll(sP) - __popcll(sM);
-                PM[((ncols == 64) ? i : i + 1) * 64] = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));   // in-place band shift
-                adv += (u32)ncols;
-            }
-            hinP = houtP; hinM = houtM;
-        }
-        if (on && ncols == 64) {
-            // every-64-columns bookkeeping (bpm_banded.c:264-301)
-            const bool c1 = (first + 2 < last) && (G.fin > 64 * (first + 1));
-            bool cut_lo = false;
-            if (c1) cut_lo = SC[((first + pos_v + 1) & 15) * 64] + (G.fin - 64 * (first + 1)) > G.cutoff;
-            if (cut_lo && pos_h >= G.prolog) first++;
-            else if (!cut_lo && pos_h < G.prolog) first--;
-            PM[(last + 1) * 64] = make_uint4(~0u, ~0u, 0u, 0u);
-            cp[(int64_t)(8 * k + 8) * cps + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
-            const int pos = last + pos_v;
-            SC[((pos + 1) & 15) * 64] = SC[(pos & 15) * 64] + 64;
-            max_row_init = max(max_row_init, pos + 1);
-            const bool c2 = (first + 2 < last) && (64 * (last - 1) > G.fin);
-            bool cut_hi = false;
-            if (c2) cut_hi = SC[((last + pos_v - 1) & 15) * 64] + (64 * (last - 1) - G.fin) > G.cutoff;
-            if (cut_hi || (pos_v + last >= stop_row)) last--;
-            pos_v++;
-            pos_h++;
-            W.cf[(int64_t)pos_h * 64 + lane] = (int16_t)first; W.cl[(int64_t)pos_h * 64 + lane] = (int16_t)last;
-        }
-    }
-    if (valid) {
-        const int row = nw - 1;
-        int score = -1;
-        if (row <= max_row_init) {
-            score = SC[(row & 15) * 64];
-            if (m & 63) score -= 64 - (m & 63);
-        }
-        A.o_score[t] = score;
-        A.o_first[t] = first;
-        A.o_last[t] = last;
-        A.o_posv[t] = pos_v;
-        A.o_maxrow[t] = max_row_init;
-        A.o_adv[t] = adv;
-    }
-}
 
 
 // ===========================================================================

@@ -76,7 +76,6 @@ struct BandedArgs {
     // outputs per task
     int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;  int32_t* o_maxrow;
     const int32_t* only_if;  // run only tasks whose flag is non-zero (fallback pass after k_banded_coop); may be null
-    int32_t multi;           // fill: K adjacent slots per pass where the wave's lanes agree (0: one slot per pass, QE_FILL_MULTI=0)
 };
 
 // BandEd score-only, G lanes per alignment (cooperative form of k_banded<false>)
