@@ -65,6 +65,17 @@ for part in ("sq1", "sq2", "grbm"):
         sq[r["Counter_Name"]] = sq.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 if sq:
     res["banded_score_sq"] = sq
+qsq = collections.defaultdict(dict)
+for r in rows(f"{out}/{tag}_quicked_pmc_sq1.csv"):
+    if "qe::" in r["Kernel_Name"]:
+        k = short(r["Kernel_Name"])
+        qsq[k][r["Counter_Name"]] = qsq[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+for k, v in qsq.items():
+    if v.get("SQ_WAVE_CYCLES"):
+        v["wait_any_share"] = v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]
+        v["active_valu_share"] = v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_WAVE_CYCLES"]
+if qsq:
+    res["quicked_sq"] = qsq
 with open(f"{out}/{tag}_pmc_summary.json", "w") as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res, indent=1))
