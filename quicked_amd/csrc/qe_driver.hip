@@ -272,7 +272,7 @@ static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
     if (src.empty()) return;
     const size_t bytes = src.size() * sizeof(T);
     Context* C = tl_ctx;
-    if (C && C->staging && s == C->sa()) {
+    if (C && C->staging && (s == C->sa() || s == C->stream_w)) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
         uint8_t* st = C->stage[C->si].take(bytes);
         memcpy(st, src.data(), bytes);
         HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
@@ -465,7 +465,7 @@ struct DevTasks {
 static void h2d_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
     Context* C = tl_ctx;
-    if (C && C->staging && s == C->sa()) {
+    if (C && C->staging && (s == C->sa() || s == C->stream_w)) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
         uint8_t* st = C->stage[C->si].take(bytes);
         memcpy(st, src, bytes);
         HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
@@ -1590,8 +1590,10 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0], true, sse,
                          nullptr, false, false, nullptr, nullptr, &W1, &T1);
             qe_timer_stop(tl_timers.windowed_s);
+            QE_TRACE_POINT("fast: stage 1 queued");
             HIP_CHECK(hipEventRecord(C.ev_stage, C.stream_w));
             enter_a();
+            QE_TRACE_POINT("fast: phase A entered");
             HIP_CHECK(hipStreamWaitEvent(C.sa(), C.ev_stage, 0));
             const size_t nt = L.pair.size();
             int32_t* d_cut = C.scratch_p->take<int32_t>(nt); int32_t* d_skip = C.scratch_p->take<int32_t>(nt);
@@ -1603,6 +1605,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             hipLaunchKernelGGL(k_stage1_decide, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, C.stream, sa);
             HIP_CHECK(hipEventRecord(C.ev_decided, C.stream));          // the stage's outputs live in pool_w, which the next run recycles
             C.decided_set = true;
+            QE_TRACE_POINT("fast: decide queued");
             TaskList LA;
             for (size_t t = 0; t < nt; ++t) {
                 if (L.pair[t] < 0) continue;
