@@ -81,9 +81,10 @@ quicked_status_t quicked_batch_reload_packed(quicked_batch_t* batch, int64_t n, 
  * the ASCII bytes resident in HBM to scores (and CIGAR runs) resident in HBM.
  * sync != 0: waits for the run and copies scores / statuses / CIGARs / counters
  * to the host, where the getters below read them.
- * sync == 0: returns once the run is queued (QUICKED / HIRSCHBERG: once their
- * bound stages, which need host decisions, are done); nothing is copied to the
- * host until quicked_batch_fetch().  Consecutive runs of a thread rotate over up to three sets of stream, device
+ * sync == 0: returns once the run is queued; nothing is copied to the host until quicked_batch_fetch().  HIRSCHBERG, and
+ * QUICKED where a pair may split or the batch runs for the first time, return once their host-driven stages are done;
+ * otherwise QUICKED queues stage 1 and the align step together (the stage-1 rule of quicked.c:201-202 runs on the
+ * device) and aligns the pairs that go on to stages 2 / 3 when the run is fetched.  Consecutive runs of a thread rotate over up to three sets of stream, device
  * pool and bit-planes, so the kernels of runs k+1 and k+2 overlap those of run k;
  * the device results of a run stay valid until the next run of that thread starts. */
 quicked_status_t quicked_batch_run(quicked_batch_t* batch, const quicked_params_t* params, int sync);
@@ -91,8 +92,10 @@ quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
 /* Brings the results of the batch's last sync == 0 run to the host: waits for that run (only that one: later runs of
  * this or other batches keep executing) and copies scores / statuses / CIGARs / counters to where the getters read
  * them.  A sync == 0 run itself leaves the getters' data untouched.  The device-side results live in the queueing
- * thread's rotating pools: fetch before that thread has queued two more runs, or QUICKED_ERROR is returned; call it
- * from the thread that queued the run. */
+ * thread's rotating pools: at most sets - 1 more runs of that thread may be queued before the fetch (sets =
+ * quicked_pool_stats()[2], normally 3), or QUICKED_ERROR is returned.  Any
+ * thread may fetch (bench.py's end-to-end leg fetches on a thread of its own) as long as no other call on this batch
+ * object runs at the same time; what the fetch itself has to compute runs on the calling thread's streams and pools. */
 quicked_status_t quicked_batch_fetch(quicked_batch_t* batch);
 
 /* results of the last sync != 0 run or of the last quicked_batch_fetch (host copies) */
