@@ -312,6 +312,8 @@ def main():
     ap.add_argument("--length", type=int, default=10000)
     ap.add_argument("--error", type=float, default=0.05)
     ap.add_argument("--bandwidth", type=int, default=15)
+    ap.add_argument("--indels-num", type=int, default=0, help="large indels per pair (generate_dataset's -I), with --indels-len")
+    ap.add_argument("--indels-len", type=int, default=0)
     ap.add_argument("--workload", choices=["banded_score", "quicked"], default="banded_score")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -379,14 +381,29 @@ def main():
         rb.sync()
     parallelism = f"pairs sharded over {world} GPU(s), no data-path collective" + (" [test: ranks share device 0]" if share else "")
 
+    flow = {}
+
     def timed_resident(first, count, steps, warmup):
         """the contract's loop: `warmup` untimed steps, then exactly `steps` steps between two barrier + synchronize"""
-        batch = datagen.generate(count, args.length, args.error, seed=args.seed, first=first)
+        batch = datagen.generate(count, args.length, args.error, seed=args.seed, first=first,
+                                 indels_num=args.indels_num, indels_len=args.indels_len)
         rb = capi.ResidentBatch(batch)           # H2D happens here, outside the timed region
         for _ in range(max(warmup, 0)):
             st = rb.run(params, sync=True)
             assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
         rb.kernel_time()                         # drop the warm-up launches
+        if args.workload == "quicked":
+            # A QuickEd run queued with sync = 0 leaves the pairs that go past stage 1 (or exceed the planned buffers) to
+            # the fetch.  The timed loop never fetches: if this data has such pairs, time the host-driven flow instead,
+            # which does all the work inside the run.
+            wc = rb.counters() if warmup > 0 else np.zeros(8, dtype=np.int64)
+            flow["stage2_pairs"], flow["stage3_pairs"] = int(wc[6]), int(wc[7])
+            flow["deferred_pairs"] = rb.deferred_pairs() if warmup > 0 else 0
+            if flow["stage2_pairs"] or flow["deferred_pairs"]:
+                os.environ["QE_QUICKED_FAST"] = "0"
+                flow["timed_flow"] = "classic (host-driven stages): pairs leave stage 1 on this data"
+            else:
+                flow.setdefault("timed_flow", "stage-1 rule on the device, align step queued with it; no pair deferred to the fetch")
         barrier(rb)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -514,6 +531,8 @@ def main():
                              "time; peak assumes the 2.4 GHz peak clock (the chip holds less under this load: DESIGN.md 4.1)"},
             "score_checksum": tot_checksum,
         }
+        if flow:
+            line["quicked_flow"] = flow
         if e2e is not None:
             line["e2e"] = e2e
         if strong is not None:

@@ -57,7 +57,8 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free",
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
            "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
-           "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats", "quicked_batch_cigar_view"]
+           "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats", "quicked_batch_cigar_view",
+           "quicked_batch_deferred_pairs"]
 
 _LIB = None
 
@@ -112,6 +113,8 @@ def lib():
     L.quicked_batch_fetch.argtypes = [C.c_void_p]
     L.quicked_pool_stats.argtypes = [C.c_void_p]
     L.quicked_batch_cigar_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.quicked_batch_deferred_pairs.restype = C.c_int64
+    L.quicked_batch_deferred_pairs.argtypes = [C.c_void_p]
     L.quicked_host_alloc.restype = C.c_void_p
     L.quicked_host_alloc.argtypes = [C.c_size_t]
     L.quicked_host_free.argtypes = [C.c_void_p]
@@ -338,6 +341,10 @@ class ResidentBatch:
         pv = np.ctypeslib.as_array((C.c_uint8 * max(nb, 1)).from_address(pool.value))[:nb] if (nb and pool.value) else np.zeros(0, np.uint8)
         ov = np.ctypeslib.as_array((C.c_int64 * self.n).from_address(off.value)) if self.n else np.zeros(0, np.int64)
         return pv, ov
+
+    def deferred_pairs(self):
+        """pairs of the last fetched / synchronous QuickEd run that were aligned at fetch time (quicked_batch.h)"""
+        return int(self._lib.quicked_batch_deferred_pairs(self._h))
 
     def counters(self):
         c = np.zeros(8, dtype=np.int64)

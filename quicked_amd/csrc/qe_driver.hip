@@ -332,6 +332,7 @@ struct quicked_batch {
     size_t last_mat_bytes = 0;                    // fill matrices of this batch's last CIGAR run (all leaves at once)
     size_t last_fixed_bytes = 0;                  // everything else its align stage took from the pool (runs, strings, workspaces)
     int last_groups = 0;                          // 64-task groups of that stage
+    int64_t deferred_pairs = 0;                   // QuickEd: pairs of the last fetched run that were aligned at fetch time (quicked_batch_deferred_pairs)
     int est_bound = 0;                            // QuickEd: the cutoff the next run's align buffers are sized for (0: none yet, < 0: classic flow only)
     hipEvent_t ev_done[NP] = {};    // end of the A phase of the last run that used this parity
     bool ev_done_set[NP] = {};
@@ -969,6 +970,7 @@ static void reset_host_results(quicked_batch& B) {
     B.cigar_off.assign((size_t)B.n, -1);
     B.cigar_pool.size = 0;
     B.check_ok.assign((size_t)B.n, -1);
+    B.deferred_pairs = 0;
 }
 
 struct HNode { int32_t pair, p0, m, t0, n, cutoff, left, right, leaf_task; };
@@ -1245,7 +1247,8 @@ static void scatter_scores(quicked_batch& B, const TaskList& L, const std::vecto
 // QuickEd sizes the align step's buffers for an ESTIMATE of the bounds that is the same whether the bounds are known on
 // the host (classic flow) or still being computed on the device (fast flow): the pools then see one request sequence.
 static int quicked_estimate(int top) { return top + top / 8 + 16; }
-static int quicked_task_estimate(int est_bound, int cap) { return std::max(1, std::min(est_bound, std::max(cap, 65))); }
+// per task: no bound exceeds max(m, n) (the bandwidth percentage only enters stage 3, quicked.c:246)
+static int quicked_task_estimate(int est_bound, int longest) { return std::max(1, std::min(est_bound, std::max(longest, 65))); }
 static bool quicked_fast_enabled(const Context& C) { return !C.memory_tight && env_int("QE_QUICKED_FAST", 1) != 0; }
 
 static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t& p, const TaskList& L, bool fetch,
@@ -1348,7 +1351,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
         uint64_t mat_bytes = 0;
         for (size_t t = 0; t < L.pair.size() && est_sized; ++t) {
             if (L.pair[t] < 0) continue;
-            est_t[t] = std::max(bound[t], quicked_task_estimate(B.est_bound, max_cutoff(p.bandwidth, L.m[t], L.n[t])));
+            est_t[t] = std::max(bound[t], quicked_task_estimate(B.est_bound, std::max(L.m[t], L.n[t])));
             const HGeom G = host_geometry(L.m[t], L.n[t], est_t[t]);
             if ((uint64_t)G.ebb * (uint64_t)L.n[t] * 16u > split) est_sized = false;
             mat_bytes += (uint64_t)9 * (uint64_t)(L.n[t] / 64 + 3) * (uint64_t)G.ebb * 16u;     // band_layout's checkpoints
@@ -1402,8 +1405,7 @@ static bool quicked_fast_wanted(const quicked_batch& B, const Context& C, const 
     est.assign(L.pair.size(), 0);
     for (size_t t = 0; t < L.pair.size(); ++t) {
         if (L.pair[t] < 0) continue;
-        const int cap = max_cutoff(p.bandwidth, L.m[t], L.n[t]);
-        const int e = quicked_task_estimate(forced > 0 ? forced : B.est_bound, cap);
+        const int e = quicked_task_estimate(forced > 0 ? forced : B.est_bound, std::max(L.m[t], L.n[t]));
         est[t] = e;
         // an align step that might split (bpm_hirschberg.c:63-65) needs its real cutoff on the host
         const HGeom G = host_geometry(L.m[t], L.n[t], e);
@@ -1428,6 +1430,7 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
         else B.counters[2] += steps[t];            // the classic flow below counts its own pairs' stage 1
     }
     B.est_bound = quicked_estimate(top);
+    B.deferred_pairs = (int64_t)Ls.pair.size();
     if (Ls.pair.empty()) return;
     Ls.pad();
     // the classic flow for the pairs left, on idle streams, above whatever the pools hold (a later run of this thread
@@ -2189,6 +2192,8 @@ QE_API quicked_status_t quicked_pool_stats(int64_t stats_out[8]) {
     stats_out[2] = C->last_na; stats_out[3] = C->last_sub_batches; stats_out[4] = (int64_t)C->pool_budget;
     return QUICKED_OK;
 }
+
+QE_API int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch) { return batch ? batch->deferred_pairs : -1; }
 
 QE_API quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]) {
     memcpy(counters_out, batch->counters, sizeof(batch->counters));

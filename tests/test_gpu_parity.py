@@ -738,6 +738,8 @@ def test_quicked_device_side_stage1_equals_the_classic_flow(monkeypatch):
         assert rb.fetch() >= 0
         check(rb, mixed, ("async", est))
         assert list(rb.counters()[:5]) == list(classic_counters[:5])
+        # how many pairs the fetch had to align itself: those past stage 1 at least, all of them with an estimate of 3
+        assert rb.deferred_pairs() >= classic_counters[6] and (est != "3" or rb.deferred_pairs() == len(mixed))
         # two batches, two runs in flight, fetched in order
         rb2 = capi.ResidentBatch(other)
         assert rb.run(prm, sync=False) >= 0
@@ -748,6 +750,23 @@ def test_quicked_device_side_stage1_equals_the_classic_flow(monkeypatch):
         check(rb2, other, ("two in flight", est))
         rb.close()
         rb2.close()
+
+
+def test_bench_times_the_classic_flow_when_pairs_leave_stage_1():
+    """bench.py's timed loop never fetches, and an un-fetched fast QuickEd run leaves the pairs past stage 1 undone: on
+    data with such pairs the bench must time the host-driven flow (and say so), on the benchmark's kind of data the fast one"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, want in ((["--error", "0.02", "--indels-num", "2", "--indels-len", "300"], "classic"),
+                        (["--error", "0.05"], "stage-1 rule on the device"), (["--error", "0.35"], "stage-1 rule on the device")):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "quicked", "--pairs", "1500", "--length", "2000",
+                              "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-e2e"] + extra,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        f = d["quicked_flow"]
+        assert f["timed_flow"].startswith(want), f
+        assert (f["stage2_pairs"] > 0) == (want == "classic"), f
 
 
 def test_streaming_reload_from_an_uploader_thread():
