@@ -56,7 +56,7 @@ struct DevicePool {
     struct Chunk { uint8_t* base; size_t cap; };
     std::vector<Chunk> chunks;
     size_t cur = 0, top = 0, cap = 0;            // cap = total bytes over all chunks
-    uint64_t generation = 0;                     // bumped whenever handed-out pointers stop being valid (reset / release_all)
+    std::atomic<uint64_t> generation{0};         // bumped whenever handed-out pointers stop being valid (reset / release_all); read by fetching threads
     // out of memory: the thread's other pools are asked to give theirs back (their runs are waited for first) and the
     // allocation is tried once more; set by Context
     static inline bool (*reclaim_fn)(DevicePool* keep) = nullptr;
@@ -1650,7 +1650,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     QE_TRACE_POINT("pool mirror");
     B.ev_done_set[par] = true;
     if (pf && pf->kind != 0) {
-        pf->pool = &C.pa(); pf->generation = C.pa().generation; pf->parity = par;
+        pf->pool = &C.pa(); pf->generation = C.pa().generation.load(); pf->parity = par;
         for (int q = 0; q < 8; ++q) pf->counters[q] = B.counters[q];
         B.pending_fetch = pfp;
     }
@@ -1678,7 +1678,7 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
     PendingFetch& F = *static_cast<PendingFetch*>(hold.get());
     B.pending_fetch.reset();
     HIP_CHECK(hipEventSynchronize(B.ev_done[F.parity]));
-    if (F.pool->generation != F.generation) {
+    if (F.pool->generation.load() != F.generation) {
         fprintf(stderr, "[quicked_hip] quicked_batch_fetch: the run's device results were overwritten by later runs of the "
                         "thread that queued it (fetch before queueing a third run)\n");
         return QUICKED_ERROR;
