@@ -211,7 +211,8 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
     for rb in rbs:                                        # warm: code objects, pools of the rotation
         assert rb.run(params, sync=True) >= 0
     uploaded = [threading.Event() for _ in range(nbatches)]
-    fetched = [threading.Event() for _ in range(nbatches)]
+    fetched = [threading.Event() for _ in range(nbatches)]      # results checked: the batch object may be reloaded
+    on_host = [threading.Event() for _ in range(nbatches)]      # quicked_batch_fetch returned
     err = []
 
     tm = {"reload": 0.0, "run": 0.0, "fetch": 0.0}
@@ -244,6 +245,7 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
         tf = time.perf_counter()
         assert rb.fetch() >= 0, "quicked_batch_fetch failed"
         tm["fetch"] += time.perf_counter() - tf
+        on_host[k].set()                                   # the run's device results are no longer needed: its pool set may be reused
         s, st = rb.scores()
         assert (st >= 0).all()
         checks.append(int(s.astype(np.int64).sum()))
@@ -263,7 +265,7 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
                 finish(k)
         except Exception as e:      # noqa: BLE001
             err.append(e)
-            for ev in fetched:
+            for ev in fetched + on_host:
                 ev.set()
 
     t0 = time.perf_counter()
@@ -275,7 +277,7 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
     for k in range(nbatches):
         uploaded[k].wait()
         if k >= inflight:
-            fetched[k - inflight].wait()                    # at most `inflight` runs queued and not fetched (their device
+            on_host[k - inflight].wait()                    # at most `inflight` runs queued and not fetched (their device
         if err:                                             # results live in the queueing thread's three rotating pools)
             break
         tr = time.perf_counter()
