@@ -273,6 +273,56 @@ __device__ __forceinline__ void slots_pass(bool act, int i, int r, u64* Pv, u64*
     hinP = houtP; hinM = houtM;
 }
 
+// Second 64-column chunk of an on-chip WindowEd(2,1) window: its two blocks in one skewed pass (slot 1 one column behind
+// slot 0, cf. run64_skew).  Slot 0 collects its 64 carry-outs (gP / gM: the traceback recomputes block 1's tiles from
+// them), slot 1 leaves {Pv, Mv} BEFORE every 8th column in LDS (st[grp * st_stride], run64_fast's STORE == 3).
+// patch: the x86 SSE kernel feeds block 1's LAST column the carries of block 0's column one past the window
+// (bpm_windowed.c:428-444); Eq_x is that column's Eq word for block 0.
+__device__ __forceinline__ void run64_win2(u64& P0, u64& M0, u64& P1, u64& M1, u64 a0, u64 b0, u64 a1, u64 b1, u64 T0, u64 T1,
+                                           u64 hinP, bool patch, u64 Eq_x, u64& gP, u64& gM, uint4* st, int st_stride) {
+    const u32 a0lo = lo32(a0), a0hi = hi32(a0), b0lo = lo32(b0), b0hi = hi32(b0);
+    const u32 a1lo = lo32(a1), a1hi = hi32(a1), b1lo = lo32(b1), b1hi = hi32(b1);
+    u32 P0lo = lo32(P0), P0hi = hi32(P0), M0lo = lo32(M0), M0hi = hi32(M0);
+    u32 P1lo = lo32(P1), P1hi = hi32(P1), M1lo = lo32(M1), M1hi = hi32(M1);
+    u32 oPlo = 0, oPhi = 0, oMlo = 0, oMhi = 0;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const u32 t0 = half ? hi32(T0) : lo32(T0), t1 = half ? hi32(T1) : lo32(T1);
+        const u32 hp = half ? hi32(hinP) : lo32(hinP);
+        u32 g0P = 0, g0M = 0;
+        u32 m0[32], m1[32];
+#pragma unroll
+        for (int s = 0; s < 33; ++s) {
+            if (s < 32) {
+                m0[s] = (u32)__builtin_amdgcn_sbfe((int)t0, s, 1);
+                m1[s] = (u32)__builtin_amdgcn_sbfe((int)t1, s, 1);
+            }
+            if (s >= 1) {                                     // slot 1 first: it consumes the carries of the previous step
+                const int c = s - 1;
+                if ((c & 7) == 0) st[(4 * half + (c >> 3)) * st_stride] = make_uint4(P1lo, P1hi, M1lo, M1hi);
+                u32 inP = g0P & 1u, inM = g0M & 1u;
+                if (c == 31 && half == 1 && patch) {
+                    u64 Ph, Mh, Pe = mk64(P0lo, P0hi), Me = mk64(M0lo, M0hi);
+                    block_step(Eq_x, Pe, Me, 1u, 0u, Ph, Mh);
+                    inP = (u32)(Ph >> 63); inM = (u32)(Mh >> 63);
+                    g0P = (g0P & ~1u) | inP; g0M = (g0M & ~1u) | inM;      // the carry words the traceback reads carry the patch too
+                }
+                const u32 elo = bitop3<0x90>(~(a1lo ^ m0[c]), b1lo, m1[c]), ehi = bitop3<0x90>(~(a1hi ^ m0[c]), b1hi, m1[c]);
+                u32 ph_, mh_;
+                block_step_core(elo, ehi, P1lo, P1hi, M1lo, M1hi, inP, inM, ph_, mh_);      // the window's bottom carries go nowhere
+            }
+            if (s < 32) {
+                const u32 elo = bitop3<0x90>(~(a0lo ^ m0[s]), b0lo, m1[s]), ehi = bitop3<0x90>(~(a0hi ^ m0[s]), b0hi, m1[s]);
+                block_step_fused(elo, ehi, P0lo, P0hi, M0lo, M0hi, __builtin_amdgcn_ubfe(hp, s, 1), 0u, g0P, g0M);
+            }
+        }
+        const u32 rP = __builtin_bitreverse32(g0P), rM = __builtin_bitreverse32(g0M);
+        if (half) { oPhi = rP; oMhi = rM; } else { oPlo = rP; oMlo = rM; }
+    }
+    P0 = mk64(P0lo, P0hi); M0 = mk64(M0lo, M0hi); P1 = mk64(P1lo, P1hi); M1 = mk64(M1lo, M1hi);
+    gP = mk64(oPlo, oPhi); gM = mk64(oMlo, oMhi);
+}
+
 // ---------------------------------------------------------------------------
 // 64 columns of one block, fast form: every lane runs all 64 columns, bases are
 // pure ACGT, exported row is bit 63.  Fully unrolled; c is a literal.
@@ -1663,19 +1713,18 @@ __global__ __launch_bounds__(512) void k_windowed(WindowArgs A) {
                 run64_multi<2>(Pw, Mw, aw, bw, tx0[0], tx0[1], sse ? (0x5555555555555556ull | (ph_first & 1)) : ph_first, 0, xP, xM);
                 P0 = Pw[0]; M0 = Mw[0]; P1 = Pw[1]; M1 = Mw[1];
             }
-            run64_fast<0, true>(P0, M0, pl0[0], pl0[1], tx1[0], tx1[1], sse ? 0x5555555555555555ull : ph_first, 0, gP, gM, false, nullptr, 0, nullptr);
-            if (sse) {
-                // the SSE kernel runs block 0 one column past the window and feeds THAT column's carries to
-                // block 1's last column (bpm_windowed.c:428-444); 127 is odd, so always here
-                int tc = 4;                                              // text[tlen] reads as N (A.7(4))
-                if (on && pos_h + 1 < n) tc = plane_code(tp, t0 + pos_h + 1);
-                const u64 Eq = (tc == 4) ? pl0[2] : (~(pl0[0] ^ ((u64)0 - (u64)(tc & 1))) & ~(pl0[1] ^ ((u64)0 - (u64)((tc >> 1) & 1))) & ~pl0[2]);
-                u64 Ph, Mh, Pe = P0, Me = M0;
-                block_step(Eq, Pe, Me, 1u, 0u, Ph, Mh);
-                gP = (gP & ~(1ull << 63)) | (Ph & (1ull << 63));
-                gM = (gM & ~(1ull << 63)) | (Mh & (1ull << 63));
+            {   // second 64 columns: both blocks in one skewed pass; block 1 leaves its checkpoints in LDS
+                u64 Eq_x = 0;
+                if (sse) {
+                    // the SSE kernel runs block 0 one column past the window and feeds THAT column's carries to
+                    // block 1's last column (bpm_windowed.c:428-444); 127 is odd, so always here
+                    int tc = 4;                                              // text[tlen] reads as N (A.7(4))
+                    if (on && pos_h + 1 < n) tc = plane_code(tp, t0 + pos_h + 1);
+                    Eq_x = (tc == 4) ? pl0[2] : (~(pl0[0] ^ ((u64)0 - (u64)(tc & 1))) & ~(pl0[1] ^ ((u64)0 - (u64)((tc >> 1) & 1))) & ~pl0[2]);
+                }
+                run64_win2(P0, M0, P1, M1, pl0[0], pl0[1], pl1[0], pl1[1], tx1[0], tx1[1], sse ? 0x5555555555555555ull : ph_first,
+                           sse, Eq_x, gP, gM, &wck[0][lane], 64);
             }
-            run64_fast<3, true>(P1, M1, pl1[0], pl1[1], tx1[0], tx1[1], gP, gM, xP, xM, true, &wck[0][lane], 64, nullptr);
             if (on) steps += 256u;
             int vw = 127, hw = 127, wscore = 0;
             bool inr = on;
