@@ -1437,20 +1437,17 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     // may have its buffers there)
     HIP_CHECK(hipStreamSynchronize(C.stream_w));
     for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
-    const int keep_parity = B.parity;
-    const bool keep_staging = C.staging;
-    int32_t* const keep_score = B.d_score;
+    struct Restore {            // also when a HIP error unwinds through here
+        quicked_batch& B; Context& C; int parity; bool staging; int32_t* score; DevicePool::Mark mw, ma;
+        ~Restore() { C.pool_w.release(mw); C.pa().release(ma); C.phase_w(); B.parity = parity; C.staging = staging; B.d_score = score; }
+    } restore{B, C, B.parity, C.staging, B.d_score, C.pool_w.mark(), C.pa().mark()};
     B.parity = parity;
     C.staging = false;
     C.phase_w();
-    const DevicePool::Mark mw = C.pool_w.mark(), ma = C.pa().mark();
     auto enter_a = [&]() { C.phase_a(); };
     quicked_classic(B, C, p, Ls, true, matrix_budget, nullptr, enter_a, false);
     HIP_CHECK(hipStreamSynchronize(C.stream_w));
     for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
-    C.pool_w.release(mw); C.pa().release(ma);
-    C.phase_w();
-    B.parity = keep_parity; C.staging = keep_staging; B.d_score = keep_score;
 }
 
 static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
