@@ -405,7 +405,8 @@ def main():
                 os.environ["QE_QUICKED_FAST"] = "0"
                 flow["timed_flow"] = "classic (host-driven stages): pairs leave stage 1 on this data"
             else:
-                flow.setdefault("timed_flow", "stage-1 rule on the device, align step queued with it; no pair deferred to the fetch")
+                flow.setdefault("timed_flow", "stage-1 rule on the device, align step queued with it, where no pair may split (else host-driven "
+                                              "stage by stage: reads of >~ 20 kb); no pair deferred to the fetch")
         barrier(rb)
         t0 = time.perf_counter()
         for _ in range(steps):
