@@ -1357,9 +1357,10 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
             mat_bytes += (uint64_t)9 * (uint64_t)(L.n[t] / 64 + 3) * (uint64_t)G.ebb * 16u;     // band_layout's checkpoints
         }
         // Buffers for the estimate are wider than buffers for the bounds (every group is as wide as the batch's widest
-        // pair, plus the margin): worth it while three pool sets of them fit easily; a batch near the HBM's size keeps
-        // the classic flow (its runs take ~100 ms: one host round trip is nothing there) until it is reloaded
-        if (est_sized && (double)mat_bytes * 3.0 > 0.5 * (double)C.seen_total) { est_sized = false; B.est_bound = -1; }
+        // pair, plus the margin; 400 k pairs of 10 kb: 115 instead of 92 GB per run, cut into fill sub-batches by the
+        // planner either way).  A batch whose checkpoints exceed the HBM several times over keeps the classic flow (its
+        // runs take seconds: one host round trip is nothing there) until it is reloaded
+        if (est_sized && (double)mat_bytes > 1.5 * (double)C.seen_total) { est_sized = false; B.est_bound = -1; }
     }
     for (size_t t = 0; t < L.pair.size(); ++t) {
         if (L.pair[t] < 0) continue;
@@ -1641,7 +1642,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     {   // pre-size the other pools of the rotation -- only while that is cheap: big fill matrices are left to grow on demand
         size_t cap_all = 0;
         for (const auto& q : C.pool_a2) cap_all += q.cap;
-        if ((double)(cap_all + (size_t)(na - 1) * C.pa().cap) < 0.6 * (double)total0)
+        if ((double)(cap_all + (size_t)(na - 1) * C.pa().cap) < 0.78 * (double)total0)
             for (int q = 0; q < na; ++q) if (q != C.ai) C.pool_a2[q].mirror(C.pa());
     }
     QE_TRACE_POINT("pool mirror");
