@@ -1,34 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- the headline benchmark of the hot path on MI355X.
 
-A "step" is one pass of the hot path over one batch of synthetic read pairs
-whose ASCII bytes are already resident in HBM: pack -> BandEd score-only kernel
--> scores in HBM (configs[1] of BASELINE.json: 100 k pairs of 10 kb at 5 %
-error, reference default bandwidth 15 %).  `--workload quicked` runs configs[2]
-(QuickEd bound-and-align + CIGAR), `--workload quicked --pairs 10000 --length
-100000 --error 0.1` configs[3].
+A "step" is one pass of the hot path over one batch of synthetic read pairs whose ASCII bytes are already resident in
+HBM: pack -> kernels -> results in HBM.  The headline (`value`) is configs[1] of BASELINE.json: BandEd score-only,
+100 k pairs of 10 kb at 5 % error, reference default bandwidth 15 %.  The same JSON line also carries
+
+  workloads.quicked  configs[2]: QuickEd bound-and-align + CIGAR on the same pairs, with its own roofline / e2e /
+                     cpu_baseline objects (this is the HBM-relevant workload of the path)
+  strong_share       (N = 1) both workloads at 12 500 pairs per step: the per-GPU share of BASELINE.json's "100 k pairs
+                     at 8 GPUs", i.e. the rate one GPU of the 8-GPU strong-scaling target sees
+  strong             (N > 1) both workloads with `--pairs` pairs IN TOTAL split over the ranks
+  roofline           dominant kernel: algorithmic bytes / its launch duration ALONE on the chip (HIP events, a few
+                     synchronous steps); `kernel_ms_overlapped` is the same launch's duration inside the timed region,
+                     where up to `sets` runs share the chip; `aggregate_*` divide by the step time
+  valu               the same kernel against the chip's VALU issue rate (its real bound), step-time based
+  e2e                PCIe-inclusive rates: host buffers -> HBM -> run -> results on the host, batch after batch;
+                     ASCII over the link, 2-bit words the caller already holds, and ASCII packed to 2 bits by the
+                     library's SIMD host packer inside the clock (`ascii_hostpacked`)
+  cpu_baseline       the compiled reference (or the oracle port) on the host cores, N = 1 only
+  ranks_seen         all-reduce SUM of 1 over the ranks
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU.  Under a launcher (WORLD_SIZE set: the driver's
-`python -m torch.distributed.run ... bench.py --gpus N`) this process is one
-rank; without one, `--gpus N` starts the N ranks itself as a child
-torch.distributed.run BEFORE anything touches the GPU and relays its JSON line.
-Every rank owns its own shard of the seeded dataset (quicked_amd/shard.py), there
-is no data-path collective, and RCCL only reduces {pairs, cells, checksum} (SUM)
-and the elapsed time (MAX) at the end.
-
-The one JSON line carries, besides the contract's fields:
-  roofline      dominant kernel, algorithmic bytes / HIP-event launch duration
-  valu          the same kernel against the chip's VALU issue rate (its real bound)
-  e2e           PCIe-inclusive rate: reload (H2D) of batch k+1 overlapped with the run
-                of batch k, scores fetched (D2H) for every batch; per input format
-  strong        (N > 1) the same workload with `--pairs` pairs IN TOTAL split over the ranks
-  cpu_baseline  the compiled reference (or the oracle port) on the host cores, N = 1 only
+N > 1: one process per GPU.  Under a launcher (WORLD_SIZE set: the driver's `python -m torch.distributed.run ...
+bench.py --gpus N`) this process is one rank; without one, `--gpus N` starts the N ranks itself as a child
+torch.distributed.run BEFORE anything touches the GPU and relays its JSON line.  Every rank owns its own shard of the
+seeded dataset (quicked_amd/shard.py), there is no data-path collective, and RCCL only reduces {pairs, cells, checksum}
+(SUM) and the elapsed time (MAX) at the end.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import threading
 import time
@@ -52,6 +56,28 @@ INSTR_PER_BLOCK_COLUMN = 26.1
 ISSUE_CYCLES_PER_BLOCK_COLUMN = 61.0     # (2 766 x 2 + 570 x 4) / 128 block-columns of the unrolled 4-slot loop
 # reference anchors of BASELINE.md section 2 (one core of the survey container's 2.1 GHz Xeon, AVX2 build)
 CPU_ANCHOR_PER_CORE = {"banded_score": 2463.0, "quicked": 1680.0}
+STRONG_SHARE_PAIRS = 12500       # 100 k pairs over 8 GPUs (BASELINE.json north_star)
+
+
+def visible_gpus():
+    """GPUs of this node WITHOUT touching HIP (the launcher parent must not initialise the GPU): KFD topology nodes that
+    have SIMDs, else DRM render nodes; capped by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set"""
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                m = re.search(r"^simd_count\s+(\d+)", f.read(), re.M)
+            if m and int(m.group(1)) > 0:
+                n += 1
+        except OSError:
+            continue
+    if n == 0:
+        n = len(glob.glob("/dev/dri/renderD*"))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def measured_copy_bandwidth(nbytes=1 << 30, reps=8):
@@ -119,7 +145,7 @@ def usable_cpus():
     return n, quota
 
 
-def cpu_baseline(batch, params_kw, workload, budget_s=15.0, anchored=True):
+def cpu_baseline(batch, params_kw, workload, budget_s=10.0, anchored=True):
     """The compiled reference (oracle/_ref, kind "reference") or the oracle restatement (kind "port") on the host cores:
     oracle/cpu_bench.c, one aligner per OpenMP thread over disjoint pair ranges (the reference's own model,
     align_benchmark.c:246-284), on a bounded prefix of the same workload.  Threads = what this process may really use."""
@@ -158,7 +184,7 @@ def cpu_baseline(batch, params_kw, workload, budget_s=15.0, anchored=True):
     out = {"value": n / wall, "unit": "alignments/s", "cores": cores, "cpu_model": cpu_model(), "kind": kind,
            "sample": f"first {n} pairs of the same workload, {cores} OpenMP threads (affinity mask"
                      f"{'' if quota is None else f', cgroup quota {quota:.1f} CPUs'}; os.cpu_count() = {os.cpu_count()}), "
-                     "one aligner per thread",
+                     f"one aligner per thread, {wall:.1f} s of wall clock",
            "single_thread_value": single, "per_thread_value": per_thread,
            "reference_anchor_per_core": anchor,
            # a host whose cores run the reference far below the survey's anchor (shared / throttled
@@ -168,31 +194,61 @@ def cpu_baseline(batch, params_kw, workload, budget_s=15.0, anchored=True):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# end to end: host buffers -> HBM (H2D) -> run -> scores on the host (D2H), batch after batch
+# end to end: host buffers -> HBM (H2D) -> run -> results on the host (D2H), batch after batch
 # ---------------------------------------------------------------------------------------------------------------
 def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflight=2, uploaders=2, expect_cigar_bytes=None):
     """`nbatches` batches of the same host data through `slots` resident batch objects: `uploaders` uploader threads
     reload (quicked_batch_reload*, H2D) batches k+1.. (uploader u takes the batches with k % uploaders == u) while the main
-    thread queues run k (sync = 0) and fetches the scores of run k - inflight + 1 (quicked_batch_fetch, D2H).  Returns
-    alignments/s over everything between the first reload and the last fetch; batch creation (hipMalloc) and the first
-    upload are warm-up."""
+    thread queues run k (sync = 0) and a fetcher thread brings the results of run k over (quicked_batch_fetch, D2H).
+    fmt: ascii_pinned (ASCII pools over the link), 2bit_pinned (2-bit words the caller already holds),
+    ascii_hostpacked (ASCII pools packed to 2-bit words by quicked_wire_pack_pool on the uploader threads, inside the
+    clock, then shipped).  Returns alignments/s over everything between the first reload and the last fetch; batch
+    creation (hipMalloc) and the first upload are warm-up."""
     L = capi.lib()
     n = len(batch)
     frees = []
+    pack_threads = 0
+    src = None
     if fmt == "ascii_pinned":
         src = capi.pinned_copy(batch)
         make = lambda: capi.ResidentBatch(src)                                       # noqa: E731
-        reload_ = lambda rb: rb.reload(src)                                          # noqa: E731
+        reload_ = lambda rb, slot: rb.reload(src)                                    # noqa: E731
         nbytes = int(batch.pattern_len.astype(np.int64).sum() + batch.text_len.astype(np.int64).sum())
     elif fmt == "2bit_pinned":
         pw, po = capi.wire_pack_pool(batch.pattern_pool, batch.pattern_off, batch.pattern_len, capi.WIRE_2BIT)
         tw, to = capi.wire_pack_pool(batch.text_pool, batch.text_off, batch.text_len, capi.WIRE_2BIT)
         (pwp, h1), (twp, h2) = capi.pinned_array(pw), capi.pinned_array(tw)
         frees += [h1, h2]
-        src = None
         make = lambda: capi.ResidentBatch.from_wire(batch, capi.WIRE_2BIT, pwp, po, twp, to)       # noqa: E731
-        reload_ = lambda rb: rb.reload_wire(batch, capi.WIRE_2BIT, pwp, po, twp, to)               # noqa: E731
+        reload_ = lambda rb, slot: rb.reload_wire(batch, capi.WIRE_2BIT, pwp, po, twp, to)         # noqa: E731
         nbytes = int(pw.nbytes + tw.nbytes)
+    elif fmt == "ascii_hostpacked":
+        # the caller holds ASCII (pageable is fine: the CPU reads it); every batch is packed into the slot's own pinned word
+        # buffers by the uploader thread that then ships them
+        po, ptotal = capi.wire_offsets(batch.pattern_len, capi.WIRE_2BIT)
+        to, ttotal = capi.wire_offsets(batch.text_len, capi.WIRE_2BIT)
+        cores, _ = usable_cpus()
+        pack_threads = max(1, cores // max(uploaders, 1))
+        bufs = []
+        for _ in range(slots):
+            (pwp, h1), (twp, h2) = capi.pinned_array(np.zeros(ptotal + 1, np.uint64)), capi.pinned_array(np.zeros(ttotal + 1, np.uint64))
+            frees += [h1, h2]
+            bufs.append((pwp, twp))
+
+        def pack(slot):
+            pwp, twp = bufs[slot]
+            capi.wire_pack_pool(batch.pattern_pool, batch.pattern_off, batch.pattern_len, capi.WIRE_2BIT, threads=pack_threads, out=pwp)
+            capi.wire_pack_pool(batch.text_pool, batch.text_off, batch.text_len, capi.WIRE_2BIT, threads=pack_threads, out=twp)
+            return pwp, twp
+
+        def make():
+            pwp, twp = pack(0)
+            return capi.ResidentBatch.from_wire(batch, capi.WIRE_2BIT, pwp, po, twp, to)
+
+        def reload_(rb, slot):
+            pwp, twp = pack(slot)
+            return rb.reload_wire(batch, capi.WIRE_2BIT, pwp, po, twp, to)
+        nbytes = int(8 * (ptotal + ttotal))
     else:
         raise ValueError(fmt)
     rbs = []
@@ -208,12 +264,23 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
         for h in frees:
             L.quicked_host_free(h)
         raise
-    for rb in rbs:                                        # warm: code objects, pools of the rotation
-        assert rb.run(params, sync=True) >= 0
+    for rb in rbs:                                        # warm: code objects, pools of the rotation (asynchronous runs:
+        if rb.run(params, sync=False) < 0 or rb.fetch() < 0:      # the planner's depth for a stream of runs)
+            raise RuntimeError("end-to-end warm-up run failed")
+    # a run's device results live in one of the queueing thread's rotating pool sets until fetched: at most sets - 1
+    # runs may be queued and not yet fetched (include/quicked_batch.h)
+    sets = capi.pool_stats()["sets"]
+    inflight = max(1, min(inflight, sets - 1))
     uploaded = [threading.Event() for _ in range(nbatches)]
     fetched = [threading.Event() for _ in range(nbatches)]      # results checked: the batch object may be reloaded
     on_host = [threading.Event() for _ in range(nbatches)]      # quicked_batch_fetch returned
+    queued = [threading.Event() for _ in range(nbatches)]
     err = []
+
+    def fail(e):
+        err.append(e)
+        for ev in uploaded + fetched + on_host + queued:
+            ev.set()
 
     tm = {"reload": 0.0, "run": 0.0, "fetch": 0.0}
     lock = threading.Lock()
@@ -223,35 +290,36 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
             for k in range(u, nbatches, uploaders):
                 if k >= slots:
                     fetched[k - slots].wait()
+                if err:
+                    return
                 tu = time.perf_counter()
-                st = reload_(rbs[k % slots])
+                st = reload_(rbs[k % slots], k % slots)
                 with lock:
                     tm["reload"] += time.perf_counter() - tu
                 if st < 0:
                     raise RuntimeError(f"quicked_batch_reload: {st}")
                 uploaded[k].set()
         except Exception as e:      # noqa: BLE001
-            err.append(e)
-            for ev in uploaded:
-                ev.set()
+            fail(e)
 
     checks = []
     d2h_bytes = [0]
 
-    queued = [threading.Event() for _ in range(nbatches)]
-
     def finish(k):
         rb = rbs[k % slots]
         tf = time.perf_counter()
-        assert rb.fetch() >= 0, "quicked_batch_fetch failed"
+        if rb.fetch() < 0:
+            raise RuntimeError("quicked_batch_fetch failed")
         tm["fetch"] += time.perf_counter() - tf
         on_host[k].set()                                   # the run's device results are no longer needed: its pool set may be reused
         s, st = rb.scores()
-        assert (st >= 0).all()
+        if not (st >= 0).all():
+            raise RuntimeError("end-to-end run: some pairs failed")
         checks.append(int(s.astype(np.int64).sum()))
         if expect_cigar_bytes is not None:                 # CIGAR strings arrive with the fetch (one DMA into pinned memory)
             pool, off = rb.cigar_view()
-            assert pool.nbytes == expect_cigar_bytes and int((off >= 0).sum()) == n, "end-to-end CIGARs differ from the resident run's"
+            if pool.nbytes != expect_cigar_bytes or int((off >= 0).sum()) != n:
+                raise RuntimeError("end-to-end CIGARs differ from the resident run's")
             d2h_bytes[0] += pool.nbytes
         fetched[k].set()
 
@@ -261,12 +329,10 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
             for k in range(nbatches):
                 queued[k].wait()
                 if err:
-                    break
+                    return
                 finish(k)
         except Exception as e:      # noqa: BLE001
-            err.append(e)
-            for ev in fetched + on_host:
-                ev.set()
+            fail(e)
 
     t0 = time.perf_counter()
     ths = [threading.Thread(target=uploader, args=(u,)) for u in range(uploaders)]
@@ -274,18 +340,20 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
         th.start()
     fth = threading.Thread(target=fetcher)
     fth.start()
-    for k in range(nbatches):
-        uploaded[k].wait()
-        if k >= inflight:
-            on_host[k - inflight].wait()                    # at most `inflight` runs queued and not fetched (their device
-        if err:                                             # results live in the queueing thread's three rotating pools)
-            break
-        tr = time.perf_counter()
-        assert rbs[k % slots].run(params, sync=False) >= 0
-        tm["run"] += time.perf_counter() - tr
-        queued[k].set()
-    for ev in queued:
-        ev.set()
+    try:
+        for k in range(nbatches):
+            uploaded[k].wait()
+            if k >= inflight:
+                on_host[k - inflight].wait()                # at most `inflight` runs queued and not fetched
+            if err:
+                break
+            tr = time.perf_counter()
+            if rbs[k % slots].run(params, sync=False) < 0:
+                raise RuntimeError("quicked_batch_run failed")
+            tm["run"] += time.perf_counter() - tr
+            queued[k].set()
+    except Exception as e:      # noqa: BLE001
+        fail(e)
     fth.join()
     elapsed = time.perf_counter() - t0
     for th in ths:
@@ -297,12 +365,254 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
     for h in frees:
         L.quicked_host_free(h)
     if err:
-        raise err[0]
-    assert all(c == expect_checksum for c in checks), "end-to-end scores differ from the resident run's"
-    return {"value": n * nbatches / elapsed, "unit": "alignments/s", "batches": nbatches, "ms_per_batch": elapsed / nbatches * 1e3,
-            "h2d_bytes_per_batch": nbytes, "h2d_GBs": nbytes * nbatches / elapsed / 1e9,
-            "host_ms_per_batch": {k: v / nbatches * 1e3 for k, v in tm.items()}, "slots": slots, "inflight": inflight,
-            "uploader_threads": uploaders, "d2h_cigar_bytes_per_batch": d2h_bytes[0] // max(nbatches, 1)}
+        raise err[0] if isinstance(err[0], RuntimeError) else RuntimeError(repr(err[0]))
+    if not all(c == expect_checksum for c in checks):
+        raise AssertionError("end-to-end scores differ from the resident run's")
+    out = {"value": n * nbatches / elapsed, "unit": "alignments/s", "batches": nbatches, "ms_per_batch": elapsed / nbatches * 1e3,
+           "h2d_bytes_per_batch": nbytes, "h2d_GBs": nbytes * nbatches / elapsed / 1e9,
+           "host_ms_per_batch": {k: v / nbatches * 1e3 for k, v in tm.items()}, "slots": slots, "inflight": inflight,
+           "pool_sets": sets, "uploader_threads": uploaders, "d2h_cigar_bytes_per_batch": d2h_bytes[0] // max(nbatches, 1)}
+    if pack_threads:
+        out["host_pack_threads_per_uploader"] = pack_threads
+        out["host_pack_kernel"] = {0: "scalar", 1: "avx2+bmi2", 2: "avx512bw+bmi2"}.get(L.quicked_wire_pack_isa(-1), "?")
+    return out
+
+
+class Bench:
+    """one rank's legs; every leg reduces over the ranks through quicked_amd/shard.py"""
+
+    def __init__(self, args, rank, world, local_rank, dist, torch, device, share):
+        from quicked_amd import capi, datagen
+        self.args, self.rank, self.world, self.dist, self.torch, self.device = args, rank, world, dist, torch, device
+        self.capi, self.datagen = capi, datagen
+        self._cache = None
+        self.parallelism = f"pairs sharded over {world} GPU(s), no data-path collective" + (" [test: ranks share device 0]" if share else "")
+        if capi.lib().quicked_set_device(local_rank) < 0:
+            sys.exit(f"bench.py: rank {rank}: no HIP device {local_rank}")
+
+    def kw(self, workload):
+        capi = self.capi
+        if workload == "banded_score":
+            return dict(algo=capi.BANDED, only_score=True, bandwidth=self.args.bandwidth)
+        return dict(algo=capi.QUICKED, only_score=False, bandwidth=self.args.bandwidth)
+
+    def barrier(self, rb):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+        rb.sync()
+
+    def reduce(self, pairs, cells, checksum, elapsed, extra=()):
+        return shard.reduce_totals(self.dist, self.torch, self.device, pairs, cells, checksum, elapsed, extra_sum=extra)
+
+    # -----------------------------------------------------------------------------------------------------------
+    def timed_resident(self, workload, first, count, steps, warmup, solo_steps=3):
+        """the contract's loop: `warmup` untimed steps, then exactly `steps` steps between two barrier + synchronize.
+        -> dict(batch, scores, counters, elapsed, kernel ms overlapped / solo, cigar bytes, flow, latency)"""
+        args, capi = self.args, self.capi
+        params = capi.make_params(**self.kw(workload))
+        if self._cache is None or self._cache[0] != (first, count):      # the workloads of one line run on the same pairs
+            self._cache = ((first, count), self.datagen.generate(count, args.length, args.error, seed=args.seed, first=first,
+                                                                 indels_num=args.indels_num, indels_len=args.indels_len))
+        batch = self._cache[1]
+        rb = capi.ResidentBatch(batch)           # H2D happens here, outside the timed region
+        quick = workload == "quicked"
+        flow = {}
+        saved_fast = os.environ.get("QE_QUICKED_FAST")
+
+        def run_checked(sync):
+            st = rb.run(params, sync=sync)
+            if st < 0:
+                raise RuntimeError(f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}")
+
+        def timed_loop():
+            self.barrier(rb)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run_checked(args.sync_each_step)      # results stay resident in HBM; the driver still syncs where a stage needs host decisions
+            rb.sync()
+            self.barrier(rb)
+            return time.perf_counter() - t0
+
+        try:
+            # QuickEd: at least two untimed synchronous runs -- the first run of a batch is always a classic one and sets
+            # the bound estimate, the second shows whether the fast flow defers pairs to the fetch
+            for _ in range(max(warmup, 2 if quick else 0)):
+                run_checked(True)
+            if quick:
+                # A QuickEd run queued with sync = 0 leaves the pairs that go past stage 1 (or exceed the planned buffers) to
+                # the fetch.  The timed loop never fetches: if this data has such pairs, time the host-driven flow instead,
+                # which does all the work inside the run.
+                wc = rb.counters()
+                flow["stage2_pairs"], flow["stage3_pairs"] = int(wc[6]), int(wc[7])
+                flow["deferred_pairs"] = rb.deferred_pairs()
+                if flow["stage2_pairs"] or flow["deferred_pairs"]:
+                    os.environ["QE_QUICKED_FAST"] = "0"
+                    flow["timed_flow"] = "classic (host-driven stages): pairs leave stage 1 on this data"
+                else:
+                    flow["timed_flow"] = ("stage-1 rule on the device, align step queued with it, where no pair may split (else host-driven "
+                                          "stage by stage: reads of >~ 20 kb); no pair deferred to the fetch")
+            if not args.sync_each_step:              # asynchronous warm-up: a stream of runs rotates over more sets than a
+                run_checked(False)                   # synchronous one (planner, qe_driver.hip); every set allocates once
+                rb.sync()
+                for _ in range(capi.pool_stats()["sets"]):
+                    run_checked(False)
+                rb.sync()
+            rb.kernel_time()                         # drop the warm-up launches
+            elapsed = timed_loop()
+            kern_ms, kern_n = rb.kernel_time()
+            sets = capi.pool_stats()["sets"]
+            # one synchronous run to fetch results + work counters for the report ...
+            tl0 = time.perf_counter()
+            run_checked(True)
+            latency = time.perf_counter() - tl0
+            if quick and os.environ.get("QE_QUICKED_FAST") != "0" and rb.deferred_pairs():
+                # ... and to catch what the warm-up runs could not: pairs deferred to a fetch the timed loop never made
+                os.environ["QE_QUICKED_FAST"] = "0"
+                flow["timed_flow"] = "classic (host-driven stages): the fast flow deferred pairs to the fetch on this data (re-timed)"
+                flow["deferred_pairs"] = rb.deferred_pairs()
+                run_checked(True)
+                rb.kernel_time()
+                elapsed = timed_loop()
+                kern_ms, kern_n = rb.kernel_time()
+                run_checked(True)
+            scores, status = rb.scores()
+            assert (status >= 0).all(), "some pairs failed"
+            counters = rb.counters()
+            cig = capi.lib().quicked_batch_cigar_bytes(rb._h) if quick else None
+            # ... then the dominant kernel ALONE on the chip (no other run in flight): what the roofline fraction divides by
+            rb.kernel_time()
+            lat = []
+            for _ in range(solo_steps):
+                tl0 = time.perf_counter()
+                run_checked(True)
+                lat.append(time.perf_counter() - tl0)
+            solo_ms, solo_n = rb.kernel_time()
+            latency = min([latency] + lat)
+        finally:
+            if saved_fast is None:
+                os.environ.pop("QE_QUICKED_FAST", None)
+            else:
+                os.environ["QE_QUICKED_FAST"] = saved_fast
+            rb.close()
+        return dict(batch=batch, scores=scores, counters=counters, elapsed=elapsed, kern_ms=kern_ms, kern_n=kern_n,
+                    solo_ms=solo_ms, solo_n=solo_n, cigar_bytes=cig, flow=flow, sets=sets, latency_s=latency, params=params)
+
+    # -----------------------------------------------------------------------------------------------------------
+    def roofline(self, workload, r, pairs, step_s):
+        """roofline + valu objects of one resident leg"""
+        args = self.args
+        batch, counters = r["batch"], r["counters"]
+        per_launch_bytes = float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64) + 4).sum())
+        solo_s = (r["solo_ms"] / 1e3 / r["solo_n"]) if r["solo_n"] else float("nan")
+        over_s = (r["kern_ms"] / 1e3 / r["kern_n"]) if r["kern_n"] else float("nan")
+        extra = {}
+        if workload == "banded_score":
+            # SURVEY 8(d): B_so = plen + tlen + 4 per pair (ASCII in, int32 score out)
+            kernel, alg_bytes, work_blocks = "k_banded<false> (BandEd score-only)", per_launch_bytes, int(counters[0])
+        else:
+            # The fill stores a 16-byte checkpoint per (slot, 8 columns) and the 16-byte carry words per (slot, chunk):
+            # 2.25 B per block-column, and reads its inputs as bit-planes (3 bits per base); the traceback recomputes
+            # 16-column tiles from those.  SURVEY 8(d)'s figure (every column stored, 16 B per block-column and per
+            # traceback step) is what the reference's layout would move: kept as survey_equivalent_bytes, never divided
+            # by the time of a kernel that does not move those bytes
+            planes_in = 0.375 * float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64)).sum())
+            alg_bytes = planes_in + 2.25 * float(counters[1])
+            extra["survey_equivalent_bytes"] = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
+            kernel, work_blocks = "k_banded<true> (BandEd fill, checkpointed)", int(counters[1])
+        traffic, traffic_src = None, None
+        try:      # HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profiles.sh)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+                pm = json.load(f)
+            ent = pm.get(f"{workload}:{pairs}x{args.length}")
+            if ent:
+                traffic, traffic_src = ent["hbm_bytes"], ent.get("source")
+        except Exception:      # noqa: BLE001
+            traffic = None
+        achieved = alg_bytes / solo_s / 1e9
+        # work_blocks counts block-columns per LANE (one alignment); a wave64 instruction serves 64 of them
+        wave_instr = work_blocks / 64.0 * INSTR_PER_BLOCK_COLUMN
+        peak_instr = SIMDS * PEAK_CLOCK_HZ / 2.0
+        roof = dict({"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms": solo_s * 1e3, "kernel_ms_source": f"HIP events around the launch, {r['solo_n']} launches, one run at a time",
+                     "kernel_ms_overlapped": over_s * 1e3, "runs_in_flight": r["sets"],
+                     "aggregate_achieved": alg_bytes / step_s / 1e9, "aggregate_frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                     "note": "the BandEd kernels are integer-VALU-bound, not HBM-bound (SURVEY 8d); see valu.  frac = algorithmic bytes / "
+                             "the kernel's duration alone on the chip; aggregate_* divide by the step time (launches of consecutive "
+                             "runs overlap, so a launch inside the timed region lasts kernel_ms_overlapped)"}, **extra)
+        valu = {"bound": "VALU issue, one wave64 instruction per SIMD per 2 cycles", "unit": "wave-instructions/s",
+                "peak": peak_instr, "aggregate_achieved": wave_instr / step_s, "aggregate_frac": wave_instr / step_s / peak_instr,
+                "solo_kernel_frac": wave_instr / solo_s / peak_instr,
+                "block_columns_per_launch": work_blocks, "instructions_per_block_column": INSTR_PER_BLOCK_COLUMN,
+                "issue_cycles_per_block_column": ISSUE_CYCLES_PER_BLOCK_COLUMN,
+                "instruction_mix_bound_block_columns_per_s": SIMDS * PEAK_CLOCK_HZ * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN,
+                "aggregate_block_columns_per_s": work_blocks / step_s,
+                "note": "aggregate = per-step work / step time; peak assumes the 2.4 GHz peak clock (the chip holds less under this "
+                        "load: DESIGN.md 4.1)"}
+        return roof, valu, work_blocks
+
+    # -----------------------------------------------------------------------------------------------------------
+    def e2e(self, workload, r, checksum):
+        args, capi = self.args, self.capi
+        quick = workload != "banded_score"
+        out = {}
+        for fmt in ("ascii_pinned", "2bit_pinned", "ascii_hostpacked"):
+            res = None
+            # QuickEd's run call does more host work per run: one more run in flight and one more uploader hide it
+            for slots, inflight, uploaders in ((args.e2e_slots or (6 if quick else 4), args.e2e_inflight or (3 if quick else 2),
+                                                args.e2e_uploaders or (3 if quick else 2)), (3, 2, 1)):
+                try:
+                    res = e2e_leg(capi, r["batch"], r["params"], fmt, args.e2e_batches, checksum, slots=slots, inflight=inflight,
+                                  uploaders=uploaders, expect_cigar_bytes=r["cigar_bytes"])
+                    break
+                except (RuntimeError, MemoryError) as e:
+                    print(f"[bench] end-to-end leg ({workload}, {fmt}, {slots} resident batches): {e}", file=sys.stderr)
+            if res is None:      # HBM is held by the resident leg's pools: reported, not hidden
+                res = {"value": 0.0, "h2d_GBs": 0.0, "skipped": "no HBM left for resident batch objects next to the run's device pools"}
+            _, _, _, _, ext = self.reduce(0, 0, 0, 0.0, extra=(res["value"], res["h2d_GBs"]))
+            res["value"], res["h2d_GBs"] = ext[0], ext[1]
+            out[fmt] = res
+        out["note"] = ("reload (H2D) of batch k+1 overlapped with the run of batch k, scores (and CIGAR strings, where the workload "
+                       "makes them) fetched (D2H) per batch; summed over ranks.  ascii_pinned ships the bytes the reference's API "
+                       "takes (PCIe Gen5 x16 moves ~47-55 GB/s from pinned memory: ~2.7 M alignments/s of 10 kb); 2bit_pinned is a "
+                       "caller that already holds 2-bit words; ascii_hostpacked packs the caller's ASCII to 2-bit words on the host "
+                       "cores inside the clock (quicked_wire_pack_pool) and ships those")
+        return out
+
+    # -----------------------------------------------------------------------------------------------------------
+    def workload_object(self, workload, pairs, steps, warmup, with_e2e, with_cpu, scaling="weak"):
+        """one workload at `pairs` pairs per GPU (weak) or in total (strong): resident rate (+ roofline, e2e, cpu baseline)"""
+        args = self.args
+        first, count, _ = shard.plan(pairs, self.rank, self.world, scaling)
+        r = self.timed_resident(workload, first, count, steps, warmup)
+        cells = r["batch"].cells()
+        checksum = int(r["scores"].astype(np.int64).sum())
+        tot_pairs, tot_cells, tot_checksum, max_elapsed, _ = self.reduce(count, cells, checksum, r["elapsed"])
+        step_s = max_elapsed / steps
+        roof, valu, work_blocks = self.roofline(workload, r, pairs, step_s)
+        obj = {"value": tot_pairs * steps / max_elapsed, "unit": "alignments/s", "ms_per_step": step_s * 1e3,
+               "gcups": tot_cells * steps / max_elapsed / 1e9,
+               # cells actually computed (SURVEY 8d "band GCUPS"): 64 rows x block-advances of the dominant kernel, this rank x world
+               "band_gcups": 64.0 * work_blocks * self.world * steps / max_elapsed / 1e9,
+               "pairs_per_gpu": count, "total_pairs": tot_pairs, "scaling": scaling, "steps": steps,
+               "runs_in_flight": r["sets"], "single_batch_latency_ms": r["latency_s"] * 1e3,
+               "single_batch_value": count / r["latency_s"],
+               "score_checksum": tot_checksum, "roofline": roof, "valu": valu}
+        if r["flow"]:
+            obj["quicked_flow"] = r["flow"]
+        if r["cigar_bytes"] is not None:
+            obj["cigar_bytes_per_step"] = int(r["cigar_bytes"])
+        if with_e2e:
+            obj["e2e"] = self.e2e(workload, r, checksum)
+        if with_cpu and self.rank == 0 and self.world == 1:      # the CPU reference is timed on rank 0 at N = 1 only
+            base, ref_scores = cpu_baseline(r["batch"], dict(self.kw(workload)), workload, budget_s=args.cpu_budget,
+                                            anchored=(args.length == 10000 and abs(args.error - 0.05) < 1e-9))
+            n = len(ref_scores)
+            base["gpu_scores_identical_on_sample"] = bool((r["scores"][:n].astype(np.int64) == ref_scores).all())
+            obj["cpu_baseline"] = base
+        return obj
 
 
 def main():
@@ -316,15 +626,18 @@ def main():
     ap.add_argument("--bandwidth", type=int, default=15)
     ap.add_argument("--indels-num", type=int, default=0, help="large indels per pair (generate_dataset's -I), with --indels-len")
     ap.add_argument("--indels-len", type=int, default=0)
-    ap.add_argument("--workload", choices=["banded_score", "quicked"], default="banded_score")
+    ap.add_argument("--workload", choices=["banded_score", "quicked"], default="banded_score",
+                    help="the headline workload; with the default, QuickEd + CIGAR is also measured (workloads.quicked)")
+    ap.add_argument("--no-workloads", action="store_true", help="headline workload only (no workloads.quicked object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of wall clock for the CPU baseline's sample")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-batches", type=int, default=32,
+    ap.add_argument("--e2e-batches", type=int, default=24,
                     help="batches per end-to-end leg (pipeline fill and drain are inside the clock: ~3 batches' worth)")
     ap.add_argument("--e2e-slots", type=int, default=0, help="resident batch objects in rotation (0: 4 for score-only BandEd, 6 for QuickEd)")
     ap.add_argument("--e2e-uploaders", type=int, default=0, help="uploader threads (0: 2 for score-only BandEd, 3 for QuickEd)")
     ap.add_argument("--e2e-inflight", type=int, default=0, help="runs queued and not yet fetched (0: 2 for score-only BandEd, 3 for QuickEd)")
-    ap.add_argument("--no-strong", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="no strong (N > 1) / strong_share (N = 1) legs")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="profiling aid: no overlap between consecutive runs, so per-kernel durations are those of a kernel alone")
     ap.add_argument("--seed", type=int, default=0x51CED)
@@ -333,9 +646,8 @@ def main():
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # no launcher: start the ranks ourselves, as a child, before this process touches the GPU
-        import torch
-        have = torch.cuda.device_count()                    # does not initialise the GPU
+        # no launcher: start the ranks ourselves, as a child, before this process touches the GPU (sysfs only here)
+        have = visible_gpus()
         if have < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to run fewer ranks "
                      "than asked for")
@@ -366,186 +678,72 @@ def main():
         else:
             dist.init_process_group(backend)                    # reductions on host tensors (device = None)
 
-    from quicked_amd import capi, datagen
-    if capi.lib().quicked_set_device(local_rank) < 0:
-        sys.exit(f"bench.py: rank {rank}: no HIP device {local_rank}")
-
-    if args.workload == "banded_score":
-        kw = dict(algo=capi.BANDED, only_score=True, bandwidth=args.bandwidth)
-    else:
-        kw = dict(algo=capi.QUICKED, only_score=False, bandwidth=args.bandwidth)
-    params = capi.make_params(**kw)
-
-    def barrier(rb):
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        rb.sync()
-    parallelism = f"pairs sharded over {world} GPU(s), no data-path collective" + (" [test: ranks share device 0]" if share else "")
-
-    flow = {}
-
-    def timed_resident(first, count, steps, warmup):
-        """the contract's loop: `warmup` untimed steps, then exactly `steps` steps between two barrier + synchronize"""
-        batch = datagen.generate(count, args.length, args.error, seed=args.seed, first=first,
-                                 indels_num=args.indels_num, indels_len=args.indels_len)
-        rb = capi.ResidentBatch(batch)           # H2D happens here, outside the timed region
-        for _ in range(max(warmup, 0)):
-            st = rb.run(params, sync=True)
-            assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
-        rb.kernel_time()                         # drop the warm-up launches
-        if args.workload == "quicked":
-            # A QuickEd run queued with sync = 0 leaves the pairs that go past stage 1 (or exceed the planned buffers) to
-            # the fetch.  The timed loop never fetches: if this data has such pairs, time the host-driven flow instead,
-            # which does all the work inside the run.
-            wc = rb.counters() if warmup > 0 else np.zeros(8, dtype=np.int64)
-            flow["stage2_pairs"], flow["stage3_pairs"] = int(wc[6]), int(wc[7])
-            flow["deferred_pairs"] = rb.deferred_pairs() if warmup > 0 else 0
-            if flow["stage2_pairs"] or flow["deferred_pairs"]:
-                os.environ["QE_QUICKED_FAST"] = "0"
-                flow["timed_flow"] = "classic (host-driven stages): pairs leave stage 1 on this data"
-            else:
-                flow.setdefault("timed_flow", "stage-1 rule on the device, align step queued with it, where no pair may split (else host-driven "
-                                              "stage by stage: reads of >~ 20 kb); no pair deferred to the fetch")
-        barrier(rb)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            st = rb.run(params, sync=args.sync_each_step)     # results stay resident in HBM; the driver still syncs where a stage needs host decisions
-            assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
-        rb.sync()
-        barrier(rb)
-        elapsed = time.perf_counter() - t0
-        kern_ms, kern_n = rb.kernel_time()
-        # one synchronous run to fetch results + work counters for the report
-        st = rb.run(params, sync=True)
-        assert st >= 0, f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}"
-        scores, status = rb.scores()
-        assert (status >= 0).all(), "some pairs failed"
-        counters = rb.counters()
-        cig = capi.lib().quicked_batch_cigar_bytes(rb._h) if not kw.get("only_score") else None
-        rb.kernel_time()
-        rb.close()
-        return batch, scores, counters, elapsed, kern_ms, kern_n, cig
+    B = Bench(args, rank, world, local_rank, dist, torch, device, share)
+    ranks_seen = shard.count_ranks(dist, torch, device)
 
     # ---- the headline: weak scaling, `pairs` pairs per GPU, inputs resident in HBM
-    first, count, _ = shard.plan(args.pairs, rank, world, "weak")
-    batch, scores, counters, elapsed, kern_ms, kern_n, cigar_bytes = timed_resident(first, count, args.steps, args.warmup)
-    cells = batch.cells()
-    checksum = int(scores.astype(np.int64).sum())
-    tot_pairs, tot_cells, tot_checksum, max_elapsed, _ = shard.reduce_totals(dist, torch, device, count, cells, checksum, elapsed)
-
-    # ---- end to end (PCIe-inclusive), every rank on its own GPU and PCIe link; rates add up
-    e2e = None
-    if not args.no_e2e:
-        e2e = {}
-        for fmt in ("ascii_pinned", "2bit_pinned"):
-            # QuickEd's run call blocks while its bound stage executes (host decisions): one more run in flight hides it
-            quick = args.workload != "banded_score"
-            r = None
-            for slots, inflight, uploaders in ((args.e2e_slots or (6 if quick else 4), args.e2e_inflight or (3 if quick else 2),
-                                                args.e2e_uploaders or (3 if quick else 2)), (3, 2, 1)):
-                try:
-                    r = e2e_leg(capi, batch, params, fmt, args.e2e_batches, checksum, slots=slots, inflight=inflight,
-                                uploaders=uploaders, expect_cigar_bytes=cigar_bytes)
-                    break
-                except RuntimeError as e:
-                    print(f"[bench] end-to-end leg ({fmt}, {slots} resident batches): {e}", file=sys.stderr)
-            if r is None:      # HBM is held by the resident leg's pools: reported, not hidden
-                r = {"value": 0.0, "h2d_GBs": 0.0, "skipped": "no HBM left for resident batch objects next to the run's device pools"}
-            _, _, _, _, ext = shard.reduce_totals(dist, torch, device, 0, 0, 0, 0.0, extra_sum=(r["value"], r["h2d_GBs"]))
-            r["value"], r["h2d_GBs"] = ext[0], ext[1]
-            e2e[fmt] = r
-        e2e["note"] = ("create/reload (H2D) of batch k+1 overlapped with the run of batch k, scores (and CIGAR strings, where the "
-                       "workload makes them) fetched (D2H) per batch; "
-                       "summed over ranks; PCIe Gen5 x16 moves ~47-55 GB/s from pinned memory, which bounds the ASCII form at "
-                       "~2.5 M alignments/s per GPU")
-
-    # ---- strong scaling: the same workload with `pairs` pairs in total (BASELINE.json's "100 k pairs at 8 GPUs")
-    strong = None
-    if world > 1 and not args.no_strong:
-        sfirst, scount, stotal = shard.plan(args.pairs, rank, world, "strong")
-        _, s_scores, _, s_elapsed, _, _, _ = timed_resident(sfirst, scount, args.steps, 1)
-        s_pairs, _, s_checksum, s_max, _ = shard.reduce_totals(dist, torch, device, scount, 0, int(s_scores.astype(np.int64).sum()), s_elapsed)
-        strong = {"scaling": "strong", "total_pairs": s_pairs, "pairs_per_gpu": scount, "value": s_pairs * args.steps / s_max,
-                  "unit": "alignments/s", "ms_per_step": s_max / args.steps * 1e3, "score_checksum": s_checksum}
+    head = B.workload_object(args.workload, args.pairs, args.steps, args.warmup, with_e2e=not args.no_e2e,
+                             with_cpu=not args.no_cpu_baseline)
+    default_shape = args.workload == "banded_score" and not args.no_workloads
+    others = {}
+    if default_shape:
+        # configs[2] on the same pairs: QuickEd bound-and-align + CIGAR (the HBM-relevant workload of the path)
+        args.cpu_budget = min(args.cpu_budget, 6.0)
+        others["quicked"] = B.workload_object("quicked", args.pairs, args.steps, args.warmup, with_e2e=not args.no_e2e,
+                                              with_cpu=not args.no_cpu_baseline)
+    # ---- strong scaling: `pairs` pairs in total (BASELINE.json's "100 k pairs at 8 GPUs"); at N = 1 the per-GPU share of it
+    strong, strong_share = None, None
+    if not args.no_strong:
+        wls = [args.workload] + list(others)
+        if world > 1:
+            strong = {}
+            for wl in wls:
+                o = B.workload_object(wl, args.pairs, args.steps, 1, with_e2e=False, with_cpu=False, scaling="strong")
+                strong[wl] = {k: o[k] for k in ("value", "unit", "ms_per_step", "total_pairs", "pairs_per_gpu", "score_checksum",
+                                                 "runs_in_flight", "single_batch_latency_ms")}
+            # the headline workload's figures at the top of the object, as in round 2's line
+            strong.update({"scaling": "strong", **strong[args.workload]})
+        elif args.pairs > STRONG_SHARE_PAIRS:
+            strong_share = {"pairs_per_gpu": STRONG_SHARE_PAIRS, "of": "100 k pairs in total over 8 GPUs (BASELINE.json north_star)",
+                            "note": "`value` = steady rate of a stream of such batches (runs_in_flight of them on the device at once); "
+                                    "single_batch_value = one batch alone, synchronous (what a caller with exactly 100 k pairs sees)"}
+            for wl in wls:
+                o = B.workload_object(wl, STRONG_SHARE_PAIRS, max(args.steps, 40), 1, with_e2e=False, with_cpu=False)
+                strong_share[wl] = {k: o[k] for k in ("value", "unit", "ms_per_step", "runs_in_flight", "single_batch_latency_ms",
+                                                       "single_batch_value", "score_checksum")}
+                strong_share[wl]["aggregate_block_columns_per_s"] = o["valu"]["aggregate_block_columns_per_s"]
 
     line = None
     if rank == 0:
-        value = tot_pairs * args.steps / max_elapsed
-        per_launch_bytes = float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64) + 4).sum())
-        kern_s = (kern_ms / 1e3 / kern_n) if kern_n else float("nan")
-        step_s = max_elapsed / args.steps
-        roof_extra = {}
-        if args.workload == "banded_score":
-            # SURVEY 8(d): B_so = plen + tlen + 4 per pair (ASCII in, int32 score out)
-            kernel, alg_bytes, work_blocks = "k_banded<false> (BandEd score-only)", per_launch_bytes, int(counters[0])
-        else:
-            # The fill stores a 16-byte checkpoint per (slot, 8 columns) and the 16-byte carry words per (slot, chunk):
-            # 2.25 B per block-column, and reads its inputs as bit-planes (3 bits per base); the traceback recomputes
-            # 16-column tiles from those.  SURVEY 8(d)'s figure (every column stored, 16 B per block-column and per
-            # traceback step) is what the reference's layout would move: kept as survey_equivalent_bytes, never divided
-            # by the time of a kernel that does not move those bytes
-            planes_in = 0.375 * float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64)).sum())
-            alg_bytes = planes_in + 2.25 * float(counters[1])
-            roof_extra["survey_equivalent_bytes"] = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
-            kernel, work_blocks = "k_banded<true> (BandEd fill, checkpointed)", int(counters[1])
-        traffic, traffic_src = None, None
-        try:      # HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profiles.sh)
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
-                pm = json.load(f)
-            ent = pm.get(f"{args.workload}:{args.pairs}x{args.length}")
-            if ent:
-                traffic, traffic_src = ent["hbm_bytes"], ent.get("source")
-        except Exception:      # noqa: BLE001
-            traffic = None
-        achieved = alg_bytes / kern_s / 1e9
-        # work_blocks counts block-columns per LANE (one alignment); a wave64 instruction serves 64 of them
-        wave_instr = work_blocks / 64.0 * INSTR_PER_BLOCK_COLUMN
-        instr_rate = wave_instr / kern_s
-        peak_instr = SIMDS * PEAK_CLOCK_HZ / 2.0
+        label = f"{args.length / 1000:g}kb x {args.length / 1000:g}kb {args.error * 100:g}%-error pairs"
         line = {
-            "metric": "alignments/sec + GCUPS, 10kb x 10kb 5%-error pairs",
-            "value": value, "unit": "alignments/s", "gcups": tot_cells * args.steps / max_elapsed / 1e9,
-            # cells actually computed (SURVEY 8d "band GCUPS"): 64 rows x block-advances of the dominant kernel, this rank x world
-            "band_gcups": 64.0 * work_blocks * world * args.steps / max_elapsed / 1e9,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": max_elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": f"alignments/sec + GCUPS, {label}",
+            "value": head["value"], "unit": "alignments/s", "gcups": head["gcups"], "band_gcups": head["band_gcups"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": ranks_seen,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.workload}, DEVICE-RESIDENT inputs: {args.pairs} pairs/GPU x {args.length} bp @ {args.error:g} error, "
                                    f"bandwidth {args.bandwidth} %, seeded generator (SURVEY 8d), ASCII already in HBM when the clock "
-                                   "starts, scores left in HBM (end-to-end rates: e2e)",
+                                   "starts, results left in HBM (end-to-end rates: e2e)",
                        "pairs_per_gpu": args.pairs, "length": args.length, "error": args.error,
-                       "bandwidth": args.bandwidth, "parallelism": parallelism},
-            "roofline": dict({"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                              "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
-                              "aggregate_achieved": alg_bytes / step_s / 1e9,
-                              "hbm_copy_measured_GBs": measured_copy_bandwidth(),
-                              "note": "the BandEd kernels are integer-VALU-bound, not HBM-bound (SURVEY 8d); see valu"}, **roof_extra),
-            "valu": {"bound": "VALU issue, one wave64 instruction per SIMD per 2 cycles", "unit": "wave-instructions/s",
-                     "achieved": instr_rate, "peak": peak_instr, "frac": instr_rate / peak_instr,
-                     "aggregate_achieved": wave_instr / step_s,
-                     "aggregate_frac": wave_instr / step_s / peak_instr,
-                     "block_columns_per_launch": work_blocks, "instructions_per_block_column": INSTR_PER_BLOCK_COLUMN,
-                     "issue_cycles_per_block_column": ISSUE_CYCLES_PER_BLOCK_COLUMN,
-                     "instruction_mix_bound_block_columns_per_s": SIMDS * PEAK_CLOCK_HZ * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN,
-                     "aggregate_block_columns_per_s": work_blocks / step_s,
-                     "note": "achieved uses the launch duration (launches of consecutive runs overlap); aggregate uses the step "
-                             "time; peak assumes the 2.4 GHz peak clock (the chip holds less under this load: DESIGN.md 4.1)"},
-            "score_checksum": tot_checksum,
+                       "bandwidth": args.bandwidth, "parallelism": B.parallelism},
+            "runs_in_flight": head["runs_in_flight"], "single_batch_latency_ms": head["single_batch_latency_ms"],
+            "roofline": dict(head["roofline"], hbm_copy_measured_GBs=measured_copy_bandwidth()),
+            "valu": head["valu"],
+            "score_checksum": head["score_checksum"],
         }
-        if flow:
-            line["quicked_flow"] = flow
-        if e2e is not None:
-            line["e2e"] = e2e
+        for k in ("quicked_flow", "cigar_bytes_per_step", "e2e", "cpu_baseline"):
+            if k in head:
+                line[k] = head[k]
+        if others:
+            line["workloads"] = {wl: dict(o, config={"workload": f"{wl}, DEVICE-RESIDENT inputs, the same {args.pairs} pairs/GPU x "
+                                                                 f"{args.length} bp @ {args.error:g} error; CIGAR strings left in HBM "
+                                                                 "(end-to-end: e2e, strings on the host)"})
+                                 for wl, o in others.items()}
         if strong is not None:
             line["strong"] = strong
-        if not args.no_cpu_baseline and world == 1:          # the CPU reference is timed on rank 0 at N = 1 only
-            base, ref_scores = cpu_baseline(batch, {k: v for k, v in kw.items()}, args.workload,
-                                            anchored=(args.length == 10000 and abs(args.error - 0.05) < 1e-9))
-            n = len(ref_scores)
-            base["gpu_scores_identical_on_sample"] = bool((scores[:n].astype(np.int64) == ref_scores).all())
-            line["cpu_baseline"] = base
+        if strong_share is not None:
+            line["strong_share"] = strong_share
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -69,6 +69,19 @@ typedef enum { QUICKED_WIRE_2BIT = 2, QUICKED_WIRE_PLANES3 = 3 } quicked_wire_t;
 int64_t quicked_wire_words(int32_t len, int wire);
 /* host-side serializer of one sequence; QUICKED_ERROR if a symbol is not representable in `wire` */
 quicked_status_t quicked_wire_pack(const char* seq, int32_t len, int wire, uint64_t* out);
+/* The same serializer over a whole pool in one call: sequence i = pool[off[i] .. +len[i]) goes to out_words + out_off[i]
+ * (quicked_wire_words(len[i], wire) words; quicked_wire_offsets lays the sequences out back to back and returns the
+ * total).  SIMD (AVX-512BW or AVX2, with BMI2; picked at run time, scalar otherwise) on `threads` host threads (0: the
+ * CPUs the process may use, at most 32).  This is how a caller that holds ASCII -- what the reference's API consumes,
+ * quicked.c:405-437 -- gets under the PCIe bound: 2 GB of ASCII per 100 k pairs of 10 kb become 0.5 GB on the wire.
+ * Words identical to quicked_wire_pack's.  QUICKED_ERROR if a sequence holds a symbol `wire` cannot represent;
+ * *bad_seq (may be NULL) = the first such sequence, else -1. */
+quicked_status_t quicked_wire_pack_pool(int64_t n, const char* pool, const int64_t* off, const int32_t* len, int wire,
+                                        uint64_t* out_words, const int64_t* out_off, int threads, int64_t* bad_seq);
+int64_t quicked_wire_offsets(int64_t n, const int32_t* len, int wire, int64_t* out_off);
+/* which kernel quicked_wire_pack_pool uses: 0 scalar, 1 AVX2, 2 AVX-512BW; force >= 0 pins a kernel the CPU has (tests),
+ * force < 0 restores the run-time choice; returns the kernel in use, or -1 if the CPU lacks the one asked for */
+int quicked_wire_pack_isa(int force);
 quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
                                              const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
                                              const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len);

@@ -45,12 +45,16 @@ def hip_sources():
 def build_hip(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    # one translation unit: qe_driver.hip includes qe_kernels.hip
+    # one device translation unit (qe_driver.hip includes qe_kernels.hip) plus the host-only SIMD packer, which g++
+    # compiles (x86 intrinsics with per-function targets; never seen by the device pass)
     if force or _newer(HIP_LIB, hip_sources()):
+        hostpack_o = os.path.join(HERE, "qe_hostpack.o")
+        _run(["g++", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra", "-pthread", "-c",
+              "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "qe_hostpack.cpp"), "-o", hostpack_o])
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
                "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-               os.path.join(CSRC, "qe_driver.hip"), "-o", HIP_LIB]
+               os.path.join(CSRC, "qe_driver.hip"), "-Wl," + hostpack_o, "-lpthread", "-o", HIP_LIB]      # -Wl,: hipcc would compile a bare .o as HIP source
         cmd += os.environ.get("QE_HIPCC_FLAGS", "").split()      # experiments: -D switches of qe_kernels.hip
         _run(cmd)
     return HIP_LIB

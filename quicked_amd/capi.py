@@ -58,7 +58,7 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
            "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
            "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats", "quicked_batch_cigar_view",
-           "quicked_batch_deferred_pairs"]
+           "quicked_batch_deferred_pairs", "quicked_wire_pack_pool", "quicked_wire_offsets", "quicked_wire_pack_isa"]
 
 _LIB = None
 
@@ -115,6 +115,11 @@ def lib():
     L.quicked_batch_cigar_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.quicked_batch_deferred_pairs.restype = C.c_int64
     L.quicked_batch_deferred_pairs.argtypes = [C.c_void_p]
+    L.quicked_wire_pack_pool.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.POINTER(C.c_int64)]
+    L.quicked_wire_offsets.restype = C.c_int64
+    L.quicked_wire_offsets.argtypes = [C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+    L.quicked_wire_pack_isa.argtypes = [C.c_int]
     L.quicked_host_alloc.restype = C.c_void_p
     L.quicked_host_alloc.argtypes = [C.c_size_t]
     L.quicked_host_free.argtypes = [C.c_void_p]
@@ -208,19 +213,31 @@ class QuickedAligner:
 WIRE_2BIT, WIRE_PLANES3 = 2, 3
 
 
-def wire_pack_pool(pool, off, length, wire):
-    """host-side serializer over a byte pool: -> (uint64 words back to back, word offsets); QuickedException if a
-    sequence holds a symbol the wire format cannot represent"""
+def wire_offsets(length, wire):
+    """dense word layout of sequences of these lengths: -> (int64 word offsets, total words)"""
+    length = np.ascontiguousarray(length, dtype=np.int32)
+    woff = np.zeros(len(length), dtype=np.int64)
+    total = lib().quicked_wire_offsets(len(length), length.ctypes.data, wire, woff.ctypes.data)
+    if total < 0:
+        raise QuickedException(QUICKED_ERROR)
+    return woff, int(total)
+
+
+def wire_pack_pool(pool, off, length, wire, threads=0, out=None):
+    """host-side serializer over a byte pool, one C call (quicked_wire_pack_pool: SIMD, multi-threaded): -> (uint64 words
+    back to back, word offsets); `out` = a preallocated uint64 array (e.g. pinned) to pack into.  QuickedException if a
+    sequence holds a symbol the wire format cannot represent."""
     L = lib()
-    nw = np.array([L.quicked_wire_words(int(n), wire) for n in length], dtype=np.int64)
-    woff = np.concatenate([[0], np.cumsum(nw[:-1])]).astype(np.int64) if len(nw) else np.zeros(0, np.int64)
-    words = np.zeros(int(nw.sum()) + 1, dtype=np.uint64)
-    base = pool.ctypes.data
-    for i in range(len(length)):
-        st = L.quicked_wire_pack(C.cast(base + int(off[i]), C.c_char_p), int(length[i]), wire,
-                                 words.ctypes.data + 8 * int(woff[i]))
-        if st < 0:
-            raise QuickedException(st)
+    length = np.ascontiguousarray(length, dtype=np.int32)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    woff, total = wire_offsets(length, wire)
+    words = out if out is not None else np.zeros(total + 1, dtype=np.uint64)
+    assert words.dtype == np.uint64 and len(words) >= total
+    bad = C.c_int64(-1)
+    st = L.quicked_wire_pack_pool(len(length), pool.ctypes.data, off.ctypes.data, length.ctypes.data, wire,
+                                  words.ctypes.data, woff.ctypes.data, int(threads), C.byref(bad))
+    if st < 0:
+        raise QuickedException(st)
     return words, woff
 
 

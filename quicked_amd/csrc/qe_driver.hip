@@ -57,6 +57,10 @@ struct DevicePool {
     std::vector<Chunk> chunks;
     size_t cur = 0, top = 0, cap = 0;            // cap = total bytes over all chunks
     std::atomic<uint64_t> generation{0};         // bumped whenever handed-out pointers stop being valid (reset / release_all); read by fetching threads
+    // A fetch (any thread) copies a queued run's results out of this pool while holding `fetching`; whoever is about to
+    // recycle or free the pool's memory (the owner's next run on this set, the planner, the out-of-memory path) takes it
+    // first, so a fetch in progress finishes on valid memory and a fetch that comes too late sees the new generation
+    std::mutex fetching;
     // out of memory: the thread's other pools are asked to give theirs back (their runs are waited for first) and the
     // allocation is tried once more; set by Context
     static inline bool (*reclaim_fn)(DevicePool* keep) = nullptr;
@@ -79,6 +83,7 @@ struct DevicePool {
             chunks.clear(); cap = 0;
             add_chunk(total);
         }
+        std::lock_guard<std::mutex> lk(fetching);
         cur = 0; top = 0; ++generation;
     }
     struct Mark { size_t cur, top; };
@@ -114,8 +119,17 @@ struct DevicePool {
         }
     }
     void release_all() {
+        std::lock_guard<std::mutex> lk(fetching);
         for (auto& c : chunks) if (c.base) (void)hipFree(c.base);
         chunks.clear(); cap = 0; cur = 0; top = 0; ++generation;
+    }
+    // the out-of-memory path must not wait for a fetch that may itself be waiting for memory: skip a pool that is being read
+    bool try_release_all() {
+        std::unique_lock<std::mutex> lk(fetching, std::try_to_lock);
+        if (!lk.owns_lock()) return false;
+        for (auto& c : chunks) if (c.base) (void)hipFree(c.base);
+        chunks.clear(); cap = 0; cur = 0; top = 0; ++generation;
+        return true;
     }
     size_t used_hint() const { return cap; }
     ~DevicePool() { for (auto& c : chunks) if (c.base) (void)hipFree(c.base); }
@@ -170,25 +184,31 @@ struct Context {
     // VALU- or HBM-bound); a batch double-buffers its planes for that.
     // Consecutive runs alternate between two A streams / pools: a 100 k-pair kernel fills 391 of the 512 workgroup
     // slots launch_groups() allows, and the next run's kernel takes the other 121 at once instead of waiting.
-    // up to NA = 3 sets: at most two runs execute at a time (a batch has two plane sets); a third set lets the host
-    // queue run k while runs k-2 and k-1 are still on the device instead of blocking on the pool of run k-2
-    static constexpr int NA = 3;
-    hipStream_t stream_w = nullptr, stream_a2[NA] = {};
+    // Up to NA sets of {W stream + pool, A stream + pool, pinned stages} rotate between the consecutive runs of a thread;
+    // a batch object has as many plane sets.  Large batches use three (a 100 k-pair kernel nearly fills the chip: more in
+    // flight only queue); small ones as many as it takes to keep ~2 waves on every SIMD (plan in run_batch): a 12.5 k-pair
+    // run is 196 waves of ~11 ms each, the chip holds 2048.
+    static constexpr int NA = 12;
+    hipStream_t stream_w = nullptr;          // utility stream: loads, fetches, the validator -- everything outside a run
+    hipStream_t stream_w2[NA] = {}, stream_a2[NA] = {};
     hipStream_t stream = nullptr;            // where the current phase launches
-    DevicePool pool_w, pool_a2[NA];
-    int ai = 0;                              // which A stream / pool the current run uses
+    DevicePool pool_w, pool_w2[NA], pool_a2[NA];
+    int ai = 0;                              // which set the current run uses
     PinnedStage stage[2 * NA];               // see PinnedStage
     int si = 0;
     bool staging = false;                    // uploads on the current A stream go through stage[si]
     bool memory_tight = false;               // a pool had to take the others' memory once: no more rotation on this thread
     int last_na = 0, last_sub_batches = 0;   // what the planner chose for the last run (quicked_pool_stats)
+    int in_flight = 1;                       // runs of this thread that may be on the device at once while the current one executes
     size_t pool_budget = 0;                  // bytes one A pool may hold in this run (plan_pools)
     size_t seen_free = 0, seen_total = 0;    // last hipMemGetInfo reading of this device
     hipStream_t& sa() { return stream_a2[ai]; }
     DevicePool& pa() { return pool_a2[ai]; }
+    hipStream_t& sw() { return stream_w2[ai]; }
+    DevicePool& pw() { return pool_w2[ai]; }
     DevicePool* scratch_p = nullptr;         // the current phase's pool
-    hipEvent_t ev_pack = nullptr, ev_stage = nullptr, ev_decided = nullptr;
-    bool decided_set = false;                // the last run's k_stage1_decide (stream A) still reads pool_w: the next W phase waits for it
+    hipEvent_t ev_pack = nullptr, ev_stage = nullptr, ev_decided[NA] = {};
+    bool decided_set[NA] = {};               // the set's last run's k_stage1_decide (stream A) still reads its W pool: the set's next W phase waits for it
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // HIP-event pairs around the dominant kernel of every run since the last collection (bench.py's roofline leg)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
@@ -202,17 +222,24 @@ struct Context {
         }
         return &kev[kev_used++];
     }
-    void phase_w() { stream = stream_w; scratch_p = &pool_w; }
+    void phase_w() { stream = sw(); scratch_p = &pw(); }
     void phase_a() { stream = sa(); scratch_p = &pa(); }
+    void phase_u() { stream = stream_w; scratch_p = &pool_w; }
+    void sync_all() {
+        HIP_CHECK(hipStreamSynchronize(stream_w));
+        for (auto q : stream_w2) HIP_CHECK(hipStreamSynchronize(q));
+        for (auto q : stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+    }
     void init() {
         if (stream) return;
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&stream_w, hipStreamNonBlocking));
         for (auto& q : stream_a2) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        for (auto& q : stream_w2) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_decided, hipEventDisableTiming));
-        phase_w();
+        for (auto& e : ev_decided) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        phase_u();
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
     }
@@ -224,6 +251,7 @@ static void qe_timer_start(profiler_timer_t* t);
 static void qe_timer_stop(profiler_timer_t* t);
 static thread_local Context* tl_ctx = nullptr;
 static bool reclaim_pools(DevicePool* keep);
+static thread_local DevicePool* tl_fetch_hold = nullptr;     // the pool whose `fetching` lock this thread holds (fetch_pending)
 static thread_local int tl_device = 0;
 // one Context per (host thread, device): a thread that alternates between devices keeps both (streams, pools and
 // pinned stages of the device it left stay where they are)
@@ -254,25 +282,36 @@ static bool reclaim_pools(DevicePool* keep) {
     C->memory_tight = true;
     ++g_reclaim_events;
     for (int q = 0; q < Context::NA; ++q) {
-        if (&C->pool_a2[q] == keep || C->pool_a2[q].cap == 0) continue;
-        if (hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
-        C->pool_a2[q].release_all();
-        freed = true;
+        if (&C->pool_a2[q] != keep && &C->pool_a2[q] != tl_fetch_hold && C->pool_a2[q].cap != 0) {
+            if (hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
+            freed |= C->pool_a2[q].try_release_all();
+        }
+        // a W pool of another set (its run, if any, is waited for; the current run's own W pool is still being read)
+        if (&C->pool_w2[q] != keep && C->pool_w2[q].cap > ((size_t)1 << 28) && q != C->ai) {
+            if (hipStreamSynchronize(C->stream_w2[q]) != hipSuccess || hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
+            freed |= C->pool_w2[q].try_release_all();
+        }
     }
     if (&C->pool_w != keep && C->pool_w.cap > ((size_t)1 << 30) && C->scratch_p != &C->pool_w) {
         if (hipStreamSynchronize(C->stream_w) != hipSuccess) return false;
-        C->pool_w.release_all();
-        freed = true;
+        freed |= C->pool_w.try_release_all();
     }
     return freed;
 }
+
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that
+// share a queue serialise.  A thread's runs rotate over up to NA sets of two streams, so that small batches can have many
+// runs on the device at once: ask for more queues unless the user has chosen a value.  Read by the runtime when it
+// initialises (the first HIP call of the process), so this has to happen at load time; a process that has already
+// initialised HIP keeps what it has.
+__attribute__((constructor)) static void qe_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 template <typename T>
 static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
     if (src.empty()) return;
     const size_t bytes = src.size() * sizeof(T);
     Context* C = tl_ctx;
-    if (C && C->staging && (s == C->sa() || s == C->stream_w)) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
+    if (C && C->staging && (s == C->sa() || s == C->sw())) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
         uint8_t* st = C->stage[C->si].take(bytes);
         memcpy(st, src.data(), bytes);
         HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
@@ -324,7 +363,8 @@ struct quicked_batch {
     int64_t *d_p_off = nullptr, *d_t_off = nullptr, *d_plp_off = nullptr, *d_plt_off = nullptr;
     int32_t *d_p_len = nullptr, *d_t_len = nullptr;
     // planes and flags are double-buffered by run parity (see Context)
-    static constexpr int NP = 3;                  // plane sets: runs k, k+1 (and for large batches k+2) may be on the device at once
+    static constexpr int NP = qe::Context::NA;    // plane sets: one per run of this batch that may be on the device at once
+    int np_alloc = 3;                             // how many of them this batch has (batch_load: 3 for large batches, more for small ones)
     u64 *d_pl_p[NP] = {}, *d_pl_t[NP] = {}, *d_pl_pr[NP] = {}, *d_pl_tr[NP] = {};
     u32* d_flags[NP] = {};
     int parity = 0;
@@ -406,16 +446,21 @@ static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ng
     int wpb = 4;
     static const int wpb_env = env_int("QE_WG_WAVES", 0);
     if (wpb_env > 0) wpb = std::min(wpb_env, max_waves);
-    static const int pin_env = env_int("QE_PIN_LDS", 54 * 1024);      // 3 x 54 KB > 160 KB >= 2 x 54 KB
-    const size_t lds = std::max((size_t)pin_env, lds_per_wave * (size_t)wpb);
+    const unsigned blocks = (unsigned)((ngroups + wpb - 1) / wpb);
+    // 54 KB: 3 x 54 KB > 160 KB >= 2 x 54 KB, two workgroups per CU.  When the launches in flight have fewer workgroups than
+    // the chip has CUs, 84 KB (one per CU): the dispatcher packs the workgroups of CONCURRENT small kernels two to a CU
+    // while other CUs idle (three 49-workgroup launches in flight: 16.5 ms each at 54 KB, 11.7 ms at 84 KB, 11.4 ms alone)
+    static const int pin_env = env_int("QE_PIN_LDS", 0);
+    const size_t pin = pin_env > 0 ? (size_t)pin_env : (((size_t)blocks * (size_t)std::max(1, C.in_flight) > 256) ? (size_t)54 * 1024 : (size_t)84 * 1024);
+    const size_t lds = std::max(pin, lds_per_wave * (size_t)wpb);
     static thread_local std::vector<std::pair<const void*, int>> configured;      // per host thread and device
     const void* fn = reinterpret_cast<const void*>(kernel);
     if (std::find(configured.begin(), configured.end(), std::make_pair(fn, tl_device)) == configured.end()) {
         HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured.emplace_back(fn, tl_device);
     }
-    const unsigned blocks = (unsigned)((ngroups + wpb - 1) / wpb);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * wpb), lds, C.stream, args);
+    HIP_CHECK(hipGetLastError());             // a rejected launch (block shape, LDS) must not pass for zeroed results
 }
 
 static void launch_pack(quicked_batch& B, Context& C, bool reversed) {
@@ -466,7 +511,7 @@ struct DevTasks {
 static void h2d_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
     Context* C = tl_ctx;
-    if (C && C->staging && (s == C->sa() || s == C->stream_w)) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
+    if (C && C->staging && (s == C->sa() || s == C->sw())) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
         uint8_t* st = C->stage[C->si].take(bytes);
         memcpy(st, src, bytes);
         HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
@@ -626,14 +671,14 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     a.only_if = nullptr;
     auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-    launch_groups(C, k_banded<false>, a, L.ngroups(), 16, 0);
+    launch_groups(C, k_banded<false>, a, L.ngroups(), 8, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
 }
 
 // lanes per alignment for the cooperative score-only kernel: enough waves to fill the chip
 // (>= ~4 per SIMD) while every lane keeps >= 2 band slots; QE_COOP_G overrides (0 / 1 = off)
-static int coop_lanes(const TaskList& L) {
+static int coop_lanes(const TaskList& L, int in_flight = 1) {
     const char* e = getenv("QE_COOP_G");
     int min_nsl = 1 << 30, n_max = 1;
     size_t live = 0;
@@ -651,7 +696,7 @@ static int coop_lanes(const TaskList& L) {
     const size_t target = std::min<size_t>(4096, (size_t)700 * (size_t)std::max(1, n_max / 10000));
     if (e) G = atoi(e);
     else
-        while (G < 64 && (live * G) / 64 < target) G *= 2;
+        while (G < 64 && ((live * G) / 64) * (size_t)std::max(1, in_flight) < target) G *= 2;      // runs in flight fill the chip together
     // the band-height test first + 2 < last must stay decidable G-2 chunks early: keep the band >= 3 G + 4 slots
     while (G > 1 && min_nsl < 3 * G + 4) G /= 2;
     return G < 2 ? 1 : G;
@@ -706,7 +751,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     b.mat = nullptr; b.g_mat_off = S.D.mat_off;
     b.o_score = S.O.score; b.o_first = S.O.first; b.o_last = S.O.last; b.o_posv = S.O.posv; b.o_adv = S.O.adv;
     b.o_maxrow = S.O.len; b.only_if = S.O.hew;
-    launch_groups(C, k_banded<false>, b, L.ngroups(), 16, 0);
+    launch_groups(C, k_banded<false>, b, L.ngroups(), 8, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
 }
@@ -793,7 +838,7 @@ static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskLi
     a.o_maxrow = S.O.len;
     auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-    launch_groups(C, k_banded_wave, a, S.nt, 16, 0);                    // one wave per task
+    launch_groups(C, k_banded_wave, a, S.nt, 4, 0);                     // one wave per task
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
 }
@@ -801,7 +846,7 @@ static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskLi
 static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
                              bool fetch, int32_t** d_score_out, PendingFetch* pf = nullptr) {
     const bool wave = wave_form_wanted(L);
-    const int G = wave ? 1 : coop_lanes(L);
+    const int G = wave ? 1 : coop_lanes(L, fetch ? 1 : C.in_flight);
     const ScoreLaunch S = wave ? launch_banded_wave(B, C, L, reversed, true)
                                : ((G >= 2) ? launch_banded_coop(B, C, L, reversed, G, true) : launch_banded_score(B, C, L, reversed, true));
     if (d_score_out) *d_score_out = S.O.score;
@@ -1015,9 +1060,9 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         }
         F.pad(); V.pad();
         if (!B.have_rev[B.parity]) {
-            hipStream_t cur = C.stream; C.stream = C.stream_w;
+            hipStream_t cur = C.stream; C.stream = C.sw();
             launch_pack(B, C, true);
-            HIP_CHECK(hipStreamSynchronize(C.stream_w));
+            HIP_CHECK(hipStreamSynchronize(C.sw()));
             C.stream = cur; B.have_rev[B.parity] = true;
         }
         const int Gf = coop_lanes(F);
@@ -1436,19 +1481,23 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     Ls.pad();
     // the classic flow for the pairs left, on idle streams, above whatever the pools hold (a later run of this thread
     // may have its buffers there)
-    HIP_CHECK(hipStreamSynchronize(C.stream_w));
-    for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+    C.sync_all();
     struct Restore {            // also when a HIP error unwinds through here
         quicked_batch& B; Context& C; int parity; bool staging; int32_t* score; DevicePool::Mark mw, ma;
-        ~Restore() { C.pool_w.release(mw); C.pa().release(ma); C.phase_w(); B.parity = parity; C.staging = staging; B.d_score = score; }
-    } restore{B, C, B.parity, C.staging, B.d_score, C.pool_w.mark(), C.pa().mark()};
+        ~Restore() { C.pw().release(mw); C.pa().release(ma); C.phase_u(); B.parity = parity; C.staging = staging; B.d_score = score; }
+    } restore{B, C, B.parity, C.staging, B.d_score, C.pw().mark(), C.pa().mark()};
     B.parity = parity;
     C.staging = false;
     C.phase_w();
     auto enter_a = [&]() { C.phase_a(); };
     quicked_classic(B, C, p, Ls, true, matrix_budget, nullptr, enter_a, false);
-    HIP_CHECK(hipStreamSynchronize(C.stream_w));
-    for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+    C.sync_all();
+}
+
+// sets of {streams, pools, planes} that rotate for a batch of n pairs: enough runs in flight for ~2048 waves (two per SIMD)
+static int rotation_depth(int64_t n) {
+    const int64_t groups = std::max<int64_t>(1, (n + 63) / 64);
+    return (int)std::max<int64_t>(3, std::min<int64_t>(Context::NA, (2048 + groups - 1) / groups));
 }
 
 static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
@@ -1496,15 +1545,21 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // a sub-batch should still fill the chip: >= ~1600 groups (two waves on every SIMD) where the batch has that many
     const double frac = need_groups > 1600 ? 1600.0 / (double)need_groups : 1.0;
     const size_t min_set = need_fixed + (size_t)((double)need_mat * frac);
+    // depth of the rotation: three sets for batches that fill the chip; a small batch (12.5 k pairs = 196 waves of ~11 ms)
+    // needs more runs in flight to keep two waves on every SIMD.  A synchronous run is alone on the device anyway.
+    const int depth_wanted = fetch ? 3 : rotation_depth(B.n);
     int na = 1;
-    for (int k = (int)Context::NA; k >= 1; --k) if ((double)min_set * k <= (double)avail) { na = k; break; }
-    if (na_env > 0) na = std::min(na_env, (int)Context::NA);
+    for (int k = std::min(depth_wanted, B.np_alloc); k >= 1; --k) if ((double)min_set * k <= (double)avail) { na = k; break; }
+    if (na_env > 0) na = std::min(std::min(na_env, (int)Context::NA), B.np_alloc);
     if (C.memory_tight) na = 1;
     C.pool_budget = avail / (size_t)na;
     C.last_na = na;
+    C.in_flight = fetch ? 1 : na;
     B.np_used = na;
-    for (int q = na; q < Context::NA; ++q)              // a set that left the rotation gives its memory back
+    for (int q = na; q < Context::NA; ++q) {            // a set that left the rotation gives its memory back
         if (C.pool_a2[q].cap > ((size_t)1 << 30)) { HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_a2[q].release_all(); }
+        if (C.pool_w2[q].cap > ((size_t)1 << 30)) { HIP_CHECK(hipStreamSynchronize(C.stream_w2[q])); HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_w2[q].release_all(); }
+    }
     C.ai = (C.ai + 1) % na;
     const int par = B.parity = (B.parity + 1) % B.np_used;
     C.si = (C.si + 1) % (2 * na);
@@ -1521,9 +1576,9 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     else {
         C.phase_w();
-        C.pool_w.reset();
-        if (C.decided_set) { HIP_CHECK(hipStreamWaitEvent(C.stream_w, C.ev_decided, 0)); C.decided_set = false; }
-        if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.stream_w, B.ev_done[par], 0));
+        C.pw().reset();
+        if (C.decided_set[C.ai]) { HIP_CHECK(hipStreamWaitEvent(C.sw(), C.ev_decided[C.ai], 0)); C.decided_set[C.ai] = false; }
+        if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.sw(), B.ev_done[par], 0));
     }
     B.only_score_run = p.only_score;
     // sync == 0 leaves the host-side results of the last fetched run untouched (quicked_batch_fetch brings this run's)
@@ -1536,12 +1591,13 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     if ((unsigned)p.algo > (unsigned)HIRSCHBERG) {
         if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNKNOWN_ALGO);
         C.staging = false;
+        C.phase_u();
         return QUICKED_UNKNOWN_ALGO;
     }
     HIP_CHECK(hipEventRecord(C.ev0, C.stream));
     if (!B.packed) HIP_CHECK(hipMemsetAsync(B.d_flags[par], 0, (size_t)B.n * sizeof(u32), C.stream));
     launch_pack(B, C, false);
-    if (!serial) HIP_CHECK(hipEventRecord(C.ev_pack, C.stream_w));
+    if (!serial) HIP_CHECK(hipEventRecord(C.ev_pack, C.sw()));
     // phase A starts on the device when the planes are there and (stream order) the previous run's A phase is over;
     // its pool can be reset now because everything it launches is ordered behind that previous A phase
     auto enter_a = [&]() {
@@ -1557,7 +1613,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     QE_TRACE_POINT("setup+pack launch");
     TaskList L = all_pairs(B, p);
     QE_TRACE_POINT("task list");
-    if (L.pair.empty()) { C.staging = false; HIP_CHECK(hipStreamSynchronize(C.stream_w)); return QUICKED_EMPTY_SEQUENCE; }
+    if (L.pair.empty()) { C.staging = false; HIP_CHECK(hipStreamSynchronize(C.stream)); C.phase_u(); return QUICKED_EMPTY_SEQUENCE; }
     StageResult R;
 
     switch (p.algo) {
@@ -1592,7 +1648,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
                          nullptr, false, false, nullptr, nullptr, &W1, &T1);
             qe_timer_stop(tl_timers.windowed_s);
             QE_TRACE_POINT("fast: stage 1 queued");
-            HIP_CHECK(hipEventRecord(C.ev_stage, C.stream_w));
+            HIP_CHECK(hipEventRecord(C.ev_stage, C.sw()));
             enter_a();
             QE_TRACE_POINT("fast: phase A entered");
             HIP_CHECK(hipStreamWaitEvent(C.sa(), C.ev_stage, 0));
@@ -1604,8 +1660,8 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             sa.nt = (int32_t)nt; sa.pair = T1.pair; sa.m = T1.m; sa.n = T1.n; sa.score = W1.score; sa.hew = W1.hew; sa.steps = W1.steps;
             sa.est = d_est; sa.hew_percentage = p.hew_percentage[0]; sa.o_cut = d_cut; sa.o_skip = d_skip; sa.o_steps = d_steps;
             hipLaunchKernelGGL(k_stage1_decide, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, C.stream, sa);
-            HIP_CHECK(hipEventRecord(C.ev_decided, C.stream));          // the stage's outputs live in pool_w, which the next run recycles
-            C.decided_set = true;
+            HIP_CHECK(hipEventRecord(C.ev_decided[C.ai], C.stream));    // the stage's outputs live in the set's W pool, which the set's next run recycles
+            C.decided_set[C.ai] = true;
             QE_TRACE_POINT("fast: decide queued");
             TaskList LA;
             for (size_t t = 0; t < nt; ++t) {
@@ -1652,11 +1708,10 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         for (int q = 0; q < 8; ++q) pf->counters[q] = B.counters[q];
         B.pending_fetch = pfp;
     }
-    C.phase_w();
+    C.phase_u();
     B.pending = true;
     if (fetch) {
-        HIP_CHECK(hipStreamSynchronize(C.stream_w));
-        for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+        C.sync_all();
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, C.ev0, C.ev1));
         B.counters[5] = (int64_t)(ms * 1e6);
@@ -1676,12 +1731,19 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
     PendingFetch& F = *static_cast<PendingFetch*>(hold.get());
     B.pending_fetch.reset();
     HIP_CHECK(hipEventSynchronize(B.ev_done[F.parity]));
+    // the run's device results stay where they are until this fetch is over: whoever recycles or frees that pool (the
+    // queueing thread's next run on the set, its planner, its out-of-memory path) waits for `fetching`
+    struct Hold {
+        std::unique_lock<std::mutex> lk;
+        explicit Hold(DevicePool* p) : lk(p->fetching) { tl_fetch_hold = p; }
+        ~Hold() { tl_fetch_hold = nullptr; }
+    } hold_pool(F.pool);
     if (F.pool->generation.load() != F.generation) {
         fprintf(stderr, "[quicked_hip] quicked_batch_fetch: the run's device results were overwritten by later runs of the "
-                        "thread that queued it (fetch before queueing a third run)\n");
+                        "thread that queued it (fetch before that thread has queued quicked_pool_stats()[2] more runs)\n");
         return QUICKED_ERROR;
     }
-    C.phase_w();
+    C.phase_u();
     reset_host_results(B);
     for (int q = 0; q < 8; ++q) B.counters[q] = F.counters[q];
     if (F.kind == 1) {
@@ -1856,15 +1918,17 @@ static void batch_load(quicked_batch* B, Context& C, int64_t n,
             return la > lb;
         });
     auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    // plane sets: one per run of this batch that may be on the device at once (run_batch's rotation depth)
+    B->np_alloc = rotation_depth(n);
     const size_t need = pad(p_bytes + 64) + pad(t_bytes + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
-                        2 * quicked_batch::NP * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + quicked_batch::NP * pad((size_t)n * 4) + 4096;
+                        2 * (size_t)B->np_alloc * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + (size_t)B->np_alloc * pad((size_t)n * 4) + 4096;
     batch_arena(B, need);
     qe::ArenaCarver A{B->arena, 0};
     B->d_asc_p = A.take<uint8_t>(p_bytes + 64); B->d_asc_t = A.take<uint8_t>(t_bytes + 64);
     B->d_p_off = A.take<int64_t>((size_t)n); B->d_t_off = A.take<int64_t>((size_t)n);
     B->d_plp_off = A.take<int64_t>((size_t)n); B->d_plt_off = A.take<int64_t>((size_t)n);
     B->d_p_len = A.take<int32_t>((size_t)n); B->d_t_len = A.take<int32_t>((size_t)n);
-    for (int q = 0; q < quicked_batch::NP; ++q) {
+    for (int q = 0; q < B->np_alloc; ++q) {
         B->d_pl_p[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_t[q] = A.take<u64>(B->pl_t_words + 8);
         B->d_pl_pr[q] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[q] = A.take<u64>(B->pl_t_words + 8);
         B->d_flags[q] = A.take<u32>((size_t)n);
@@ -2009,6 +2073,7 @@ static void batch_load_packed(quicked_batch* B, Context& C, int64_t n, int wire,
     B->d_pl_pr[0] = A.take<u64>(B->pl_p_words + 8); B->d_pl_tr[0] = A.take<u64>(B->pl_t_words + 8);
     B->d_flags[0] = A.take<u32>((size_t)n);
     B->d_asc_p = nullptr; B->d_asc_t = nullptr;
+    B->np_alloc = quicked_batch::NP;
     for (int q = 0; q < quicked_batch::NP; ++q) {          // every set is the same resident planes
         B->d_pl_p[q] = B->d_pl_p[0]; B->d_pl_t[q] = B->d_pl_t[0]; B->d_pl_pr[q] = B->d_pl_pr[0]; B->d_pl_tr[q] = B->d_pl_tr[0];
         B->d_flags[q] = B->d_flags[0];
@@ -2086,8 +2151,7 @@ QE_API quicked_status_t quicked_batch_sync(quicked_batch_t* batch) {
     return guard(batch, [](quicked_batch* B, void*) {
         tl_device = B->device;
         Context& C = ctx();
-        HIP_CHECK(hipStreamSynchronize(C.stream_w));
-        for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+        C.sync_all();
         B->pending = false;
         return QUICKED_OK;
     }, nullptr);
@@ -2099,8 +2163,7 @@ QE_API quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double
         Arg* x = (Arg*)a;
         tl_device = B->device;
         Context& C = ctx();
-        HIP_CHECK(hipStreamSynchronize(C.stream_w));
-        for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+        C.sync_all();
         double total = 0;
         for (size_t i = 0; i < C.kev_used; ++i) {
             float ms = 0;
@@ -2159,9 +2222,8 @@ QE_API quicked_status_t quicked_batch_validate(quicked_batch_t* batch, const cha
         if (B->packed) return QUICKED_UNIMPLEMENTED;          // the validator compares raw bytes; a packed batch has none
         tl_device = B->device;
         Context& C = ctx();
-        for (auto q : C.stream_a2) HIP_CHECK(hipStreamSynchronize(q));
-        HIP_CHECK(hipStreamSynchronize(C.stream_w));
-        C.phase_w();
+        C.sync_all();
+        C.phase_u();
         const DevicePool::Mark mk = C.pool_w.mark();
         char* d_pool = C.pool_w.take<char>((size_t)x->bytes + 16);
         int64_t* d_off = C.pool_w.take<int64_t>((size_t)B->n + 1);
@@ -2186,6 +2248,7 @@ QE_API quicked_status_t quicked_pool_stats(int64_t stats_out[8]) {
     Context* C = tl_ctx;
     if (!C) return QUICKED_OK;
     for (const auto& q : C->pool_a2) stats_out[0] += (int64_t)q.cap;
+    for (const auto& q : C->pool_w2) stats_out[0] += (int64_t)q.cap;
     stats_out[0] += (int64_t)C->pool_w.cap;
     stats_out[2] = C->last_na; stats_out[3] = C->last_sub_batches; stats_out[4] = (int64_t)C->pool_budget;
     return QUICKED_OK;

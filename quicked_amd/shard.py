@@ -40,6 +40,15 @@ def reduce_totals(dist, torch, device, pairs, cells, checksum, elapsed, extra_su
     return int(v[0]), int(v[1]), int(v[2]), float(e.item()), v[3:]
 
 
+def count_ranks(dist, torch, device):
+    """all-reduce SUM of 1: how many ranks really took part (1 without a process group)"""
+    if dist is None:
+        return 1
+    t = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(t.item()))
+
+
 def launch_ranks(n_gpus, script, argv, port=None):
     """`python script --gpus N ...` without a launcher: start N ranks (one per GPU) with torch.distributed.run as a CHILD
     process -- before this process has touched the GPU; a process that has initialised HIP must never exec -- relay the

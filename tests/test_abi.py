@@ -156,3 +156,57 @@ def test_committed_bench_lines_follow_the_contract():
             assert 0 < d["valu"]["aggregate_frac"] < 1
             if "banded_score" in f:
                 assert d["e2e"]["2bit_pinned"]["value"] > d["e2e"]["ascii_pinned"]["value"] > 0
+
+
+def test_wire_pack_pool_equals_the_per_sequence_serializer():
+    """quicked_wire_pack_pool (SIMD, multi-threaded; no GPU involved) writes the words quicked_wire_pack writes, on ragged
+    lengths around every block border, for both wire formats and every kernel this CPU has; unrepresentable symbols are
+    refused with the first offending sequence"""
+    import ctypes as C
+    import numpy as np
+    from quicked_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(7)
+    lens = [0, 1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 192, 193, 1000, 4097, 10000] + \
+           [int(x) for x in rng.integers(1, 3000, 60)]
+    best = L.quicked_wire_pack_isa(-1)
+    assert best in (0, 1, 2)
+    try:
+        for wire, alphabet in ((capi.WIRE_2BIT, b"ACGT"), (capi.WIRE_PLANES3, b"ACGTN")):
+            seqs = [bytes(rng.choice(np.frombuffer(alphabet, np.uint8), n).tolist()) for n in lens]
+            gap = [int(x) for x in rng.integers(0, 9, len(seqs))]          # sequences need not lie back to back
+            pool = bytearray()
+            off = []
+            for s, g in zip(seqs, gap):
+                pool += b"#" * g
+                off.append(len(pool))
+                pool += s
+            pool = np.frombuffer(bytes(pool) + b"#" * 64, np.uint8)
+            off = np.array(off, np.int64)
+            ln = np.array(lens, np.int32)
+            ref_words = []
+            for s in seqs:
+                w = np.zeros(max(L.quicked_wire_words(len(s), wire), 1), np.uint64)
+                assert L.quicked_wire_pack(s, len(s), wire, w.ctypes.data) == 0
+                ref_words.append(w[:L.quicked_wire_words(len(s), wire)])
+            for isa in range(best + 1):
+                assert L.quicked_wire_pack_isa(isa) == isa
+                for threads in (1, 3, 0):
+                    words, woff = capi.wire_pack_pool(pool, off, ln, wire, threads=threads)
+                    for i, w in enumerate(ref_words):
+                        got = words[int(woff[i]): int(woff[i]) + len(w)]
+                        assert (got == w).all(), (wire, isa, threads, lens[i])
+                # a symbol the wire cannot carry: lower case, IUPAC, N in the 2-bit form -- at a block border and in a tail
+                for pos_seq, pos, sym in ((20, 5000, b"a"), (18, 100, b"R"), (12, 64, b"n")) + (((19, 4096, b"N"),) if wire == 2 else ()):
+                    bad = bytearray(pool.tobytes())
+                    bad[int(off[pos_seq]) + pos] = sym[0]
+                    badp = np.frombuffer(bytes(bad), np.uint8)
+                    woff2, total = capi.wire_offsets(ln, wire)
+                    out = np.zeros(total + 1, np.uint64)
+                    which = C.c_int64(-7)
+                    st = L.quicked_wire_pack_pool(len(ln), badp.ctypes.data, off.ctypes.data, ln.ctypes.data, wire, out.ctypes.data,
+                                                  woff2.ctypes.data, 2, C.byref(which))
+                    assert st < 0 and which.value == pos_seq, (wire, isa, pos_seq, which.value)
+            assert L.quicked_wire_pack_isa(best + 1) == -1 or best == 2
+    finally:
+        L.quicked_wire_pack_isa(-1)
