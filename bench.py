@@ -267,10 +267,10 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
     for rb in rbs:                                        # warm: code objects, pools of the rotation (asynchronous runs:
         if rb.run(params, sync=False) < 0 or rb.fetch() < 0:      # the planner's depth for a stream of runs)
             raise RuntimeError("end-to-end warm-up run failed")
-    # a run's device results live in one of the queueing thread's rotating pool sets until fetched: at most sets - 1
-    # runs may be queued and not yet fetched (include/quicked_batch.h)
+    # a queued run leaves its results in its batch object's own memory (include/quicked_batch.h): what bounds the runs in
+    # flight is the number of batch objects, not the thread's rotating pool sets
     sets = capi.pool_stats()["sets"]
-    inflight = max(1, min(inflight, sets - 1))
+    inflight = max(1, min(inflight, slots - 1))
     uploaded = [threading.Event() for _ in range(nbatches)]
     fetched = [threading.Event() for _ in range(nbatches)]      # results checked: the batch object may be reloaded
     on_host = [threading.Event() for _ in range(nbatches)]      # quicked_batch_fetch returned
@@ -561,8 +561,10 @@ class Bench:
         for fmt in ("ascii_pinned", "2bit_pinned", "ascii_hostpacked"):
             res = None
             # QuickEd's run call does more host work per run: one more run in flight and one more uploader hide it
-            for slots, inflight, uploaders in ((args.e2e_slots or (6 if quick else 4), args.e2e_inflight or (3 if quick else 2),
-                                                args.e2e_uploaders or (3 if quick else 2)), (3, 2, 1)):
+            # the host-packed leg packs on the uploader threads: one more of them
+            want = (args.e2e_slots or (6 if quick else (5 if fmt == "ascii_hostpacked" else 4)), args.e2e_inflight or (3 if quick else 2),
+                    args.e2e_uploaders or (3 if (quick or fmt == "ascii_hostpacked") else 2))
+            for slots, inflight, uploaders in (want, (3, 2, 1)):
                 try:
                     res = e2e_leg(capi, r["batch"], r["params"], fmt, args.e2e_batches, checksum, slots=slots, inflight=inflight,
                                   uploaders=uploaders, expect_cigar_bytes=r["cigar_bytes"])

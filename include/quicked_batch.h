@@ -97,17 +97,17 @@ quicked_status_t quicked_batch_reload_packed(quicked_batch_t* batch, int64_t n, 
  * sync == 0: returns once the run is queued; nothing is copied to the host until quicked_batch_fetch().  HIRSCHBERG, and
  * QUICKED where a pair may split or the batch runs for the first time, return once their host-driven stages are done;
  * otherwise QUICKED queues stage 1 and the align step together (the stage-1 rule of quicked.c:201-202 runs on the
- * device) and aligns the pairs that go on to stages 2 / 3 when the run is fetched.  Consecutive runs of a thread rotate over up to three sets of stream, device
- * pool and bit-planes, so the kernels of runs k+1 and k+2 overlap those of run k;
- * the device results of a run stay valid until the next run of that thread starts. */
+ * device) and aligns the pairs that go on to stages 2 / 3 when the run is fetched.  Consecutive runs of a thread rotate over several sets of stream, device
+ * pool and bit-planes -- three for batches that fill the chip, up to twelve for small ones (quicked_pool_stats()[2]) --
+ * so the kernels of the next runs overlap those of run k. */
 quicked_status_t quicked_batch_run(quicked_batch_t* batch, const quicked_params_t* params, int sync);
 quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
 /* Brings the results of the batch's last sync == 0 run to the host: waits for that run (only that one: later runs of
  * this or other batches keep executing) and copies scores / statuses / CIGARs / counters to where the getters read
- * them.  A sync == 0 run itself leaves the getters' data untouched.  The device-side results live in the queueing
- * thread's rotating pools: at most sets - 1 more runs of that thread may be queued before the fetch (sets =
- * quicked_pool_stats()[2], normally 3), or QUICKED_ERROR is returned.  Any
- * thread may fetch (bench.py's end-to-end leg fetches on a thread of its own) as long as no other call on this batch
+ * them.  A sync == 0 run itself leaves the getters' data untouched.  At its end such a run moves its results from the
+ * queueing thread's rotating pools into memory of the batch object (device to device), so the thread may queue any number
+ * of runs of OTHER batch objects before this one is fetched; the batch's own next run, reload or destroy discards them.
+ * Any thread may fetch (bench.py's end-to-end leg fetches on a thread of its own) as long as no other call on this batch
  * object runs at the same time; what the fetch itself has to compute runs on the calling thread's streams and pools. */
 quicked_status_t quicked_batch_fetch(quicked_batch_t* batch);
 
@@ -154,6 +154,11 @@ int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch);
  *   [0] bytes its pools hold   [1] out-of-memory reclaim events so far (process-wide; the planner is there to keep this 0)
  *   [2] pool sets in rotation in the last run   [3] fill sub-batches of the last run   [4] bytes one pool may hold */
 quicked_status_t quicked_pool_stats(int64_t stats_out[8]);
+
+/* Gives the calling thread's device pools back to the device (waits for its runs first).  The pools belong to the thread and
+ * stay allocated between runs -- that is what makes a steady stream of batches allocation-free -- so a thread that is done
+ * with large batches while others go on should call this (a thread that ENDS does it implicitly). */
+quicked_status_t quicked_pool_trim(void);
 
 /* Sum of the HIP-event durations (ms) of the dominant kernel (BandEd score /
  * fill) over the runs of this thread since the previous call, and how many

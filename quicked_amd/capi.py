@@ -58,7 +58,7 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
            "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
            "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats", "quicked_batch_cigar_view",
-           "quicked_batch_deferred_pairs", "quicked_wire_pack_pool", "quicked_wire_offsets", "quicked_wire_pack_isa"]
+           "quicked_batch_deferred_pairs", "quicked_wire_pack_pool", "quicked_wire_offsets", "quicked_wire_pack_isa", "quicked_pool_trim"]
 
 _LIB = None
 
@@ -126,6 +126,11 @@ def lib():
     L.quicked_host_free.restype = None
     _LIB = L
     return L
+
+
+def pool_trim():
+    """quicked_pool_trim: the calling thread's device pools go back to the device"""
+    return lib().quicked_pool_trim()
 
 
 def pool_stats():

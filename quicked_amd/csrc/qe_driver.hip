@@ -176,8 +176,88 @@ struct PinnedStage {
     }
 };
 
+// ---------------------------------------------------------------------------
+// Process-wide HBM ledger.  The reference runs one aligner per host thread (align_benchmark.c:246-249), each with an arena
+// that grows on demand (mm_allocator.c:251-334); here every thread's Context plans its device pools BEFORE a run, and two
+// threads that each plan against the whole device would meet in the out-of-memory path.  Every Context keeps an entry --
+// what its A pools hold, what it has planned to let them hold -- and a planning thread sees the others': it may plan with
+// what is free plus what it holds itself, minus what the others have planned but not allocated yet, where no other
+// context can claim more than an equal share of the device's pool space.
+// ---------------------------------------------------------------------------
+struct LedgerEntry { int device = 0; size_t held = 0, planned = 0, wanted = 0; uint64_t plans = 0; double last_plan_ms = -1e18, last_create_ms = -1e18; };
+static std::mutex g_ledger_mu;
+static std::vector<LedgerEntry*> g_ledger;
+static double ledger_now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+// -> bytes this context's A pools may hold together.  `wanted`: what they would grow to if the device were this thread's
+// alone.  Another context counts as a claimant while it is at work (it planned a run within the last two seconds) or
+// about to be (it created a batch object within the last ten and has not run it yet); a claimant is granted what it
+// wants, up to an equal share of the device where the wishes add up to more than there is; an idle context keeps what
+// its pools hold and no more.  Contexts re-plan before every run, so a thread that had the device to itself is down to
+// its share one run after a second one shows up.
+static size_t ledger_plan(LedgerEntry* me, size_t free_now, size_t my_held, size_t wanted) {
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    const double now = ledger_now_ms();
+    me->held = my_held;
+    me->wanted = wanted;
+    auto claimant = [&](const LedgerEntry* e) {
+        return (e->plans > 0 && now - e->last_plan_ms < 2000.0) || (now - e->last_create_ms < 10000.0 && e->last_create_ms > e->last_plan_ms);
+    };
+    size_t all_held = 0, n_active = 1;
+    for (const LedgerEntry* e : g_ledger) {
+        if (e->device != me->device) continue;
+        all_held += e->held;
+        if (e != me && claimant(e)) ++n_active;
+    }
+    const double space = 0.92 * (double)(free_now + all_held);          // what all pools of this device may hold together
+    double others = 0;
+    for (const LedgerEntry* e : g_ledger) {
+        if (e->device != me->device || e == me) continue;
+        double claim = 0;
+        if (claimant(e)) {
+            const bool knows = e->plans > 0 && e->last_plan_ms > e->last_create_ms;       // its wish is that of the batch it is running
+            claim = std::min(knows ? (double)e->wanted : space, space / (double)n_active);
+        }
+        others += std::max((double)e->held, claim);
+    }
+    const size_t mine = (size_t)std::max(space - others, (double)((size_t)2 << 30));
+    me->planned = std::min(mine, wanted);
+    ++me->plans;
+    me->last_plan_ms = now;
+    return mine;
+}
+static void ledger_note_create(LedgerEntry* me) {
+    std::lock_guard<std::mutex> lk(g_ledger_mu);
+    me->last_create_ms = ledger_now_ms();
+}
+
 struct Context {
     int device = 0;
+    LedgerEntry ledger;
+    bool registered = false;
+    // a worker thread that ends gives its device memory back (the reference's per-thread aligner frees its arena in
+    // quicked_free, quicked.c:371-375; here the pools belong to the thread, not to an aligner).  The Context object itself
+    // stays: a run this thread queued may still be fetched by another thread, whose PendingFetch points at one of the
+    // pools -- it finds the pool empty and a newer generation, and fails cleanly.
+    void retire() {
+        if (registered) {
+            std::lock_guard<std::mutex> lk(g_ledger_mu);
+            g_ledger.erase(std::remove(g_ledger.begin(), g_ledger.end(), &ledger), g_ledger.end());
+        }
+        if (!stream) return;
+        if (hipSetDevice(device) != hipSuccess) return;
+        (void)hipStreamSynchronize(stream_w);
+        for (auto q : stream_a2) if (q) (void)hipStreamSynchronize(q);
+        for (auto& st : stage) { for (auto& c : st.chunks) (void)hipHostFree(c.base); if (st.done) (void)hipEventDestroy(st.done); }
+        for (auto& e : kev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto e : {ev_pack, ev_stage, ev0, ev1}) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_decided) if (e) (void)hipEventDestroy(e);
+        for (auto& q : pool_a2) q.release_all();
+        for (auto& q : pool_w2) q.release_all();
+        pool_w.release_all();
+        for (auto q : stream_a2) if (q) (void)hipStreamDestroy(q);
+        (void)hipStreamDestroy(stream_w);
+        stream = nullptr; registered = false;
+    }
     // Two phases of a run use two streams and two pools so that consecutive runs pipeline:
     //   W: pack + bound stages (WindowEd, band doubling)      A: the BandEd kernels (score / fill / traceback / format)
     // Run k+1's W phase overlaps run k's A phase (different resources: W is latency / VALU-light, A is
@@ -233,9 +313,14 @@ struct Context {
     void init() {
         if (stream) return;
         HIP_CHECK(hipSetDevice(device));
+        { std::lock_guard<std::mutex> lk(g_ledger_mu); ledger.device = device; g_ledger.push_back(&ledger); }
+        registered = true;
         HIP_CHECK(hipStreamCreateWithFlags(&stream_w, hipStreamNonBlocking));
         for (auto& q : stream_a2) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-        for (auto& q : stream_w2) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        // a run's W phase and A phase depend on each other (pack -> bound stages -> align step): one stream per set serves
+        // both -- consecutive runs are on different sets, that is where the overlap comes from -- and the thread needs
+        // NA + 1 hardware queues instead of 2 NA + 1 (streams that share a queue serialise)
+        for (int q = 0; q < NA; ++q) stream_w2[q] = stream_a2[q];
         HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
         for (auto& e : ev_decided) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -255,7 +340,15 @@ static thread_local DevicePool* tl_fetch_hold = nullptr;     // the pool whose `
 static thread_local int tl_device = 0;
 // one Context per (host thread, device): a thread that alternates between devices keeps both (streams, pools and
 // pinned stages of the device it left stay where they are)
-static thread_local std::vector<Context*> tl_ctx_all;
+static const std::thread::id g_main_thread = std::this_thread::get_id();
+struct ContextList {
+    std::vector<Context*> v;
+    // worker threads release their contexts when they end; the main thread's live until the process does (tearing HIP
+    // objects down during static destruction races the runtime's own shutdown)
+    ~ContextList() { if (std::this_thread::get_id() != g_main_thread) for (Context* c : v) c->retire(); }
+};
+static thread_local ContextList tl_ctx_list;
+#define tl_ctx_all tl_ctx_list.v
 static thread_local int tl_bound_device = -1;
 static Context& ctx() {
     if (!tl_ctx || tl_ctx->device != tl_device) {
@@ -304,7 +397,7 @@ static bool reclaim_pools(DevicePool* keep) {
 // runs on the device at once: ask for more queues unless the user has chosen a value.  Read by the runtime when it
 // initialises (the first HIP call of the process), so this has to happen at load time; a process that has already
 // initialised HIP keeps what it has.
-__attribute__((constructor)) static void qe_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void qe_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 template <typename T>
 static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
@@ -407,11 +500,16 @@ struct quicked_batch {
     bool pending = false;
     // what quicked_batch_fetch needs to bring the results of the last sync == 0 run to the host (qe::PendingFetch)
     std::shared_ptr<void> pending_fetch;
+    // where a sync == 0 run leaves its results on the device until they are fetched: the batch's own memory, not the
+    // queueing thread's rotating pools -- so that thread may queue as many further runs (of other batches) as it likes
+    uint8_t* result_arena = nullptr;
+    size_t result_bytes = 0;
     // wire words of a packed batch (device), kept so that a reload can reuse the arena
     int wire = 0;
 
     ~quicked_batch() {
         if (arena) (void)hipFree(arena);
+        if (result_arena) (void)hipFree(result_arena);
         for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
     }
 };
@@ -698,7 +796,8 @@ static int coop_lanes(const TaskList& L, int in_flight = 1) {
     else
         while (G < 64 && ((live * G) / 64) * (size_t)std::max(1, in_flight) < target) G *= 2;      // runs in flight fill the chip together
     // the band-height test first + 2 < last must stay decidable G-2 chunks early: keep the band >= 3 G + 4 slots
-    while (G > 1 && min_nsl < 3 * G + 4) G /= 2;
+    static const int tall_env = env_int("QE_COOP_TALL", 3);
+    while (G > 1 && min_nsl < tall_env * G + 4) G /= 2;
     return G < 2 ? 1 : G;
 }
 
@@ -741,7 +840,22 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     HIP_CHECK(hipMemsetAsync(S.O.hew, 0, S.nt * sizeof(int32_t), C.stream));
     auto* ke = timed ? C.kernel_events() : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-    launch_groups(C, k_banded_coop, a, (size_t)nwaves, 8, 0);
+    // band state on chip where a wave's tasks fit its share of the LDS (k_banded_coop_lds); QE_COOP_LDS = 0: never
+    CoopLdsArgs x;
+    x.A = a;
+    x.lgG = 0; while ((1 << x.lgG) < G) ++x.lgG;
+    x.ns = 3; for (int32_t v : w_ns) x.ns = std::max(x.ns, v);
+    x.rr = x.ns + G + 4;
+    x.cr = std::max(16, 4 * G);
+    {
+        const size_t bytes = (size_t)2 * (x.ns + 1) * NA * 8 + (size_t)2 * x.rr * NA * 4 + (size_t)2 * x.cr * NA * 2 + (size_t)2 * NA * 4;
+        x.lds_per_wave = (int32_t)((bytes + 63) & ~(size_t)63);
+    }
+    const int lds_env = env_int("QE_COOP_LDS", 1);
+    if (lds_env != 0 && (size_t)x.lds_per_wave <= (size_t)38 * 1024)
+        launch_groups(C, k_banded_coop_lds, x, (size_t)nwaves, 8, (size_t)x.lds_per_wave);
+    else
+        launch_groups(C, k_banded_coop, a, (size_t)nwaves, 8, 0);
     // fallback pass: one lane per task, only where a band-edge decision could not be resolved in time
     const BandLayout lay = band_layout(L, false, false);
     S.D = upload_layout(lay, C);
@@ -780,6 +894,7 @@ struct AlignOut {                             // device, per root
     char* pool = nullptr;
     int32_t* ok = nullptr;                    // validator verdicts (null unless the batch asks for them)
     size_t nroots = 0;
+    size_t pool_bytes = 0;                    // what `pool` was sized for (the host-side bound of the strings)
 };
 
 // Results of a sync == 0 run, still on the device: what quicked_batch_fetch() copies once the run is over.  The device
@@ -804,6 +919,7 @@ struct PendingFetch {
     quicked_params_t params; TaskList L; size_t matrix_budget = 0;
     // validity
     DevicePool* pool = nullptr; uint64_t generation = 0; int parity = 0;
+    bool stashed = false;                     // the results were moved to the batch's result arena: valid until the batch's next run
 };
 
 // One wavefront per alignment (k_banded_wave) is for few, long alignments: up to ~1000 tasks every task gets a wave of its
@@ -877,6 +993,7 @@ static AlignOut format_segments(const quicked_batch& B, Context& C, const SegLis
     size_t pool_bytes = 0;
     if (want_strings) for (size_t b : SL.bound) pool_bytes += b;
     A.pool = C.scratch_p->take<char>(pool_bytes + 16);
+    A.pool_bytes = pool_bytes + 16;
     SegFormatArgs f;
     f.npairs = (int32_t)nr; f.seg_off = d_off; f.seg_kind = d_kind; f.seg_a = d_a; f.seg_b = d_b;
     f.runs = runs; f.g_runs_off = g_runs_off; f.nruns = nruns;
@@ -1494,6 +1611,51 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     C.sync_all();
 }
 
+// The results of a run queued with sync == 0 move from the run's pool set into the batch's result arena at the end of the
+// run (device-to-device, on the run's stream: scores and counters are a few hundred KB; the CIGAR strings are copied to
+// their real length, which only the device knows).  The fetch then depends on nothing but the batch object.
+struct StashItem { void** slot; size_t bytes; };
+template <typename T> static void stash_add(std::vector<StashItem>& items, T*& p, size_t bytes) {
+    if (p && bytes) items.push_back(StashItem{(void**)&p, bytes});
+}
+static void stash_results(quicked_batch& B, Context& C, PendingFetch& F) {
+    std::vector<StashItem> items;
+    const size_t nt = F.task_pair.size(), nr = F.AO.nroots, nl = F.leaf_pair.size(), nq = F.L.pair.size();
+    stash_add(items, F.d_score, nt * 4); stash_add(items, F.d_adv, nt * 4); stash_add(items, F.d_steps, nt * 4); stash_add(items, F.d_abort, nt * 4);
+    if (F.kind == 2) {
+        stash_add(items, F.AO.len, nr * 4); stash_add(items, F.AO.edits, nr * 4); stash_add(items, F.AO.nops, nr * 4);
+        stash_add(items, F.AO.ok, nr * 4); stash_add(items, F.AO.str_off, nr * 8);
+        stash_add(items, F.d_leaf_adv, nl * 4); stash_add(items, F.d_leaf_steps, nl * 4);
+        stash_add(items, F.d_cut, nq * 4); stash_add(items, F.d_skip, nq * 4); stash_add(items, F.d_stage_steps, nq * 4);
+    }
+    const bool strings = F.kind == 2 && F.want_strings && F.AO.pool && F.AO.total;
+    size_t need = 256;
+    for (const StashItem& it : items) need += (it.bytes + 255) & ~(size_t)255;
+    if (strings) need += ((F.AO.pool_bytes + 255) & ~(size_t)255) + 256;
+    if (B.result_bytes < need) {
+        if (B.result_arena) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(B.result_arena)); B.result_arena = nullptr; B.result_bytes = 0; }
+        const size_t cap = need + need / 8;
+        HIP_CHECK(hipMalloc((void**)&B.result_arena, cap));
+        B.result_bytes = cap;
+    }
+    size_t top = 0;
+    for (const StashItem& it : items) {
+        void* dst = B.result_arena + top;
+        HIP_CHECK(hipMemcpyAsync(dst, *it.slot, it.bytes, hipMemcpyDeviceToDevice, C.stream));
+        *it.slot = dst;
+        top += (it.bytes + 255) & ~(size_t)255;
+    }
+    if (strings) {
+        int64_t* d_total = (int64_t*)(B.result_arena + top); top += 256;
+        HIP_CHECK(hipMemcpyAsync(d_total, F.AO.total, 8, hipMemcpyDeviceToDevice, C.stream));
+        char* dst = (char*)(B.result_arena + top);
+        hipLaunchKernelGGL(k_copy_total, dim3(2048), dim3(256), 0, C.stream, (uint4*)dst, (const uint4*)F.AO.pool, (const int64_t*)F.AO.total,
+                           (int64_t)(F.AO.pool_bytes >> 4));
+        F.AO.total = d_total; F.AO.pool = dst;
+    }
+    F.stashed = true;
+}
+
 // sets of {streams, pools, planes} that rotate for a batch of n pairs: enough runs in flight for ~2048 waves (two per SIMD)
 static int rotation_depth(int64_t n) {
     const int64_t groups = std::max<int64_t>(1, (n + 63) / 64);
@@ -1527,7 +1689,6 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // pool's budget is cut into sub-batches by run_align -- before anything is allocated, not after an out-of-memory.
     size_t pools_held = 0;
     for (const auto& q : C.pool_a2) pools_held += q.cap;
-    const size_t avail = (size_t)(0.92 * (double)(free0 + pools_held));                 // what the A pools may hold together
     size_t need_mat = B.last_mat_bytes, need_fixed = B.last_fixed_bytes;
     int need_groups = B.last_groups;
     if (need_groups == 0 && !p.only_score && p.algo != WINDOWED) {
@@ -1548,6 +1709,10 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // depth of the rotation: three sets for batches that fill the chip; a small batch (12.5 k pairs = 196 waves of ~11 ms)
     // needs more runs in flight to keep two waves on every SIMD.  A synchronous run is alone on the device anyway.
     const int depth_wanted = fetch ? 3 : rotation_depth(B.n);
+    // what the A pools of this thread may hold together: the device's free memory plus what they hold already, less what
+    // the process's other threads have planned for theirs (the ledger above)
+    const size_t avail = ledger_plan(&C.ledger, free0, pools_held,
+                                     (size_t)(1.05 * (double)std::min(depth_wanted, B.np_alloc) * (double)(need_fixed + need_mat)) + ((size_t)256 << 20));
     int na = 1;
     for (int k = std::min(depth_wanted, B.np_alloc); k >= 1; --k) if ((double)min_set * k <= (double)avail) { na = k; break; }
     if (na_env > 0) na = std::min(std::min(na_env, (int)Context::NA), B.np_alloc);
@@ -1556,6 +1721,10 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     C.last_na = na;
     C.in_flight = fetch ? 1 : na;
     B.np_used = na;
+    for (int q = 0; q < na; ++q)                        // a set that outgrew this thread's share (another thread has joined) too
+        if (C.pool_a2[q].cap > ((size_t)1 << 30) && (double)C.pool_a2[q].cap > 1.25 * (double)C.pool_budget) {
+            HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_a2[q].release_all();
+        }
     for (int q = na; q < Context::NA; ++q) {            // a set that left the rotation gives its memory back
         if (C.pool_a2[q].cap > ((size_t)1 << 30)) { HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_a2[q].release_all(); }
         if (C.pool_w2[q].cap > ((size_t)1 << 30)) { HIP_CHECK(hipStreamSynchronize(C.stream_w2[q])); HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_w2[q].release_all(); }
@@ -1691,6 +1860,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     default: break;
     }
+    if (pf && pf->kind != 0) { C.phase_a(); stash_results(B, C, *pf); }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
     if (C.staging) { HIP_CHECK(hipEventRecord(C.stage[C.si].done, C.sa())); C.stage[C.si].pending = true; C.staging = false; }
@@ -1735,12 +1905,12 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
     // queueing thread's next run on the set, its planner, its out-of-memory path) waits for `fetching`
     struct Hold {
         std::unique_lock<std::mutex> lk;
-        explicit Hold(DevicePool* p) : lk(p->fetching) { tl_fetch_hold = p; }
+        explicit Hold(DevicePool* p) { if (p) { lk = std::unique_lock<std::mutex>(p->fetching); tl_fetch_hold = p; } }
         ~Hold() { tl_fetch_hold = nullptr; }
-    } hold_pool(F.pool);
-    if (F.pool->generation.load() != F.generation) {
+    } hold_pool(F.stashed ? nullptr : F.pool);
+    if (!F.stashed && F.pool->generation.load() != F.generation) {
         fprintf(stderr, "[quicked_hip] quicked_batch_fetch: the run's device results were overwritten by later runs of the "
-                        "thread that queued it (fetch before that thread has queued quicked_pool_stats()[2] more runs)\n");
+                        "thread that queued it\n");
         return QUICKED_ERROR;
     }
     C.phase_u();
@@ -1976,7 +2146,9 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
                                              const char* text_pool, const int64_t* text_off, const int32_t* text_len) {
     if (n < 0) return nullptr;
     return guarded_new([&](quicked_batch* B) {
-        batch_load(B, ctx(), n, pattern_pool, pattern_off, pattern_len, text_pool, text_off, text_len);
+        Context& C = ctx();
+        batch_load(B, C, n, pattern_pool, pattern_off, pattern_len, text_pool, text_off, text_len);
+        ledger_note_create(&C.ledger);
     });
 }
 
@@ -2104,7 +2276,9 @@ QE_API quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
                                                     const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len) {
     if (n < 0 || (wire != QUICKED_WIRE_2BIT && wire != QUICKED_WIRE_PLANES3)) return nullptr;
     return guarded_new([&](quicked_batch* B) {
-        batch_load_packed(B, ctx(), n, wire, pattern_words, pattern_word_off, pattern_len, text_words, text_word_off, text_len);
+        Context& C = ctx();
+        batch_load_packed(B, C, n, wire, pattern_words, pattern_word_off, pattern_len, text_words, text_word_off, text_len);
+        ledger_note_create(&C.ledger);
     });
 }
 
@@ -2252,6 +2426,22 @@ QE_API quicked_status_t quicked_pool_stats(int64_t stats_out[8]) {
     stats_out[0] += (int64_t)C->pool_w.cap;
     stats_out[2] = C->last_na; stats_out[3] = C->last_sub_batches; stats_out[4] = (int64_t)C->pool_budget;
     return QUICKED_OK;
+}
+
+QE_API quicked_status_t quicked_pool_trim(void) {
+    try {
+        Context& C = ctx();
+        C.sync_all();
+        for (auto& q : C.pool_a2) q.release_all();
+        for (auto& q : C.pool_w2) q.release_all();
+        C.pool_w.release_all();
+        std::lock_guard<std::mutex> lk(g_ledger_mu);
+        C.ledger.held = 0; C.ledger.planned = 0; C.ledger.wanted = 0;
+        return QUICKED_OK;
+    } catch (const HipError& e) {
+        fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+        return QUICKED_ERROR;
+    }
 }
 
 QE_API int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch) { return batch ? batch->deferred_pairs : -1; }

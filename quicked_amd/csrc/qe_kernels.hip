@@ -1166,6 +1166,334 @@ __global__ __launch_bounds__(512) void k_banded_coop(CoopArgs A) {
 }
 
 // ===========================================================================
+// The cooperative form with the band state ON CHIP (k_banded_coop_lds).  Same systolic pipeline as k_banded_coop --
+// lane g of a group owns band slots [g c, (g + 1) c) and runs one chunk behind lane g-1 -- same band-edge protocol,
+// same bits; what changes:
+//   * Pv / Mv of every slot, the scores[] window (a ring over block rows, two parities) and the band-edge records
+//     (rings over chunks) of a wave's 64 / G tasks live in LDS: no global round trip per (slot, chunk), and the
+//     hand-over between neighbouring lanes (lane g+1 stores the slot that becomes lane g's last slot; lane g reads it
+//     in a LATER pass of the same step) goes through LDS in program order of one wave -- ordered by the hardware, and
+//     kept in that order by wavefront-scope fences for the compiler;
+//   * a lane's c slots are walked in the SAME passes by every lane of the wave (c split into >= 2 passes of <= 4 slots),
+//     each a skewed multi-slot pass (run64_skew): a slot that is not in its task's band at this chunk is carried along
+//     masked instead of breaking the wave into one-slot passes.  A slot ABOVE the band's top runs on the fixed point
+//     Pv = 0, Mv = ~0 with carry-in (1, 0): whatever Eq is, its carry-out is (1, 0) again and its state does not
+//     change -- exactly the boundary carry PHin = 1 the band's top block takes (bpm_banded.c:238), at no instruction in
+//     the inner loop; a slot BELOW the bottom computes values nobody reads.  The scores[] chain of a pass (slots_pass)
+//     holds for any block state, so live rows get their exact sums whatever the dead slots below them did.
+// The last block row (level mask), N symbols and the partial last chunk take the one-slot general loop as before.
+// At the end the stopped band is written to the launch's global workspace in k_banded_coop's layout: the Hirschberg
+// join reads it there.
+// ===========================================================================
+struct ScoreRing {            // scores[] of block row (slot + chunk - prolog) lives at ring index (slot + chunk) mod rr
+    int kb, rr;
+    __device__ __forceinline__ int at(int slot) const {
+        int x = slot + kb;
+        x -= (x >= rr) ? rr : 0;
+        x += (x < 0) ? rr : 0;
+        return x;
+    }
+};
+
+template <int K>
+__device__ __forceinline__ void coop_pass(bool on, int i0, int fk, int hi, int pos_v, int NA, u64* Pv, u64* Mv, const int32_t* Srd, int32_t* Swr,
+                                          const ScoreRing R, const u64* pp, int p0, u64 T0, u64 T1, u64 hinP, u64 hinM, u64& houtP, u64& houtM, u32& adv) {
+    u64 P[K], M[K], a[K], b[K];
+    int sc[K], v0[K];
+    bool live[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = i0 + k;
+        live[k] = on && i >= fk && i <= hi;
+        P[k] = 0; M[k] = (on && i < fk) ? QE_ONES : 0;            // above the band: the fixed point; below / idle lane: anything
+        a[k] = 0; b[k] = 0; sc[k] = 0;
+        if (live[k]) {
+            u64 nn;
+            P[k] = Pv[i * NA]; M[k] = Mv[i * NA]; sc[k] = Srd[R.at(i) * NA];
+            load_planes(pp, p0 + 64 * (i + pos_v), a[k], b[k], nn);
+        }
+        v0[k] = __popcll(P[k]) - __popcll(M[k]);
+    }
+    run64_skew<K>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM);
+    int d = __popcll(houtP) - __popcll(houtM);                      // sum of the bottom-row deltas of slot k, from the lowest up
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+        if (live[k]) {
+            Swr[R.at(i0 + k) * NA] = sc[k] + d;
+            Pv[(i0 + k - 1) * NA] = P[k]; Mv[(i0 + k - 1) * NA] = M[k];      // band shift (bpm_banded.c:903-909)
+            adv += 64u;
+        }
+        d -= (__popcll(P[k]) - __popcll(M[k])) - v0[k];
+    }
+}
+
+__global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
+    const CoopArgs& A = X.A;
+    const int lane = threadIdx.x & 63, w = QE_GROUP_INDEX();
+    const int G = A.G, lgG = X.lgG, NA = 64 >> lgG;
+    if (w * NA >= A.T.ntasks) return;
+    const int q = lane >> lgG, g = lane & (G - 1);
+    const int t = w * NA + q;
+    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    const bool valid = pair >= 0;
+    int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0, tfin = 0;
+    const u64* pp = A.P.pl_p;
+    const u64* tp = A.P.pl_t;
+    u32 fl = 0;
+    if (valid) {
+        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
+        cut_in = A.T.cutoff[t]; tfin = A.T.tfin[t];
+        pp = A.P.pl_p + A.P.pl_p_off[pair];
+        tp = A.P.pl_t + A.P.pl_t_off[pair];
+        fl = A.P.flags[pair];
+    }
+    const bool hasN = (fl & FLAG_HAS_N) != 0;
+    const Geom GE = band_geometry(m, n, cut_in);
+    const int nw = (m + 63) >> 6;
+    const int nsl = ((GE.cutoff + 63) >> 6) + 1;
+    const int lvl_last = (m - 1) & 63;
+    const int prolog = GE.prolog;
+    // my slots, and the passes every lane of the wave walks them in
+    const int wns = A.w_nslots[w];
+    const int cper = max((wns + G - 1) >> lgG, 2);
+    const int slo = g * cper, shi = slo + cper - 1;
+    const int npass = max(2, (cper + 3) >> 2), kbase = cper / npass, kextra = cper - kbase * npass;
+
+    // LDS of this wave: Pv[(ns+1)][NA] | Mv[(ns+1)][NA] | S[2][rr][NA] | CF[cr][NA] | CL[cr][NA] | KF[NA] | KL[NA]
+    uint8_t* lb = (uint8_t*)qe_dyn_lds + (size_t)QE_WAVE_IN_BLOCK() * (size_t)X.lds_per_wave;
+    const int ns = X.ns, rr = X.rr, crm = X.cr - 1;
+    u64* const Pv = (u64*)lb + NA + q;                       lb += (size_t)(ns + 1) * NA * 8;      // slot -1 is addressable
+    u64* const Mv = (u64*)lb + NA + q;                       lb += (size_t)(ns + 1) * NA * 8;
+    int32_t* const S0 = (int32_t*)lb + q;                    lb += (size_t)2 * rr * NA * 4;
+    const int Spar = rr * NA;
+    volatile int16_t* const CF = (volatile int16_t*)lb + q;  lb += (size_t)X.cr * NA * 2;      // shared by the G lanes of a task
+    volatile int16_t* const CL = (volatile int16_t*)lb + q;  lb += (size_t)X.cr * NA * 2;
+    volatile int32_t* const KF = (volatile int32_t*)lb + q;  lb += (size_t)NA * 4;
+    volatile int32_t* const KL = (volatile int32_t*)lb + q;
+#define QE_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+
+    // bpm_reset_search (bpm_banded.c:180-197): slots 0 .. nsl-1, block rows 0 .. nsl-1 (row r at ring index r + prolog)
+    if (valid) {
+        for (int x = g; x < nsl; x += G) {
+            Pv[x * NA] = QE_ONES;
+            Mv[x * NA] = 0;
+            int ri = x + prolog; ri -= (ri >= rr) ? rr : 0;
+            S0[ri * NA] = 64 * (x + 1);
+            S0[Spar + ri * NA] = 64 * (x + 1);
+        }
+        if (g == 0) { CF[0] = (int16_t)prolog; CL[0] = (int16_t)(nsl - 1); *KF = 1; *KL = 1; }
+    }
+    QE_WAVE_FENCE();
+    const int nfull = tfin >> 6, tail = tfin & 63;
+    const int my_chunks = valid ? nfull + (tail ? 1 : 0) : 0;
+    const int nsteps = wave_max(my_chunks > 0 ? my_chunks + G - 1 : 0);
+    u64 lastP = 0, lastM = 0;          // carry words out of my last slot in the previous step
+    u32 adv = 0;
+    int maxrow = nsl - 1, aborted = 0;
+    ScoreRing R; R.rr = rr; R.kb = (g == 0) ? 0 : rr - g;           // (s - g) mod rr at s = 0
+
+    for (int s = 0; s < nsteps; ++s) {
+        const u64 cinP = __shfl_up(lastP, 1), cinM = __shfl_up(lastM, 1);
+        const int k = s - g;
+        const bool on = valid && k >= 0 && k < my_chunks;
+        const int ncols = (k < nfull) ? 64 : tail;
+        const int pos_v = k - prolog;
+        const int32_t* const Srd = S0 + (((k - 1) & 1) ? Spar : 0);     // values after chunk k-1
+        int32_t* const Swr = S0 + ((k & 1) ? Spar : 0);                 // values after chunk k
+        int fk = 0, lk = -1;
+        if (on) {
+            const int kf = *KF, kl = *KL;
+            if (k < kf) fk = CF[(k & crm) * NA];
+            else {
+                // `first` of my chunk is not decided yet (the deciding lane runs behind me): see k_banded_coop
+                const int prev = CF[((kf - 1) & crm) * NA];
+                const int d = k - (kf - 1);
+                if (shi < prev - d) fk = shi + 1;
+                else if (d == 1) fk = (k - 1 < prolog) ? prev - 1 : prev;
+                else { fk = prev; aborted = 1; }
+            }
+            lk = (k < kl) ? CL[(k & crm) * NA] : CL[((kl - 1) & crm) * NA];   // exact or an upper bound; my range end is the same
+        }
+        const int hi = min(lk, nw - 1 - pos_v);                          // rows >= nw are never computed (A.7(2))
+        const int lo_l = max(slo, fk), hi_l = min(shi, hi);
+        const bool any_live = on && hi_l >= lo_l;
+        u64 T0 = 0, T1 = 0, TN = 0;
+        if (any_live) load_planes(tp, t0 + 64 * k, T0, T1, TN);
+        const int lastrow_slot = nw - 1 - pos_v;                         // the slot of the pattern's last block row in this chunk
+        u64 cP = cinP, cM = cinM;                                        // carry words into the next slot of my walk
+        int i0 = slo;
+        for (int p = 0; p < npass; ++p) {
+            const int K = kbase + (p < kextra ? 1 : 0);                  // the same in every lane of the wave
+            const bool plive = any_live && i0 + K - 1 >= lo_l && i0 <= hi_l;
+            const bool slowl = plive && (ncols != 64 || hasN || (lastrow_slot >= max(i0, lo_l) && lastrow_slot <= min(i0 + K - 1, hi_l)));
+            if (!__any(slowl)) {
+                const u64 hP = (i0 <= fk) ? QE_ONES : cP, hM = (i0 <= fk) ? 0 : cM;      // PHin = 1 into the band's top block
+                switch (K) {
+                    case 4: coop_pass<4>(on, i0, fk, hi, pos_v, NA, Pv, Mv, Srd, Swr, R, pp, p0, T0, T1, hP, hM, cP, cM, adv); break;
+                    case 3: coop_pass<3>(on, i0, fk, hi, pos_v, NA, Pv, Mv, Srd, Swr, R, pp, p0, T0, T1, hP, hM, cP, cM, adv); break;
+                    case 2: coop_pass<2>(on, i0, fk, hi, pos_v, NA, Pv, Mv, Srd, Swr, R, pp, p0, T0, T1, hP, hM, cP, cM, adv); break;
+                    default: coop_pass<1>(on, i0, fk, hi, pos_v, NA, Pv, Mv, Srd, Swr, R, pp, p0, T0, T1, hP, hM, cP, cM, adv); break;
+                }
+            } else {
+                for (int kk = 0; kk < K; ++kk) {
+                    const int i = i0 + kk, r = i + pos_v;
+                    const bool act = on && i >= fk && i <= hi;
+                    u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
+                    int sc = 0;
+                    if (act) {
+                        P = Pv[i * NA]; M = Mv[i * NA]; sc = Srd[R.at(i) * NA];
+                        load_planes(pp, p0 + 64 * r, a, b, nn);
+                    }
+                    const bool lastblk = (r == nw - 1);
+                    const u64 hP = (i <= fk) ? QE_ONES : cP, hM = (i <= fk) ? 0 : cM;
+                    u64 houtP = 0, houtM = 0, sP, sM;
+                    const bool slow = act && (ncols != 64 || hasN || lastblk);
+                    if (!__any(slow)) {
+                        run64_fast<0, true>(P, M, a, b, T0, T1, hP, hM, houtP, houtM, act, nullptr, 0, nullptr);
+                        sP = houtP; sM = houtM;
+                    } else {
+                        run64_general<0>(P, M, a, b, nn, T0, T1, TN, hP, hM, houtP, houtM, sP, sM,
+                                         lastblk ? lvl_last : 63, act ? ncols : 0, false, nullptr, 0, nullptr);
+                    }
+                    if (act) {
+                        sc += __popcll(sP) - __popcll(sM);
+                        Swr[R.at(i) * NA] = sc;
+                        const int dst = (ncols == 64) ? i - 1 : i;
+                        Pv[dst * NA] = P;
+                        Mv[dst * NA] = M;
+                        adv += (u32)ncols;
+                        cP = houtP; cM = houtM;
+                    }
+                    QE_WAVE_FENCE();
+                }
+            }
+            QE_WAVE_FENCE();          // lane g+1's first pass stored the slot lane g reads in its last pass
+            i0 += K;
+        }
+        if (on) { lastP = cP; lastM = cM; }
+        // ---- band-edge decisions of every chunk that completed its deciding slot in this step (as in k_banded_coop)
+        const bool full = on && ncols == 64;
+        for (int round = 0; round < 6; ++round) {
+            bool decided = false;
+            if (full) {
+                // top (bpm_banded.c:889-901): decided by the owner of slot first + 1
+                int kf = *KF;
+                if (kf == k + 1) {
+                    const int f = CF[(k & crm) * NA];
+                    const int dslot = min(f + 1, nsl - 1);
+                    if (dslot >= slo && dslot <= shi) {
+                        const int kl = *KL;
+                        const int lub = CL[(min(k, kl - 1) & crm) * NA];
+                        const int llb = (k < kl) ? lub : lub - (k - (kl - 1));     // last drops by at most one per chunk
+                        bool tall;
+                        if (f + 2 < llb) tall = true;
+                        else if (f + 2 >= lub) tall = false;
+                        else { tall = true; aborted = 1; }
+                        bool cut_lo = false;
+                        if (tall && GE.fin > 64 * (f + 1))
+                            cut_lo = Swr[R.at(f + 1) * NA] + (GE.fin - 64 * (f + 1)) > GE.cutoff;
+                        int fnew = f;
+                        if (cut_lo && k >= prolog) fnew = f + 1;
+                        else if (!cut_lo && k < prolog) fnew = f - 1;
+                        CF[((k + 1) & crm) * NA] = (int16_t)fnew;
+                        *KF = k + 2;
+                        decided = true;
+                    }
+                }
+                QE_WAVE_FENCE();
+                // bottom (bpm_banded.c:903-921): decided by the owner of slot last, once the new first is known
+                kf = *KF;
+                const int kl = *KL;
+                if (kl == k + 1 && kf >= k + 2) {
+                    const int l = CL[(k & crm) * NA];
+                    if (l >= slo && l <= shi) {
+                        const int fnew = CF[((k + 1) & crm) * NA];
+                        Pv[l * NA] = QE_ONES;
+                        Mv[l * NA] = 0;
+                        const int pos = l + pos_v;
+                        Swr[R.at(l + 1) * NA] = Swr[R.at(l) * NA] + 64;
+                        maxrow = max(maxrow, pos + 1);
+                        bool cut_hi = false;
+                        if ((fnew + 2 < l) && (64 * (l - 1) > GE.fin))
+                            cut_hi = Swr[R.at(l - 1) * NA] + (64 * (l - 1) - GE.fin) > GE.cutoff;
+                        const int lnew = (cut_hi || (pos_v + l >= nw)) ? l - 1 : l;
+                        CL[((k + 1) & crm) * NA] = (int16_t)lnew;
+                        *KL = k + 2;
+                        decided = true;
+                    }
+                }
+            }
+            QE_WAVE_FENCE();
+            if (!__any(decided)) break;
+        }
+        // a wrong "no cut" guess before the end of the prologue put the carry chain on the wrong top slot
+        if (on && k >= 1 && k <= prolog && fk <= shi) {
+            const int kf = *KF;
+            if (kf > k && CF[(k & crm) * NA] != fk) aborted = 1;
+        }
+        R.kb = (R.kb + 1 == rr) ? 0 : R.kb + 1;
+    }
+    QE_WAVE_FENCE();
+    // group reductions: adv (sum), maxrow (max), aborted (or)
+    for (int o = 1; o < G; o <<= 1) {
+        adv += __shfl_xor(adv, o);
+        maxrow = max(maxrow, __shfl_xor(maxrow, o));
+        aborted |= __shfl_xor(aborted, o);
+    }
+    // ---- the stopped band goes to the launch's global workspace, k_banded_coop's layout (ColDist reads it there)
+    {
+        const int gns = wns, gnr = A.w_nrows[w];
+        uint8_t* base = A.ws + A.w_ws_off[w];
+        u64* const gP = (u64*)base + NA + q;                                   base += (int64_t)(gns + 1) * NA * 8;
+        u64* const gM = (u64*)base + NA + q;                                   base += (int64_t)(gns + 1) * NA * 8;
+        int32_t* const gS = (int32_t*)base + q;
+        const int posv_end = nfull - prolog;
+        int kbe = nfull % rr;                                                   // ring offset of chunk nfull's numbering
+        if (valid) {
+            for (int i = slo; i <= min(shi, min(nsl - 1, gns - 1)); ++i) {
+                gP[(int64_t)i * NA] = Pv[i * NA];
+                gM[(int64_t)i * NA] = Mv[i * NA];
+                const int row = i + posv_end;
+                if (row >= 0 && row < gnr) {
+                    int ri = i + kbe; ri -= (ri >= rr) ? rr : 0;
+                    gS[(int64_t)row * NA] = S0[ri * NA];
+                    gS[(int64_t)gnr * NA + (int64_t)row * NA] = S0[Spar + ri * NA];
+                }
+            }
+        }
+    }
+    if (valid && g == 0) {
+        if (*KF <= nfull || *KL <= nfull) aborted = 1;          // a decision never got made: recompute
+        const int row = nw - 1;
+        int score = -1;
+        const int flast = CF[(nfull & crm) * NA], llast = CL[(nfull & crm) * NA];
+        if (row <= maxrow) {
+            // which parity holds the row's latest value: processed in the last chunk (in band), or the
+            // never-processed row created by the last bookkeeping; anything else is recomputed
+            const int slot = row - (nfull - prolog);
+            int par = -1;
+            if (my_chunks == 0) par = 1;
+            else if (slot >= flast && slot <= llast) par = (my_chunks - 1) & 1;
+            else if (slot == llast + 1 && nfull > 0) par = (nfull - 1) & 1;
+            if (par < 0) aborted = 1;
+            else {
+                const int ri = (row + prolog) % rr;
+                score = S0[(par ? Spar : 0) + ri * NA];
+                if (m & 63) score -= 64 - (m & 63);
+            }
+        }
+        A.o_score[t] = score;
+        A.o_first[t] = flast;
+        A.o_last[t] = llast;
+        A.o_posv[t] = nfull - prolog;
+        A.o_maxrow[t] = maxrow;
+        A.o_adv[t] = adv;
+        A.o_abort[t] = aborted;
+    }
+#undef QE_WAVE_FENCE
+}
+
+// ===========================================================================
 // BandEd score-only, ONE WAVEFRONT PER ALIGNMENT (BASELINE.json's form; for few alignments: a single pair, a
 // handful of long reads -- where one lane per alignment leaves the chip empty and the latency of one lane is the run
 // time).  Lane j owns the block rows r = j (mod 64); row r works on text column c = step - r, so the rows of the band
@@ -2278,6 +2606,12 @@ __global__ __launch_bounds__(64) void k_check_strings(PairView P, int npairs, co
     }
     if (have) K.ok = false;                 // digits without an operation
     o_ok[i] = K.verdict();
+}
+
+// copies the first *total bytes (a count only the device knows: the string pool of a run) from src to dst, 16 bytes per lane
+__global__ __launch_bounds__(256) void k_copy_total(uint4* __restrict__ dst, const uint4* __restrict__ src, const int64_t* __restrict__ total, int64_t cap_u4) {
+    const int64_t n = min((*total + 15) >> 4, cap_u4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // exclusive scan of (len + 1) over tasks -> string offsets; one block, tiles of 1024 consecutive elements (coalesced

@@ -90,6 +90,16 @@ struct CoopArgs {
     int32_t* o_abort;                        // 1: a band-edge decision could not be resolved in time; rerun with k_banded<false>
 };
 
+// the same with the band state of a wave's tasks in LDS (k_banded_coop_lds): what the whole launch is sized for
+struct CoopLdsArgs {
+    CoopArgs A;
+    int32_t lgG;             // log2(A.G)
+    int32_t ns;              // band slots per task the LDS holds (>= every task's band height)
+    int32_t rr;              // scores[] ring: ns + G + 4 block rows per task and parity
+    int32_t cr;              // band-edge rings: a power of two >= G + 4 chunks
+    int32_t lds_per_wave;    // bytes
+};
+
 // BandEd traceback over a filled matrix (bpm_banded.c:967-1036) -> RLE runs, back to front
 struct TraceArgs {
     PairView P;

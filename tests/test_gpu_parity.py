@@ -269,16 +269,56 @@ def test_randomised_shapes_and_params(seed, monkeypatch):
                 assert out[i][2] == ecg, (kw, i)
 
 
-def test_cooperative_kernel_forced(monkeypatch):
-    """QE_COOP_G forces the G-lanes-per-alignment kernel (and its fallback pass) on shapes the host would not pick it for"""
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_cooperative_kernel_forced(lds, monkeypatch):
+    """QE_COOP_G forces the G-lanes-per-alignment kernel (and its fallback pass) on shapes the host would not pick it for:
+    the on-chip form (k_banded_coop_lds: uniform masked multi-slot passes, band state in LDS) and the global-memory form
+    (QE_COOP_LDS = 0), every lane count, scores AND block-advance counts equal to the oracle's; ragged lengths with N
+    symbols; Hirschberg half passes (stopped bands exported for the join) with forced splits"""
+    monkeypatch.setenv("QE_COOP_LDS", lds)
     batch = datagen.generate(count=300, length=6000, error=0.07, seed=91)
     pairs = list(batch.pairs())
-    for G in ("2", "8", "32"):
+    ref = {}
+    for bw in (8, 15, 40):
+        tr = [O.oracle_align(p, t, trace=True, algo=2, only_score=True, bandwidth=bw) for p, t in pairs]
+        ref[bw] = ([x[1] for x in tr], sum(x[3]["score_block_advances"] for x in tr))
+    for G in ("2", "4", "8", "16", "32"):
         monkeypatch.setenv("QE_COOP_G", G)
         for bw in (8, 15, 40):
             scores, status, _, cnt = gpu_batch(batch, algo=2, only_score=True, bandwidth=bw)
-            exp = [O.oracle_align(p, t, algo=2, only_score=True, bandwidth=bw)[1] for p, t in pairs]
-            assert scores.tolist() == exp, (G, bw)
+            assert scores.tolist() == ref[bw][0], (G, bw)
+            assert cnt[0] == ref[bw][1], (G, bw, int(cnt[6]))
+    # ragged lengths (64 / G tasks of different heights per wave), N symbols, short reads whose band is the whole matrix
+    rng = np.random.default_rng(17)
+    rag = []
+    for i in range(200):
+        L = int(rng.choice([700, 1500, 2500, 4000, 6000]))
+        b = datagen.generate(1, L, 0.06, seed=9100 + i)
+        p, t = next(b.pairs())
+        if i % 5 == 0:
+            p = bytearray(p)
+            for k in rng.integers(0, len(p), 4): p[k] = ord("N")
+            p = bytes(p)
+        rag.append((p, t))
+    al = capi.QuickedAligner()
+    al.setAlgorithm(capi.BANDED); al.setOnlyScore(True); al.setBandwidth(30)
+    exp = [O.oracle_align(p, t, algo=2, only_score=True, bandwidth=30)[:2] for p, t in rag]
+    for G in ("2", "4", "8"):
+        monkeypatch.setenv("QE_COOP_G", G)
+        st, out = al.alignBatch(rag)
+        assert [(o[0], o[1]) for o in out] == exp, G
+    # Hirschberg: the half passes stop mid-text and the join reads their bands from the workspace the kernel exports
+    monkeypatch.setenv("QE_SPLIT_BYTES", str(1 << 17))
+    hb = datagen.generate(count=40, length=6000, error=0.07, seed=92)
+    hexp = None
+    for G in ("1", "4", "16"):
+        monkeypatch.setenv("QE_COOP_G", G)
+        scores, status, cig, cnt = gpu_batch(hb, algo=3, bandwidth=20)
+        got = (scores.tolist(), status.tolist(), cig, int(cnt[0]))
+        if hexp is None:
+            hexp = got
+            assert all(s == O.oracle().qo_exact_distance(p, len(p), t, len(t)) for s, (p, t) in zip(got[0], hb.pairs()))
+        assert got == hexp, G
 
 
 def test_reference_callers_link_and_run():
@@ -917,6 +957,70 @@ def test_planner_cuts_a_large_cigar_batch_before_it_runs_out_of_memory():
         pt, tt = batch.pattern(i), batch.text(i)
         assert (st[i], s[i], cg[i]) == O.oracle_align(pt, tt, algo=0), i
     assert rate > 3.0e6, rate
+
+
+def test_two_host_threads_plan_hbm_together():
+    """the process-wide HBM ledger: two host threads, each with 150 k pairs of 10 kb through QuickEd + CIGAR (~35 GB of fill
+    checkpoints per run and pool set), plan their device pools against what the OTHER has planned, not against the whole
+    device each: no out-of-memory reclaim event, both threads' results equal to the oracle's on a stride.  A thread that
+    ends gives its pools back."""
+    import threading
+    n = 150000
+    batch = datagen.generate(count=n, length=10000, error=0.05, seed=0x51CED)
+    assert capi.pool_trim() == 0            # what this (idle) thread's pools hold from earlier tests goes back to the device
+    before = capi.pool_stats()["reclaim_events"]
+    errors, stats, rates = [], {}, {}
+    gate = threading.Barrier(2)
+
+    def worker(name):
+        try:
+            import time
+            rb = capi.ResidentBatch(batch)
+            p = capi.make_params(algo=capi.QUICKED)
+            gate.wait()
+            assert rb.run(p, sync=True) >= 0
+            gate.wait()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                assert rb.run(p, sync=False) >= 0
+            rb.sync()
+            rates[name] = n * 4 / (time.perf_counter() - t0)
+            assert rb.run(p, sync=True) >= 0
+            s, st = rb.scores()
+            cg = rb.cigars()
+            stats[name] = capi.pool_stats()
+            rb.close()
+            assert (st == capi.QUICKED_WIP).all()
+            for i in list(range(0, n, n // 24)) + [n - 1]:
+                assert (st[i], s[i], cg[i]) == O.oracle_align(batch.pattern(i), batch.text(i), algo=0), (name, i)
+        except Exception as e:      # noqa: BLE001
+            errors.append((name, repr(e)))
+            try:
+                gate.abort()
+            except Exception:      # noqa: BLE001
+                pass
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in ("a", "b")]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    print(f"two threads: {rates}, {stats}")
+    for k in ("a", "b"):
+        assert stats[k]["reclaim_events"] == before, stats
+        # neither thread was allowed to plan for the whole device: the budgets of their pool sets add up to less than it
+    total = 288 * 2**30
+    assert sum(stats[k]["pool_budget"] * stats[k]["sets"] for k in ("a", "b")) < total, stats
+    assert sum(stats[k]["pool_bytes"] for k in ("a", "b")) < total, stats
+    assert all(stats[k]["sets"] >= 2 and stats[k]["sub_batches"] <= 2 for k in ("a", "b")), stats      # nobody was starved
+    assert min(rates.values()) > 0.4e6, rates           # a ledger test, not a benchmark: four runs each, pools growing, two threads on one chip
+    # the threads have ended: their pools are back (this thread's own view: nothing held by it, and a fresh plan sees the device)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free_b, total_b = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0
+    assert free_b.value > 0.8 * total_b.value, (free_b.value, total_b.value)
 
 
 @pytest.mark.parametrize("force", ["1", "0"])

@@ -8,8 +8,10 @@
 //           (align_benchmark_params.c:108-131; quicked defaults bandwidth to 15: 299-306)
 //   -o      "score\tCIGAR" per pair; --output-full: plen, tlen, score, pattern, text, CIGAR
 //           (benchmark_utils.c:151-170)
-//   -c      score | alignment | correct: CIGAR validity + edit count, and for `score` an independent
-//           exact distance (full-height bit-parallel DP in this tool; the reference uses edlib)
+//   -c      score | alignment | correct: CIGAR validity + edit count -- the validity walk of every pair's CIGAR over its
+//           bases (benchmark_check.c:117-176 -> cigar_check_alignment, cigar.c:363-434) runs on the device, a batch at a
+//           time (quicked_batch_validate); the host only adds up the run lengths -- and for `score` an independent exact
+//           distance (full-height bit-parallel DP in this tool; the reference uses edlib)
 // Instead of the reference's OpenMP loop over quicked_align calls (align_benchmark.c:269-284) every
 // --batch-size pairs go through one quicked_align_batch call.
 //
@@ -67,24 +69,16 @@ static int exact_distance(const std::string& p, const std::string& t) {
     return score;
 }
 
-// CIGAR validity (cigar_check_alignment, cigar.c:363-434) and its edit count
-static bool check_cigar(const std::string& p, const std::string& t, const char* rle, int* edits) {
-    size_t v = 0, h = 0; long num = 0; int e = 0;
+// edit count of an RLE CIGAR (cigar_score_edit, cigar.c:274-289): the sum of its X / I / D run lengths -- O(runs); the
+// walk over the bases that decides validity is the device's (quicked_batch_validate)
+static long cigar_edits(const char* rle) {
+    long num = 0, e = 0;
     for (const char* q = rle; *q; ++q) {
         if (*q >= '0' && *q <= '9') { num = num * 10 + (*q - '0'); continue; }
-        for (long k = 0; k < num; ++k) {
-            switch (*q) {
-                case 'M': if (v >= p.size() || h >= t.size() || p[v] != t[h]) return false; ++v; ++h; break;
-                case 'X': if (v >= p.size() || h >= t.size() || p[v] == t[h]) return false; ++v; ++h; ++e; break;
-                case 'I': if (h >= t.size()) return false; ++h; ++e; break;
-                case 'D': if (v >= p.size()) return false; ++v; ++e; break;
-                default: return false;
-            }
-        }
+        if (*q != 'M') e += num;
         num = 0;
     }
-    *edits = e;
-    return v == p.size() && h == t.size();
+    return e;
 }
 
 int main(int argc, char** argv) {
@@ -164,6 +158,24 @@ int main(int argc, char** argv) {
         quicked_align_batch(&aligner, n, pp.data(), pl.data(), tp.data(), tl.data(), scores.data(),
                             params.only_score ? nullptr : cigs.data(), status.data());
         align_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // --check: every CIGAR of the batch validated against its pair on the device in one call
+        std::vector<int32_t> valid(n, 1);
+        if (!check.empty() && !params.only_score) {
+            std::string ppool, tpool, cpool;
+            std::vector<int64_t> po(n), to(n), co(n, -1);
+            std::vector<int32_t> pl32(n), tl32(n);
+            for (int i = 0; i < n; ++i) {
+                po[i] = (int64_t)ppool.size(); ppool += pats[i]; to[i] = (int64_t)tpool.size(); tpool += txts[i];
+                pl32[i] = pl[i]; tl32[i] = tl[i];
+                if (!quicked_check_error(status[i]) && cigs[i]) { co[i] = (int64_t)cpool.size(); cpool.append(cigs[i]); cpool.push_back('\0'); }
+            }
+            quicked_batch_t* vb = quicked_batch_create(n, ppool.data(), po.data(), pl32.data(), tpool.data(), to.data(), tl32.data());
+            if (!vb || quicked_check_error(quicked_batch_validate(vb, cpool.data(), (int64_t)cpool.size(), co.data(), valid.data()))) {
+                fprintf(stderr, "--check: the device validator failed\n");
+                exit(1);
+            }
+            quicked_batch_destroy(vb);
+        }
         for (int i = 0; i < n; ++i) {
             if (quicked_check_error(status[i])) {
                 fprintf(stderr, "%s", quicked_status_msg(status[i]));
@@ -177,9 +189,7 @@ int main(int argc, char** argv) {
             }
             if (!check.empty()) {
                 ++checked;
-                int edits = -1;
-                const bool valid = params.only_score || check_cigar(pats[i], txts[i], cg, &edits);
-                if (valid && (params.only_score || edits == scores[i])) ++ok_cigar;
+                if (params.only_score || (valid[i] == 1 && cigar_edits(cg) == scores[i])) ++ok_cigar;
                 else fprintf(stderr, "INCORRECT ALIGNMENT (pair %ld)\n", total + i);
                 if (check == "score" || check == "alignment") {
                     const int exact = exact_distance(pats[i], txts[i]);
