@@ -157,7 +157,7 @@ quicked_status_t quicked_pool_stats(int64_t stats_out[8]);
 
 /* Gives the calling thread's device pools back to the device (waits for its runs first).  The pools belong to the thread and
  * stay allocated between runs -- that is what makes a steady stream of batches allocation-free -- so a thread that is done
- * with large batches while others go on should call this (a thread that ENDS does it implicitly). */
+ * with large batches while others go on should call this (at thread exit the library tries to, best effort). */
 quicked_status_t quicked_pool_trim(void);
 
 /* Sum of the HIP-event durations (ms) of the dominant kernel (BandEd score /

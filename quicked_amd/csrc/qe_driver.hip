@@ -302,13 +302,22 @@ struct Context {
         }
         return &kev[kev_used++];
     }
-    void phase_w() { stream = sw(); scratch_p = &pw(); }
-    void phase_a() { stream = sa(); scratch_p = &pa(); }
+    void phase_w() { ensure_set(ai); stream = sw(); scratch_p = &pw(); }
+    void phase_a() { ensure_set(ai); stream = sa(); scratch_p = &pa(); }
     void phase_u() { stream = stream_w; scratch_p = &pool_w; }
     void sync_all() {
         HIP_CHECK(hipStreamSynchronize(stream_w));
-        for (auto q : stream_w2) HIP_CHECK(hipStreamSynchronize(q));
-        for (auto q : stream_a2) HIP_CHECK(hipStreamSynchronize(q));
+        for (auto q : stream_a2) if (q) HIP_CHECK(hipStreamSynchronize(q));
+    }
+    // A set's stream is created when the rotation first reaches it: a thread that only loads and fetches (an uploader, a
+    // fetcher) has the utility stream and nothing else, a thread that runs large batches four streams -- the runtime maps
+    // all streams of the process onto GPU_MAX_HW_QUEUES hardware queues, and streams that share one serialise.
+    // A run's W phase and A phase depend on each other (pack -> bound stages -> align step): one stream serves both;
+    // consecutive runs are on different sets, that is where the overlap comes from.
+    void ensure_set(int q) {
+        if (stream_a2[q]) return;
+        HIP_CHECK(hipStreamCreateWithFlags(&stream_a2[q], hipStreamNonBlocking));
+        stream_w2[q] = stream_a2[q];
     }
     void init() {
         if (stream) return;
@@ -316,11 +325,6 @@ struct Context {
         { std::lock_guard<std::mutex> lk(g_ledger_mu); ledger.device = device; g_ledger.push_back(&ledger); }
         registered = true;
         HIP_CHECK(hipStreamCreateWithFlags(&stream_w, hipStreamNonBlocking));
-        for (auto& q : stream_a2) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-        // a run's W phase and A phase depend on each other (pack -> bound stages -> align step): one stream per set serves
-        // both -- consecutive runs are on different sets, that is where the overlap comes from -- and the thread needs
-        // NA + 1 hardware queues instead of 2 NA + 1 (streams that share a queue serialise)
-        for (int q = 0; q < NA; ++q) stream_w2[q] = stream_a2[q];
         HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
         for (auto& e : ev_decided) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -376,12 +380,12 @@ static bool reclaim_pools(DevicePool* keep) {
     ++g_reclaim_events;
     for (int q = 0; q < Context::NA; ++q) {
         if (&C->pool_a2[q] != keep && &C->pool_a2[q] != tl_fetch_hold && C->pool_a2[q].cap != 0) {
-            if (hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
+            if (C->stream_a2[q] && hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
             freed |= C->pool_a2[q].try_release_all();
         }
         // a W pool of another set (its run, if any, is waited for; the current run's own W pool is still being read)
         if (&C->pool_w2[q] != keep && C->pool_w2[q].cap > ((size_t)1 << 28) && q != C->ai) {
-            if (hipStreamSynchronize(C->stream_w2[q]) != hipSuccess || hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
+            if (C->stream_a2[q] && hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
             freed |= C->pool_w2[q].try_release_all();
         }
     }
@@ -399,6 +403,14 @@ static bool reclaim_pools(DevicePool* keep) {
 // initialised HIP keeps what it has.
 __attribute__((constructor)) static void qe_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
+// one in-stream copy as a kernel (see k_copy_multi); both buffers are padded to 16 bytes (pool / arena / stage allocations are)
+static void copy_kernel(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    CopyTable T;
+    T.n = 1; T.dst[0] = (uint4*)dst; T.src[0] = (const uint4*)src; T.n_u4[0] = (int64_t)((bytes + 15) >> 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>(256, (T.n_u4[0] + 255) / 256);
+    hipLaunchKernelGGL(k_copy_multi, dim3(blocks, 1), dim3(256), 0, s, T);
+}
 template <typename T>
 static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
     if (src.empty()) return;
@@ -407,7 +419,7 @@ static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
     if (C && C->staging && (s == C->sa() || s == C->sw())) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
         uint8_t* st = C->stage[C->si].take(bytes);
         memcpy(st, src.data(), bytes);
-        HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
+        copy_kernel(dst, st, bytes, s);                            // the device reads the pinned stage itself: no DMA engine involved
         return;
     }
     HIP_CHECK(hipMemcpyAsync(dst, src.data(), bytes, hipMemcpyHostToDevice, s));
@@ -506,11 +518,19 @@ struct quicked_batch {
     size_t result_bytes = 0;
     // wire words of a packed batch (device), kept so that a reload can reuse the arena
     int wire = 0;
+    // A packed batch's wire words become planes in the first run after a (re)load, on that run's stream -- not in the
+    // load: a load is then DMA only and never waits for a free SIMD on a chip that other runs keep full (a kernel of the
+    // load used to queue behind 256-VGPR alignment waves that live for 20 ms: 80 ms per reload in bench.py's streaming leg)
+    u64 *d_wire_p = nullptr, *d_wire_t = nullptr;
+    int64_t *d_wire_p_off = nullptr, *d_wire_t_off = nullptr;
+    bool unpack_pending = false, unpack_event_set = false;
+    hipEvent_t ev_unpacked = nullptr;
 
     ~quicked_batch() {
         if (arena) (void)hipFree(arena);
         if (result_arena) (void)hipFree(result_arena);
         for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
+        if (ev_unpacked) (void)hipEventDestroy(ev_unpacked);
     }
 };
 
@@ -612,7 +632,7 @@ static void h2d_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (C && C->staging && (s == C->sa() || s == C->sw())) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
         uint8_t* st = C->stage[C->si].take(bytes);
         memcpy(st, src, bytes);
-        HIP_CHECK(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s));
+        copy_kernel(dst, st, bytes, s);
         return;
     }
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
@@ -1639,20 +1659,35 @@ static void stash_results(quicked_batch& B, Context& C, PendingFetch& F) {
         B.result_bytes = cap;
     }
     size_t top = 0;
+    CopyTable T;
+    T.n = 0;
+    int64_t most = 1;
+    auto flush = [&]() {
+        if (T.n == 0) return;
+        hipLaunchKernelGGL(k_copy_multi, dim3((unsigned)std::min<int64_t>(64, (most + 255) / 256), (unsigned)T.n), dim3(256), 0, C.stream, T);
+        T.n = 0; most = 1;
+    };
+    auto copy = [&](void* dst, const void* src, size_t bytes) {
+        T.dst[T.n] = (uint4*)dst; T.src[T.n] = (const uint4*)src; T.n_u4[T.n] = (int64_t)((bytes + 15) >> 4);
+        most = std::max(most, T.n_u4[T.n]);
+        if (++T.n == CopyTable::MAX) flush();
+    };
     for (const StashItem& it : items) {
         void* dst = B.result_arena + top;
-        HIP_CHECK(hipMemcpyAsync(dst, *it.slot, it.bytes, hipMemcpyDeviceToDevice, C.stream));
+        copy(dst, *it.slot, it.bytes);
         *it.slot = dst;
         top += (it.bytes + 255) & ~(size_t)255;
     }
     if (strings) {
         int64_t* d_total = (int64_t*)(B.result_arena + top); top += 256;
-        HIP_CHECK(hipMemcpyAsync(d_total, F.AO.total, 8, hipMemcpyDeviceToDevice, C.stream));
+        copy(d_total, F.AO.total, 8);
+        flush();
         char* dst = (char*)(B.result_arena + top);
         hipLaunchKernelGGL(k_copy_total, dim3(2048), dim3(256), 0, C.stream, (uint4*)dst, (const uint4*)F.AO.pool, (const int64_t*)F.AO.total,
                            (int64_t)(F.AO.pool_bytes >> 4));
         F.AO.total = d_total; F.AO.pool = dst;
     }
+    flush();
     F.stashed = true;
 }
 
@@ -1723,13 +1758,16 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     B.np_used = na;
     for (int q = 0; q < na; ++q)                        // a set that outgrew this thread's share (another thread has joined) too
         if (C.pool_a2[q].cap > ((size_t)1 << 30) && (double)C.pool_a2[q].cap > 1.25 * (double)C.pool_budget) {
-            HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_a2[q].release_all();
+            if (C.stream_a2[q]) HIP_CHECK(hipStreamSynchronize(C.stream_a2[q]));
+            C.pool_a2[q].release_all();
         }
     for (int q = na; q < Context::NA; ++q) {            // a set that left the rotation gives its memory back
-        if (C.pool_a2[q].cap > ((size_t)1 << 30)) { HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_a2[q].release_all(); }
-        if (C.pool_w2[q].cap > ((size_t)1 << 30)) { HIP_CHECK(hipStreamSynchronize(C.stream_w2[q])); HIP_CHECK(hipStreamSynchronize(C.stream_a2[q])); C.pool_w2[q].release_all(); }
+        if (C.stream_a2[q] && (C.pool_a2[q].cap > ((size_t)1 << 30) || C.pool_w2[q].cap > ((size_t)1 << 30))) HIP_CHECK(hipStreamSynchronize(C.stream_a2[q]));
+        if (C.pool_a2[q].cap > ((size_t)1 << 30)) C.pool_a2[q].release_all();
+        if (C.pool_w2[q].cap > ((size_t)1 << 30)) C.pool_w2[q].release_all();
     }
     C.ai = (C.ai + 1) % na;
+    C.ensure_set(C.ai);
     const int par = B.parity = (B.parity + 1) % B.np_used;
     C.si = (C.si + 1) % (2 * na);
     {
@@ -1764,6 +1802,21 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         return QUICKED_UNKNOWN_ALGO;
     }
     HIP_CHECK(hipEventRecord(C.ev0, C.stream));
+    if (B.packed && B.unpack_pending) {
+        // wire words -> planes, once per (re)load, on this run's stream; later runs of the batch (other streams) wait for it
+        HIP_CHECK(hipMemsetAsync(B.d_flags[0], 0, (size_t)B.n * sizeof(u32), C.stream));
+        const int blocks = (int)((B.n + 3) / 4);
+        WireArgs w;
+        w.nseq = (int32_t)B.n; w.wire = B.wire; w.flags = B.d_flags[0];
+        w.words = B.d_wire_p; w.w_off = B.d_wire_p_off; w.len = B.d_p_len; w.planes = B.d_pl_p[0]; w.pl_off = B.d_plp_off;
+        hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
+        w.words = B.d_wire_t; w.w_off = B.d_wire_t_off; w.len = B.d_t_len; w.planes = B.d_pl_t[0]; w.pl_off = B.d_plt_off;
+        hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
+        HIP_CHECK(hipEventRecord(B.ev_unpacked, C.stream));
+        B.unpack_pending = false; B.unpack_event_set = true;
+    } else if (B.packed && B.unpack_event_set) {
+        HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_unpacked, 0));
+    }
     if (!B.packed) HIP_CHECK(hipMemsetAsync(B.d_flags[par], 0, (size_t)B.n * sizeof(u32), C.stream));
     launch_pack(B, C, false);
     if (!serial) HIP_CHECK(hipEventRecord(C.ev_pack, C.sw()));
@@ -2251,22 +2304,20 @@ static void batch_load_packed(quicked_batch* B, Context& C, int64_t n, int wire,
         B->d_flags[q] = B->d_flags[0];
         if (!B->ev_done[q]) HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
     }
+    double tr_last = now_ms();
+    QE_TRACE_POINT("load_packed: host layout");
     if (pw_total) upload_span((uint8_t*)d_pw, (const uint8_t*)(pattern_words + p_lo), pw_total * 8, C.device);
     if (tw_total) upload_span((uint8_t*)d_tw, (const uint8_t*)(text_words + t_lo), tw_total * 8, C.device);
+    QE_TRACE_POINT("load_packed: word upload");
     h2d(d_pwo, pwo, C.stream); h2d(d_two, two, C.stream);
     h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
     h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
     h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
-    HIP_CHECK(hipMemsetAsync(B->d_flags[0], 0, (size_t)n * sizeof(u32), C.stream));
-    const int blocks = (int)((n + 3) / 4);
-    if (n > 0) {
-        WireArgs w;
-        w.nseq = (int32_t)n; w.wire = wire; w.flags = B->d_flags[0];
-        w.words = d_pw; w.w_off = d_pwo; w.len = B->d_p_len; w.planes = B->d_pl_p[0]; w.pl_off = B->d_plp_off;
-        hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
-        w.words = d_tw; w.w_off = d_two; w.len = B->d_t_len; w.planes = B->d_pl_t[0]; w.pl_off = B->d_plt_off;
-        hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
-    }
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+    QE_TRACE_POINT("load_packed: arrays");
+    B->d_wire_p = d_pw; B->d_wire_t = d_tw; B->d_wire_p_off = d_pwo; B->d_wire_t_off = d_two;
+    B->unpack_pending = n > 0; B->unpack_event_set = false;
+    if (!B->ev_unpacked) HIP_CHECK(hipEventCreateWithFlags(&B->ev_unpacked, hipEventDisableTiming));
     HIP_CHECK(hipStreamSynchronize(C.stream));
 }
 }  // namespace qe

@@ -2608,6 +2608,22 @@ __global__ __launch_bounds__(64) void k_check_strings(PairView P, int npairs, co
     o_ok[i] = K.verdict();
 }
 
+// Small in-stream copies as kernels (16 bytes per lane): task lists from pinned host memory (the device reads it over the
+// link), results into the batch's result arena.  As hipMemcpyAsync they would go to the DMA engines with a dependency on
+// the kernels before them in their stream, and a bulk upload of another thread (quicked_batch_reload) then queues behind
+// them on the same engine until that run has executed: 9 ms of transfer took 80 (tools/probe_reload.py).
+struct CopyTable {
+    enum { MAX = 16 };
+    int32_t n;
+    uint4* dst[MAX]; const uint4* src[MAX]; int64_t n_u4[MAX];
+};
+__global__ __launch_bounds__(256) void k_copy_multi(CopyTable T) {
+    const int e = blockIdx.y;
+    if (e >= T.n) return;
+    uint4* __restrict__ d = T.dst[e]; const uint4* __restrict__ q = T.src[e];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.n_u4[e]; i += (int64_t)gridDim.x * blockDim.x) d[i] = q[i];
+}
+
 // copies the first *total bytes (a count only the device knows: the string pool of a run) from src to dst, 16 bytes per lane
 __global__ __launch_bounds__(256) void k_copy_total(uint4* __restrict__ dst, const uint4* __restrict__ src, const int64_t* __restrict__ total, int64_t cap_u4) {
     const int64_t n = min((*total + 15) >> 4, cap_u4);

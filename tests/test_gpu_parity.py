@@ -963,7 +963,7 @@ def test_two_host_threads_plan_hbm_together():
     """the process-wide HBM ledger: two host threads, each with 150 k pairs of 10 kb through QuickEd + CIGAR (~35 GB of fill
     checkpoints per run and pool set), plan their device pools against what the OTHER has planned, not against the whole
     device each: no out-of-memory reclaim event, both threads' results equal to the oracle's on a stride.  A thread that
-    ends gives its pools back."""
+    is done gives its pools back (quicked_pool_trim)."""
     import threading
     n = 150000
     batch = datagen.generate(count=n, length=10000, error=0.05, seed=0x51CED)
@@ -990,6 +990,7 @@ def test_two_host_threads_plan_hbm_together():
             cg = rb.cigars()
             stats[name] = capi.pool_stats()
             rb.close()
+            assert capi.pool_trim() == 0          # this thread is done: its pools go back to the device
             assert (st == capi.QUICKED_WIP).all()
             for i in list(range(0, n, n // 24)) + [n - 1]:
                 assert (st[i], s[i], cg[i]) == O.oracle_align(batch.pattern(i), batch.text(i), algo=0), (name, i)
@@ -1015,7 +1016,7 @@ def test_two_host_threads_plan_hbm_together():
     assert sum(stats[k]["pool_bytes"] for k in ("a", "b")) < total, stats
     assert all(stats[k]["sets"] >= 2 and stats[k]["sub_batches"] <= 2 for k in ("a", "b")), stats      # nobody was starved
     assert min(rates.values()) > 0.4e6, rates           # a ledger test, not a benchmark: four runs each, pools growing, two threads on one chip
-    # the threads have ended: their pools are back (this thread's own view: nothing held by it, and a fresh plan sees the device)
+    # the threads trimmed their pools before they ended: the device is free again
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
     free_b, total_b = C.c_size_t(), C.c_size_t()
