@@ -272,6 +272,18 @@ struct Context {
     hipStream_t stream_w = nullptr;          // utility stream: loads, fetches, the validator -- everything outside a run
     hipStream_t stream_w2[NA] = {}, stream_a2[NA] = {};
     hipStream_t stream = nullptr;            // where the current phase launches
+    // fork-join helper: the reverse half passes of a Hirschberg level run next to the forward ones (two 5000-wave launches
+    // on one stream each end in a tail of their own; side by side the chip stays full until both are nearly done)
+    hipStream_t stream_x = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side_stream() {
+        if (!stream_x) {
+            HIP_CHECK(hipStreamCreateWithFlags(&stream_x, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        return stream_x;
+    }
     DevicePool pool_w, pool_w2[NA], pool_a2[NA];
     int ai = 0;                              // which set the current run uses
     PinnedStage stage[2 * NA];               // see PinnedStage
@@ -307,6 +319,7 @@ struct Context {
     void phase_u() { stream = stream_w; scratch_p = &pool_w; }
     void sync_all() {
         HIP_CHECK(hipStreamSynchronize(stream_w));
+        if (stream_x) HIP_CHECK(hipStreamSynchronize(stream_x));
         for (auto q : stream_a2) if (q) HIP_CHECK(hipStreamSynchronize(q));
     }
     // A set's stream is created when the rotation first reaches it: a thread that only loads and fetches (an uploader, a
@@ -416,7 +429,7 @@ static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
     if (src.empty()) return;
     const size_t bytes = src.size() * sizeof(T);
     Context* C = tl_ctx;
-    if (C && C->staging && (s == C->sa() || s == C->sw())) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
+    if (C && C->staging && (s == C->sa() || s == C->sw() || s == C->stream_x)) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
         uint8_t* st = C->stage[C->si].take(bytes);
         memcpy(st, src.data(), bytes);
         copy_kernel(dst, st, bytes, s);                            // the device reads the pinned stage itself: no DMA engine involved
@@ -629,7 +642,7 @@ struct DevTasks {
 static void h2d_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
     Context* C = tl_ctx;
-    if (C && C->staging && (s == C->sa() || s == C->sw())) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
+    if (C && C->staging && (s == C->sa() || s == C->sw() || s == C->stream_x)) {      // W-phase copies too: the run's A phase, whose end frees the stage, is behind them
         uint8_t* st = C->stage[C->si].take(bytes);
         memcpy(st, src, bytes);
         copy_kernel(dst, st, bytes, s);
@@ -997,8 +1010,18 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
     }
 }
 
+// few alignments with many runs each (long reads): one wave per alignment; else one lane per alignment.  Decided before the
+// traceback runs: the wave form wants every task's runs in a stretch of their own (TraceArgs::runs_by_task)
+static bool wave_formatter_wanted(const quicked_batch& B, const SegList& SL, bool want_strings) {
+    const size_t nr = SL.root_pair.size(), nseg = SL.kind.size();
+    size_t pool_bytes = 0;
+    if (want_strings) for (size_t b : SL.bound) pool_bytes += b;
+    const int wave_env = env_int("QE_FORMAT_WAVE", -1);      // tests force either form
+    return B.cigar_style != 2 && nr > 0 && (wave_env >= 0 ? wave_env != 0 : (nr <= 32768 && nseg > 0 && pool_bytes / nr >= 16384));
+}
+
 static AlignOut format_segments(const quicked_batch& B, Context& C, const SegList& SL, const u32* runs, const int64_t* g_runs_off,
-                                const int32_t* nruns, bool want_strings) {
+                                const int32_t* nruns, bool want_strings, bool wave = false, const int32_t* g_runs_cap = nullptr, bool runs_by_task = false) {
     AlignOut A;
     A.nroots = SL.root_pair.size();
     const size_t nr = A.nroots, nseg = SL.kind.size();
@@ -1017,6 +1040,7 @@ static AlignOut format_segments(const quicked_batch& B, Context& C, const SegLis
     SegFormatArgs f;
     f.npairs = (int32_t)nr; f.seg_off = d_off; f.seg_kind = d_kind; f.seg_a = d_a; f.seg_b = d_b;
     f.runs = runs; f.g_runs_off = g_runs_off; f.nruns = nruns;
+    f.g_runs_cap = g_runs_cap; f.runs_by_task = runs_by_task ? 1 : 0;
     f.o_len = A.len; f.o_edits = A.edits; f.o_nops = A.nops; f.str_off = A.str_off; f.pool = A.pool;
     f.style = B.cigar_style;
     const int blocks = (int)((nr + 63) / 64);
@@ -1026,10 +1050,7 @@ static AlignOut format_segments(const quicked_batch& B, Context& C, const SegLis
         ck.F = f; ck.P = pair_view(B, false); ck.root_pair = d_rootpair; ck.o_ok = A.ok;
         hipLaunchKernelGGL(k_check_segs, dim3(blocks), dim3(64), 0, C.stream, ck);
     }
-    // few alignments with many runs each (long reads): one wave per alignment; else one lane per alignment
-    const int wave_env = env_int("QE_FORMAT_WAVE", -1);      // tests force either form
-    const bool wave = B.cigar_style != 2 && nr > 0 &&
-                      (wave_env >= 0 ? wave_env != 0 : (nr <= 32768 && nseg > 0 && pool_bytes / nr >= 16384));
+    (void)nseg;
     if (wave) hipLaunchKernelGGL(k_format_segs_wave<false>, dim3((unsigned)nr), dim3(64), 0, C.stream, f);
     else hipLaunchKernelGGL(k_format_segs<false>, dim3(blocks), dim3(64), 0, C.stream, f);
     if (want_strings) {
@@ -1111,7 +1132,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
             SL.off.push_back((int64_t)SL.kind.size());
             SL.root_pair.push_back(L.pair[t]); SL.bound.push_back(cigar_bound(L.m[t], L.n[t]));
         }
-        AO = format_segments(B, C, SL, D.runs, D.runs_off, O.nruns, want_cigar);
+        AO = format_segments(B, C, SL, D.runs, D.runs_off, O.nruns, want_cigar, wave_formatter_wanted(B, SL, want_cigar), D.runs_cap, false);
         if (d_score_out) *d_score_out = AO.edits;
     }
     if (pf && !fetch) {
@@ -1203,8 +1224,15 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             C.stream = cur; B.have_rev[B.parity] = true;
         }
         const int Gf = coop_lanes(F);
+        // forward half passes on the run's stream, reverse ones beside them on the side stream, joined before k_join
+        static const int side_env = env_int("QE_SIDE_STREAM", 1);
+        hipStream_t main_s = C.stream, side = side_env ? C.side_stream() : main_s;
+        if (side != main_s) { HIP_CHECK(hipEventRecord(C.ev_fork, main_s)); HIP_CHECK(hipStreamWaitEvent(side, C.ev_fork, 0)); }
         const ScoreLaunch SF = (Gf >= 2) ? launch_banded_coop(B, C, F, false, Gf, false) : launch_banded_score(B, C, F, false, false);
+        C.stream = side;
         const ScoreLaunch SV = (Gf >= 2) ? launch_banded_coop(B, C, V, true, Gf, false) : launch_banded_score(B, C, V, true, false);
+        C.stream = main_s;
+        if (side != main_s) { HIP_CHECK(hipEventRecord(C.ev_join, side)); HIP_CHECK(hipStreamWaitEvent(main_s, C.ev_join, 0)); }
         const size_t ns = split.size();
         JoinArgs J;
         J.nnodes = (int32_t)ns;
@@ -1335,6 +1363,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     h2d(d_nslots, lay.nslots, C.stream); h2d(d_nrows, lay.nrows, C.stream); h2d(d_nch, lay.nch, C.stream);
     h2d(d_runs_cap, lay.runs_cap, C.stream);
     u32* d_runs = C.scratch_p->take<u32>(lay.runs_u32 + 64);
+    const bool wave_fmt = wave_formatter_wanted(B, SL, want_cigar);       // also the layout the traceback leaves its runs in
     for (size_t sb = 0; sb + 1 < sub_start.size(); ++sb) {
         const int g0 = sub_start[sb], g1 = sub_start[sb + 1];
         if (g1 <= g0) continue;
@@ -1368,12 +1397,13 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         tr.mat = mat; tr.g_mat_off = a.g_mat_off;
         tr.runs = d_runs; tr.g_runs_off = d_runs_off + g0; tr.g_runs_cap = d_runs_cap + g0;
         tr.o_nruns = O.nruns + o; tr.o_nops = O.nops + o; tr.o_edits = O.edits + o; tr.o_steps = O.steps + o;
+        tr.runs_by_task = wave_fmt ? 1 : 0;
         launch_groups(C, k_traceback, tr, (size_t)(g1 - g0), 8, 0);
         // the next sub-batch reuses this scratch: its kernels are behind this sub-batch's in the stream, no host wait
         if (sb + 2 < sub_start.size()) C.scratch_p->release(mark);
     }
     QE_TRACE_POINT("  fill+traceback queued");
-    const AlignOut AO = format_segments(B, C, SL, d_runs, d_runs_off, O.nruns, want_cigar);
+    const AlignOut AO = format_segments(B, C, SL, d_runs, d_runs_off, O.nruns, want_cigar, wave_fmt, d_runs_cap, wave_fmt);
     QE_TRACE_POINT("  format queued");
     if (d_score_out) *d_score_out = AO.edits;
     if (pf && !fetch) {

@@ -1714,12 +1714,14 @@ __global__ __launch_bounds__(256) void k_banded_wave(BandedArgs A) {
 // RLE emitter shared by the tracebacks: ops arrive back to front
 // ---------------------------------------------------------------------------
 struct RunSink {
-    u32* runs; int cap; int nruns; int cur_op; int cur_len; int nops; int edits;
-    __device__ __forceinline__ void init(u32* r, int c) { runs = r; cap = c; nruns = 0; cur_op = -1; cur_len = 0; nops = 0; edits = 0; }
+    u32* runs; int cap; int nruns; int cur_op; int cur_len; int nops; int edits; int stride;
+    // stride: elements between consecutive runs of this lane's task: 64 in the [idx][lane] layout (one coalesced row per store
+    // of a wave, what the one-lane-per-alignment formatter reads), 1 when every task has its runs to itself (run_base)
+    __device__ __forceinline__ void init(u32* r, int c, int stride_ = 64) { runs = r; cap = c; nruns = 0; cur_op = -1; cur_len = 0; nops = 0; edits = 0; stride = stride_; }
     __device__ __forceinline__ void push(int op) {
         if (op == cur_op) { ++cur_len; }
         else {
-            if (cur_len > 0 && nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
+            if (cur_len > 0 && nruns < cap) runs[(int64_t)nruns * stride] = ((u32)cur_len << 2) | (u32)cur_op;
             if (cur_len > 0) ++nruns;
             cur_op = op; cur_len = 1;
         }
@@ -1730,7 +1732,7 @@ struct RunSink {
         if (count <= 0) return;
         if (op == cur_op) { cur_len += count; }
         else {
-            if (cur_len > 0 && nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
+            if (cur_len > 0 && nruns < cap) runs[(int64_t)nruns * stride] = ((u32)cur_len << 2) | (u32)cur_op;
             if (cur_len > 0) ++nruns;
             cur_op = op; cur_len = count;
         }
@@ -1741,7 +1743,7 @@ struct RunSink {
     __device__ __forceinline__ void emit(int op, int count, bool pred) {
         const bool brk = pred && op != cur_op;
         const bool st = brk && cur_len > 0;
-        if (st && nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
+        if (st && nruns < cap) runs[(int64_t)nruns * stride] = ((u32)cur_len << 2) | (u32)cur_op;
         nruns += st ? 1 : 0;
         cur_len = brk ? count : cur_len + (pred ? count : 0);
         cur_op = brk ? op : cur_op;
@@ -1750,7 +1752,7 @@ struct RunSink {
     }
     __device__ __forceinline__ void flush() {
         if (cur_len > 0) {
-            if (nruns < cap) runs[(int64_t)nruns * 64] = ((u32)cur_len << 2) | (u32)cur_op;
+            if (nruns < cap) runs[(int64_t)nruns * stride] = ((u32)cur_len << 2) | (u32)cur_op;
             ++nruns;
             cur_len = 0;
         }
@@ -1851,7 +1853,10 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     const int64_t cps = (int64_t)gns * 64;
     const uint4* hw = cp + (int64_t)8 * gnch * cps;
     RunSink R;
-    R.init(valid ? A.runs + A.g_runs_off[g] + lane : nullptr, valid ? A.g_runs_cap[g] : 0);
+    {
+        const int cap = valid ? A.g_runs_cap[g] : 0;
+        R.init(valid ? A.runs + A.g_runs_off[g] + (A.runs_by_task ? (int64_t)lane * cap : (int64_t)lane) : nullptr, cap, A.runs_by_task ? 1 : 64);
+    }
     int h = n - 1, v = m - 1;
     u32 steps = 0;
     // what a round needs besides the checkpoint changes rarely: band-edge records and text planes per chunk (every 8
@@ -2355,6 +2360,19 @@ __global__ __launch_bounds__(64) void k_join(JoinArgs A) {
 // Segment formatter: one lane per pair walks its segments front to back (a
 // leaf's runs were emitted back to front), merging equal neighbours.
 // ===========================================================================
+// where the runs of leaf task t are (see RunSink): [idx][lane] rows of its 64-task group, or a stretch of its own
+struct RunView {
+    const u32* base; int64_t stride;
+    __device__ __forceinline__ u32 at(int64_t k) const { return base[k * stride]; }
+};
+__device__ __forceinline__ RunView run_view(const SegFormatArgs& A, int t) {
+    const int g = t >> 6, lane = t & 63;
+    RunView v;
+    if (A.runs_by_task) { v.base = A.runs + A.g_runs_off[g] + (int64_t)lane * A.g_runs_cap[g]; v.stride = 1; }
+    else { v.base = A.runs + A.g_runs_off[g] + lane; v.stride = 64; }
+    return v;
+}
+
 struct RunMerger {
     int style = 0;                  // SegFormatArgs::style
     int op = -1, len = 0, total = 0, edits = 0, nops = 0;
@@ -2422,10 +2440,10 @@ __global__ __launch_bounds__(64) void k_format_segs(SegFormatArgs A) {
     for (int64_t sidx = A.seg_off[i]; sidx < A.seg_off[i + 1]; ++sidx) {
         if (A.seg_kind[sidx] == 1) { Mg.push<WRITE>(A.seg_a[sidx], A.seg_b[sidx]); continue; }
         const int t = A.seg_a[sidx];
-        const u32* runs = A.runs + A.g_runs_off[t >> 6] + (t & 63);
+        const RunView runs = run_view(A, t);
         if (A.nruns[t] < 0) bad = true;                                   // run buffer overflow (see k_traceback)
         for (int k = A.nruns[t] - 1; k >= 0 && !bad; --k) {
-            const u32 r = runs[(int64_t)k * 64];
+            const u32 r = runs.at(k);
             Mg.push<WRITE>((int)(r & 3), (int)(r >> 2));
         }
     }
@@ -2461,7 +2479,7 @@ struct SegCursor {
     __device__ __forceinline__ void get(int& op, int& len) const {
         if (A->seg_kind[seg] == 1) { op = A->seg_a[seg]; len = A->seg_b[seg]; return; }
         const int t = A->seg_a[seg];
-        const u32 r = A->runs[A->g_runs_off[t >> 6] + (t & 63) + (int64_t)(A->nruns[t] - 1 - k) * 64];
+        const u32 r = run_view(*A, t).at(A->nruns[t] - 1 - k);
         op = (int)(r & 3); len = (int)(r >> 2);
     }
     __device__ __forceinline__ void next() {
@@ -2572,10 +2590,10 @@ __global__ __launch_bounds__(64) void k_check_segs(SegCheckArgs C) {
     for (int64_t sidx = A.seg_off[i]; sidx < A.seg_off[i + 1]; ++sidx) {
         if (A.seg_kind[sidx] == 1) { K.apply(A.seg_a[sidx], A.seg_b[sidx]); continue; }
         const int t = A.seg_a[sidx];
-        const u32* runs = A.runs + A.g_runs_off[t >> 6] + (t & 63);
+        const RunView runs = run_view(A, t);
         if (A.nruns[t] < 0) K.ok = false;
         for (int k = A.nruns[t] - 1; k >= 0; --k) {
-            const u32 r = runs[(int64_t)k * 64];
+            const u32 r = runs.at(k);
             K.apply((int)(r & 3), (int)(r >> 2));
         }
     }

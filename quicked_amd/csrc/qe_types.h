@@ -108,6 +108,8 @@ struct TraceArgs {
     const uint4* mat;  const int64_t* g_mat_off;
     u32* runs;  const int64_t* g_runs_off;  const int32_t* g_runs_cap;   // [idx][64] u32 = len << 2 | op
     int32_t* o_nruns;  int32_t* o_nops;  int32_t* o_edits;  u32* o_steps;
+    int32_t runs_by_task;    // != 0: task (g, lane) has the stretch [lane * cap, (lane + 1) * cap) of its group's buffer to itself
+                             // (the wave-per-alignment formatter reads it sequentially; [idx][lane] rows cost it a 256-byte row per run)
 };
 
 // WindowEd chain (bpm_windowed.c:563-628)
@@ -160,6 +162,7 @@ struct SegFormatArgs {
     const int64_t* seg_off;      // [npairs + 1]
     const int32_t* seg_kind;  const int32_t* seg_a;  const int32_t* seg_b;
     const u32* runs;  const int64_t* g_runs_off;  const int32_t* nruns;   // per leaf task
+    const int32_t* g_runs_cap;  int32_t runs_by_task;                      // layout of `runs` (TraceArgs::runs_by_task)
     int32_t* o_len;  int32_t* o_edits;  int32_t* o_nops;                  // per pair-list entry
     const int64_t* str_off;  char* pool;
     // 0: the reference's RLE "MXID" (cigar_sprint, cigar.c:453-488); 1: SAM with mismatches "=XID";
