@@ -640,6 +640,9 @@ def main():
     ap.add_argument("--e2e-uploaders", type=int, default=0, help="uploader threads (0: 2 for score-only BandEd, 3 for QuickEd)")
     ap.add_argument("--e2e-inflight", type=int, default=0, help="runs queued and not yet fetched (0: 2 for score-only BandEd, 3 for QuickEd)")
     ap.add_argument("--no-strong", action="store_true", help="no strong (N > 1) / strong_share (N = 1) legs")
+    ap.add_argument("--indel-pairs", type=int, default=20000,
+                    help="pairs of the indel-heavy QuickEd leg (4 x 800-base indels per 10 kb pair: stages 2 / 3 and band doubling, "
+                         "SURVEY's own trigger set); 0: no such leg")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="profiling aid: no overlap between consecutive runs, so per-kernel durations are those of a kernel alone")
     ap.add_argument("--seed", type=int, default=0x51CED)
@@ -693,10 +696,23 @@ def main():
         args.cpu_budget = min(args.cpu_budget, 6.0)
         others["quicked"] = B.workload_object("quicked", args.pairs, args.steps, args.warmup, with_e2e=not args.no_e2e,
                                               with_cpu=not args.no_cpu_baseline)
+    if default_shape and args.indel_pairs > 0 and args.indels_num == 0 and world == 1:
+        # QuickEd's stages 2 / 3 (quicked.c:204-280): pairs with large indels leave stage 1, go through WindowEd(L) forward
+        # and reverse and, most of them, through score-only BandEd with band doubling before the align step.  Host-driven
+        # regrouping here (qe_driver.hip, quicked_classic); timed so that the rate is on record next to the uniform one
+        saved = (args.indels_num, args.indels_len)
+        args.indels_num, args.indels_len = 4, 800
+        B._cache = None
+        o = B.workload_object("quicked", args.indel_pairs, min(args.steps, 10), 2, with_e2e=False, with_cpu=False)
+        args.indels_num, args.indels_len = saved
+        B._cache = None
+        others["quicked_indels"] = {k: o[k] for k in ("value", "unit", "ms_per_step", "pairs_per_gpu", "steps", "runs_in_flight",
+                                                       "single_batch_latency_ms", "quicked_flow", "score_checksum")}
+        others["quicked_indels"]["data"] = "4 x 800-base indels per pair on top of the 5 % edits (generate_dataset's -I 4 -L 800)"
     # ---- strong scaling: `pairs` pairs in total (BASELINE.json's "100 k pairs at 8 GPUs"); at N = 1 the per-GPU share of it
     strong, strong_share = None, None
     if not args.no_strong:
-        wls = [args.workload] + list(others)
+        wls = [args.workload] + [w for w in others if w == "quicked"]
         if world > 1:
             strong = {}
             for wl in wls:
@@ -738,8 +754,9 @@ def main():
             if k in head:
                 line[k] = head[k]
         if others:
-            line["workloads"] = {wl: dict(o, config={"workload": f"{wl}, DEVICE-RESIDENT inputs, the same {args.pairs} pairs/GPU x "
-                                                                 f"{args.length} bp @ {args.error:g} error; CIGAR strings left in HBM "
+            line["workloads"] = {wl: dict(o, config={"workload": f"{wl}, DEVICE-RESIDENT inputs, " +
+                                                                 (f"the same {args.pairs}" if wl == "quicked" else str(o.get("pairs_per_gpu"))) +
+                                                                 f" pairs/GPU x {args.length} bp @ {args.error:g} error; CIGAR strings left in HBM "
                                                                  "(end-to-end: e2e, strings on the host)"})
                                  for wl, o in others.items()}
         if strong is not None:

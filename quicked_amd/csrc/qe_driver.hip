@@ -132,6 +132,7 @@ struct DevicePool {
         return true;
     }
     size_t used_hint() const { return cap; }
+    size_t largest_chunk() const { size_t m = 0; for (const auto& c : chunks) m = std::max(m, c.cap); return m; }
     ~DevicePool() { for (auto& c : chunks) if (c.base) (void)hipFree(c.base); }
 };
 
@@ -1497,8 +1498,22 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
             StageResult F, V;
             const int W = (int)p.window_size, O = (int)p.overlap_size;
             qe_timer_start(tl_timers.windowed_l);
-            run_windowed(B, C, L2, false, W, O, (int)p.hew_threshold[1], true, sse, &F, true, false, nullptr);
-            run_windowed(B, C, L2, true, W, O, (int)p.hew_threshold[1], true, sse, &V, true, false, nullptr);
+            {
+                // forward and reverse WindowEd(L) side by side (quicked.c:204-235 runs them one after the other): each is a
+                // few hundred waves of serial window chains, i.e. latency, and neither needs the other's result
+                TaskOut OF, OV;
+                hipStream_t main_s = C.stream, side = C.side_stream();
+                HIP_CHECK(hipEventRecord(C.ev_fork, main_s)); HIP_CHECK(hipStreamWaitEvent(side, C.ev_fork, 0));
+                run_windowed(B, C, L2, false, W, O, (int)p.hew_threshold[1], true, sse, nullptr, false, false, nullptr, nullptr, &OF);
+                C.stream = side;
+                run_windowed(B, C, L2, true, W, O, (int)p.hew_threshold[1], true, sse, nullptr, false, false, nullptr, nullptr, &OV);
+                const size_t nt2 = L2.pair.size();
+                d2h(V.score, OV.score, nt2, side); d2h(V.hew, OV.hew, nt2, side); d2h(V.steps, OV.steps, nt2, side);
+                C.stream = main_s;
+                d2h(F.score, OF.score, nt2, main_s); d2h(F.hew, OF.hew, nt2, main_s); d2h(F.steps, OF.steps, nt2, main_s);
+                HIP_CHECK(hipStreamSynchronize(side));
+                HIP_CHECK(hipStreamSynchronize(main_s));
+            }
             qe_timer_stop(tl_timers.windowed_l);
             B.counters[2] += (int64_t)sum_u32(F.steps) + (int64_t)sum_u32(V.steps);
             TaskList L3; std::vector<size_t> idx3;
@@ -1655,6 +1670,12 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     } restore{B, C, B.parity, C.staging, B.d_score, C.pw().mark(), C.pa().mark()};
     B.parity = parity;
     C.staging = false;
+    // Everything this thread's pools hold is dead by now: its streams are idle (sync_all above), the run being fetched has
+    // its results on the host or in the batch's result arena, and the three small arrays read above were the last thing
+    // needed from the pools.  The classic flow for the pairs left starts the pools over instead of stacking its buffers
+    // on the fast flow's (76 k of 100 k indel-heavy pairs: 100 GB on top of 170 GB did not fit)
+    C.pw().release(DevicePool::Mark{0, 0});
+    C.pa().release(DevicePool::Mark{0, 0});
     C.phase_w();
     auto enter_a = [&]() { C.phase_a(); };
     quicked_classic(B, C, p, Ls, true, matrix_budget, nullptr, enter_a, false);
@@ -1798,6 +1819,21 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     C.ai = (C.ai + 1) % na;
     C.ensure_set(C.ai);
+    {
+        // A pool is a list of chunks and a request has to fit ONE of them.  When this run's largest request (a sub-batch of
+        // fill checkpoints) is larger than any chunk the pool has, and the pool could not keep its chunks AND get a new one
+        // inside its budget, it starts over with one allocation of the right size (reserve() in run_align) instead of
+        // running out of memory with tens of GB of too-small chunks in hand (100 k indel-heavy pairs: 157 GB of matrices)
+        DevicePool& P = C.pa();
+        // ... the run's largest request: everything but the matrices plus one of its equal fill sub-batches (run_align)
+        const size_t room = C.pool_budget > need_fixed + ((size_t)64 << 20) ? C.pool_budget - need_fixed : (size_t)64 << 20;
+        const size_t nsub = std::max<size_t>(1, (need_mat + room - 1) / room);
+        const size_t want = need_fixed + need_mat / nsub;
+        if (P.cap > ((size_t)1 << 30) && (double)P.largest_chunk() < 0.9 * (double)want && (double)P.cap + (double)want > (double)C.pool_budget) {
+            HIP_CHECK(hipStreamSynchronize(C.sa()));
+            P.release_all();
+        }
+    }
     const int par = B.parity = (B.parity + 1) % B.np_used;
     C.si = (C.si + 1) % (2 * na);
     {

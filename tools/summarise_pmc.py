@@ -78,4 +78,17 @@ if qsq:
     res["quicked_sq"] = qsq
 with open(f"{out}/{tag}_pmc_summary.json", "w") as f:
     json.dump(res, f, indent=1)
+# what bench.py prints as roofline.traffic: the dominant kernel's HBM bytes per launch, keyed by workload and size
+shape = {"banded_score": ("banded_score:100000x10000", "k_banded<false>"), "quicked": ("quicked:100000x10000", "k_banded<true>"),
+         "cfg4": ("quicked:10000x100000", "k_banded<true>"), "share": ("banded_score:12500x10000", "k_banded<false>")}
+latest = {}
+for wl, (key, kern) in shape.items():
+    ent = res.get(wl, {}).get(kern)
+    if ent:
+        latest[key] = dict(kernel=kern, hbm_bytes=ent["hbm_bytes"], FETCH_SIZE_KiB=ent["FETCH_SIZE_KiB"], WRITE_SIZE_KiB=ent["WRITE_SIZE_KiB"],
+                           fetch_factor=ent["fetch_factor"],
+                           source=f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, per launch; "
+                                  "x2 on FETCH_SIZE calibrated with tools/pmc_calib.hip for 4/8/16 B per lane)")
+with open(f"{out}/pmc_traffic_latest.json", "w") as f:
+    json.dump(latest, f, indent=1)
 print(json.dumps(res, indent=1))
