@@ -1195,6 +1195,12 @@ struct ScoreRing {            // scores[] of block row (slot + chunk - prolog) l
     }
 };
 
+struct FillSink {             // where a FILL pass leaves what the traceback reads (k_banded<true>'s layout, this task's column)
+    uint4* cp;                // checkpoints: cp[(8 chunk + j) * cps + slot * 64]
+    uint4* hw;                // carry-in words: hw[(chunk * gns + slot) * 64]
+    int64_t cps; int gns;
+};
+
 template <int K>
 __device__ __forceinline__ void coop_pass(bool on, int i0, int fk, int hi, int pos_v, int NA, u64* Pv, u64* Mv, const int32_t* Srd, int32_t* Swr,
                                           const ScoreRing R, const u64* pp, int p0, u64 T0, u64 T1, u64 hinP, u64 hinM, u64& houtP, u64& houtM, u32& adv) {
@@ -1227,6 +1233,7 @@ __device__ __forceinline__ void coop_pass(bool on, int i0, int fk, int hi, int p
     }
 }
 
+template <bool FILL>
 __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
     const CoopArgs& A = X.A;
     const int lane = threadIdx.x & 63, w = QE_GROUP_INDEX();
@@ -1242,7 +1249,7 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
     u32 fl = 0;
     if (valid) {
         m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
-        cut_in = A.T.cutoff[t]; tfin = A.T.tfin[t];
+        cut_in = A.T.cutoff[t]; tfin = FILL ? n : A.T.tfin[t];
         pp = A.P.pl_p + A.P.pl_p_off[pair];
         tp = A.P.pl_t + A.P.pl_t_off[pair];
         fl = A.P.flags[pair];
@@ -1250,11 +1257,13 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
     const bool hasN = (fl & FLAG_HAS_N) != 0;
     const Geom GE = band_geometry(m, n, cut_in);
     const int nw = (m + 63) >> 6;
-    const int nsl = ((GE.cutoff + 63) >> 6) + 1;
+    const int nsl = FILL ? GE.ebb : ((GE.cutoff + 63) >> 6) + 1;        // the score-only passes use their own narrower band (bpm_banded.c:801-803)
+    const int stop_row = FILL ? nw - 1 : nw;                            // bpm_banded.c:295 / 917
     const int lvl_last = (m - 1) & 63;
     const int prolog = GE.prolog;
     // my slots, and the passes every lane of the wave walks them in
-    const int wns = A.w_nslots[w];
+    const int grp = (w * NA) >> 6, lane_t = (w * NA + q) & 63;           // FILL: my task's group and column in the traceback's layout
+    const int wns = FILL ? X.g_nslots[grp] : A.w_nslots[w];
     const int cper = max((wns + G - 1) >> lgG, 2);
     const int slo = g * cper, shi = slo + cper - 1;
     const int npass = max(2, (cper + 3) >> 2), kbase = cper / npass, kextra = cper - kbase * npass;
@@ -1271,6 +1280,17 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
     volatile int32_t* const KF = (volatile int32_t*)lb + q;  lb += (size_t)NA * 4;
     volatile int32_t* const KL = (volatile int32_t*)lb + q;
 #define QE_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+    // FILL: checkpoints, carry words and band-edge records go where k_traceback reads them (k_banded<true>'s layout)
+    FillSink FS; FS.cp = nullptr; FS.hw = nullptr; FS.cps = 0; FS.gns = 0;
+    int16_t* gcf = nullptr; int16_t* gcl = nullptr;
+    if (FILL) {
+        const int gns = X.g_nslots[grp], gnch = X.g_nch[grp];
+        const GroupWs GW = group_ws(X.gws, X.g_ws_off[grp], gns, X.g_nrows[grp], gnch);
+        gcf = GW.cf + lane_t; gcl = GW.cl + lane_t;
+        FS.cp = X.mat + X.g_mat_off[grp] + lane_t;
+        FS.cps = (int64_t)gns * 64; FS.gns = gns;
+        FS.hw = FS.cp + (int64_t)8 * gnch * FS.cps;
+    }
 
     // bpm_reset_search (bpm_banded.c:180-197): slots 0 .. nsl-1, block rows 0 .. nsl-1 (row r at ring index r + prolog)
     if (valid) {
@@ -1280,8 +1300,12 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
             int ri = x + prolog; ri -= (ri >= rr) ? rr : 0;
             S0[ri * NA] = 64 * (x + 1);
             S0[Spar + ri * NA] = 64 * (x + 1);
+            if (FILL) FS.cp[(int64_t)x * 64] = make_uint4(~0u, ~0u, 0u, 0u);
         }
-        if (g == 0) { CF[0] = (int16_t)prolog; CL[0] = (int16_t)(nsl - 1); *KF = 1; *KL = 1; }
+        if (g == 0) {
+            CF[0] = (int16_t)prolog; CL[0] = (int16_t)(nsl - 1); *KF = 1; *KL = 1;
+            if (FILL) { gcf[0] = (int16_t)prolog; gcl[0] = (int16_t)(nsl - 1); }
+        }
     }
     QE_WAVE_FENCE();
     const int nfull = tfin >> 6, tail = tfin & 63;
@@ -1326,7 +1350,10 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
             const int K = kbase + (p < kextra ? 1 : 0);                  // the same in every lane of the wave
             const bool plive = any_live && i0 + K - 1 >= lo_l && i0 <= hi_l;
             const bool slowl = plive && (ncols != 64 || hasN || (lastrow_slot >= max(i0, lo_l) && lastrow_slot <= min(i0 + K - 1, hi_l)));
-            if (!__any(slowl)) {
+            // FILL: every slot leaves its checkpoints and carry words for the traceback -- one slot at a time (run64_fast's
+            // STORE == 2, as in k_banded<true>; a multi-slot pass that also stores spills hundreds of registers): what the
+            // cooperative form buys a fill is lanes, for launches of few leaves
+            if (!FILL && !__any(slowl)) {
                 const u64 hP = (i0 <= fk) ? QE_ONES : cP, hM = (i0 <= fk) ? 0 : cM;      // PHin = 1 into the band's top block
                 switch (K) {
                     case 4: coop_pass<4>(on, i0, fk, hi, pos_v, NA, Pv, Mv, Srd, Swr, R, pp, p0, T0, T1, hP, hM, cP, cM, adv); break;
@@ -1347,13 +1374,21 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
                     const bool lastblk = (r == nw - 1);
                     const u64 hP = (i <= fk) ? QE_ONES : cP, hM = (i <= fk) ? 0 : cM;
                     u64 houtP = 0, houtM = 0, sP, sM;
+                    uint4* st = nullptr; uint4* st_last = nullptr;
+                    if (FILL) {
+                        // the chunk's last column belongs to the NEXT chunk's slot numbering (bpm_banded.c:279-287)
+                        st = FS.cp + (int64_t)(8 * k) * FS.cps + (int64_t)i * 64;
+                        st_last = FS.cp + (int64_t)(8 * k + 8) * FS.cps + (int64_t)(i - 1) * 64;
+                        if (i == 0) st_last = st + 8 * FS.cps;                 // slot -1 does not exist; dropped row, never read
+                        if (act) FS.hw[((int64_t)k * FS.gns + i) * 64] = make_uint4(lo32(hP), hi32(hP), lo32(hM), hi32(hM));
+                    }
                     const bool slow = act && (ncols != 64 || hasN || lastblk);
                     if (!__any(slow)) {
-                        run64_fast<0, true>(P, M, a, b, T0, T1, hP, hM, houtP, houtM, act, nullptr, 0, nullptr);
+                        run64_fast<FILL ? 2 : 0, true>(P, M, a, b, T0, T1, hP, hM, houtP, houtM, act, st, FS.cps, st_last);
                         sP = houtP; sM = houtM;
                     } else {
-                        run64_general<0>(P, M, a, b, nn, T0, T1, TN, hP, hM, houtP, houtM, sP, sM,
-                                         lastblk ? lvl_last : 63, act ? ncols : 0, false, nullptr, 0, nullptr);
+                        run64_general<FILL ? 2 : 0>(P, M, a, b, nn, T0, T1, TN, hP, hM, houtP, houtM, sP, sM,
+                                                    lastblk ? lvl_last : 63, act ? ncols : 0, true, st, FS.cps, st_last);
                     }
                     if (act) {
                         sc += __popcll(sP) - __popcll(sM);
@@ -1396,6 +1431,7 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
                         if (cut_lo && k >= prolog) fnew = f + 1;
                         else if (!cut_lo && k < prolog) fnew = f - 1;
                         CF[((k + 1) & crm) * NA] = (int16_t)fnew;
+                        if (FILL) gcf[(int64_t)(k + 1) * 64] = (int16_t)fnew;
                         *KF = k + 2;
                         decided = true;
                     }
@@ -1410,14 +1446,16 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
                         const int fnew = CF[((k + 1) & crm) * NA];
                         Pv[l * NA] = QE_ONES;
                         Mv[l * NA] = 0;
+                        if (FILL) FS.cp[(int64_t)(8 * k + 8) * FS.cps + (int64_t)l * 64] = make_uint4(~0u, ~0u, 0u, 0u);
                         const int pos = l + pos_v;
                         Swr[R.at(l + 1) * NA] = Swr[R.at(l) * NA] + 64;
                         maxrow = max(maxrow, pos + 1);
                         bool cut_hi = false;
                         if ((fnew + 2 < l) && (64 * (l - 1) > GE.fin))
                             cut_hi = Swr[R.at(l - 1) * NA] + (64 * (l - 1) - GE.fin) > GE.cutoff;
-                        const int lnew = (cut_hi || (pos_v + l >= nw)) ? l - 1 : l;
+                        const int lnew = (cut_hi || (pos_v + l >= stop_row)) ? l - 1 : l;
                         CL[((k + 1) & crm) * NA] = (int16_t)lnew;
+                        if (FILL) gcl[(int64_t)(k + 1) * 64] = (int16_t)lnew;
                         *KL = k + 2;
                         decided = true;
                     }
@@ -1441,7 +1479,7 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
         aborted |= __shfl_xor(aborted, o);
     }
     // ---- the stopped band goes to the launch's global workspace, k_banded_coop's layout (ColDist reads it there)
-    {
+    if (!FILL) {
         const int gns = wns, gnr = A.w_nrows[w];
         uint8_t* base = A.ws + A.w_ws_off[w];
         u64* const gP = (u64*)base + NA + q;                                   base += (int64_t)(gns + 1) * NA * 8;
@@ -1492,6 +1530,8 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
     }
 #undef QE_WAVE_FENCE
 }
+template __global__ void k_banded_coop_lds<false>(CoopLdsArgs);
+template __global__ void k_banded_coop_lds<true>(CoopLdsArgs);
 
 // ===========================================================================
 // BandEd score-only, ONE WAVEFRONT PER ALIGNMENT (BASELINE.json's form; for few alignments: a single pair, a

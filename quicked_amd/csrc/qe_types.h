@@ -98,6 +98,10 @@ struct CoopLdsArgs {
     int32_t rr;              // scores[] ring: ns + G + 4 block rows per task and parity
     int32_t cr;              // band-edge rings: a power of two >= G + 4 chunks
     int32_t lds_per_wave;    // bytes
+    // FILL form only (k_banded_coop_lds<true>): where the traceback expects the fill's checkpoints, carry words and band
+    // edges -- BandedArgs' per-GROUP layout (64 tasks per group, column = task & 63); a wave's 64 / G tasks lie in one group
+    uint4* mat;  const int64_t* g_mat_off;
+    uint8_t* gws;  const int64_t* g_ws_off;  const int32_t* g_nslots;  const int32_t* g_nrows;  const int32_t* g_nch;
 };
 
 // BandEd traceback over a filled matrix (bpm_banded.c:967-1036) -> RLE runs, back to front

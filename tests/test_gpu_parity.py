@@ -321,6 +321,49 @@ def test_cooperative_kernel_forced(lds, monkeypatch):
         assert got == hexp, G
 
 
+def test_cooperative_fill_forced(monkeypatch):
+    """QE_COOP_FILL_G forces the G-lanes-per-leaf fill (k_banded_coop_lds<true>: band state on chip, checkpoints / carry words /
+    band edges written in the one-lane fill's layout for the same k_traceback) where the host would fill with one lane per
+    leaf: CIGARs byte-identical to the oracle's and block-advance counts equal, BandEd + CIGAR at three bandwidths, QuickEd
+    through both of its flows (bounds on the host; bounds still on the device), Hirschberg leaves after forced splits,
+    ragged / N-bearing pairs"""
+    batch = datagen.generate(count=200, length=5000, error=0.06, seed=191)
+    pairs = list(batch.pairs())
+    for G in ("2", "4", "8"):
+        monkeypatch.setenv("QE_COOP_FILL_G", G)
+        for bw in (10, 15, 40):
+            scores, status, cig, cnt = gpu_batch(batch, algo=2, bandwidth=bw)
+            tr = [O.oracle_align(p, t, trace=True, algo=2, bandwidth=bw) for p, t in pairs]
+            assert [(int(a), int(b), c) for a, b, c in zip(status, scores, cig)] == [(x[0], x[1], x[2]) for x in tr], (G, bw)
+            assert cnt[1] == sum(x[3]["fill_block_advances"] for x in tr), (G, bw)
+        rb = capi.ResidentBatch(batch)
+        p = capi.make_params(algo=capi.QUICKED)
+        exp = [O.oracle_align(pt, tt, algo=0) for pt, tt in pairs]
+        for rep in range(3):                          # first run: classic flow; then the stage-1 rule on the device
+            assert rb.run(p, sync=True) >= 0
+            s, st = rb.scores()
+            assert [(int(a), int(b), c) for a, b, c in zip(st, s, rb.cigars())] == exp, (G, rep)
+        rb.close()
+    monkeypatch.setenv("QE_COOP_FILL_G", "4")
+    monkeypatch.setenv("QE_SPLIT_BYTES", str(1 << 17))
+    hb = datagen.generate(count=40, length=6000, error=0.07, seed=92)
+    scores, status, cig, cnt = gpu_batch(hb, algo=3, bandwidth=20)
+    monkeypatch.setenv("QE_COOP_FILL_G", "1")
+    s1, st1, cig1, cnt1 = gpu_batch(hb, algo=3, bandwidth=20)
+    assert (scores.tolist(), status.tolist(), cig, int(cnt[1])) == (s1.tolist(), st1.tolist(), cig1, int(cnt1[1]))
+    monkeypatch.delenv("QE_SPLIT_BYTES")
+    monkeypatch.setenv("QE_COOP_FILL_G", "2")
+    mixed = mixed_batch()
+    al = capi.QuickedAligner()
+    al.setAlgorithm(capi.BANDED); al.setBandwidth(30)
+    st, out = al.alignBatch(mixed)
+    for i, (pp, tt) in enumerate(mixed):
+        est, esc, ecg = O.oracle_align(pp, tt, algo=2, bandwidth=30)
+        in_domain = est < 0 or O.oracle().qo_exact_distance(pp, len(pp), tt, len(tt)) <= max(len(pp), len(tt)) * 30 // 100
+        if in_domain:
+            assert out[i] == (est, esc if est >= 0 else out[i][1], ecg if est >= 0 else out[i][2]), i
+
+
 def test_reference_callers_link_and_run():
     """the reference's own harness, examples and C++ binding, compiled unmodified against the reference's
     headers and linked with libquicked_hip.so (quicked_amd/build.py: build_ref_callers): the drop-in claim.
