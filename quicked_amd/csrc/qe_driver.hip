@@ -573,7 +573,7 @@ static PairView pair_view(const quicked_batch& B, bool reversed) {
 // ---------------------------------------------------------------------------
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 template <typename Kernel, typename Args>
-static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ngroups, int max_waves, size_t lds_per_wave) {
+static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ngroups, int max_waves, size_t lds_per_wave, bool chain = false) {
     if (ngroups == 0) return;
     int wpb = 4;
     static const int wpb_env = env_int("QE_WG_WAVES", 0);
@@ -583,7 +583,12 @@ static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ng
     // the chip has CUs, 84 KB (one per CU): the dispatcher packs the workgroups of CONCURRENT small kernels two to a CU
     // while other CUs idle (three 49-workgroup launches in flight: 16.5 ms each at 54 KB, 11.7 ms at 84 KB, 11.4 ms alone)
     static const int pin_env = env_int("QE_PIN_LDS", 0);
-    const size_t pin = pin_env > 0 ? (size_t)pin_env : (((size_t)blocks * (size_t)std::max(1, C.in_flight) > 256) ? (size_t)54 * 1024 : (size_t)84 * 1024);
+    size_t pin = pin_env > 0 ? (size_t)pin_env : (((size_t)blocks * (size_t)std::max(1, C.in_flight) > 256) ? (size_t)54 * 1024 : (size_t)84 * 1024);
+    // chain: a launch of few waves whose duration is one wave's serial chain (WindowEd on a few thousand long reads: 157
+    // waves of 1563 windows each).  108 KB: no 54 KB workgroup fits beside it, so its waves have their SIMDs to themselves
+    // instead of sharing them with the fill of the run before (config 4: the stage took 59 ms beside that fill, 36 alone)
+    static const int chain_env = env_int("QE_PIN_CHAIN", 108 * 1024);
+    if (chain && pin_env == 0 && (size_t)blocks * (size_t)std::max(1, C.in_flight) <= 128 && chain_env > 0) pin = (size_t)chain_env;
     const size_t lds = std::max(pin, lds_per_wave * (size_t)wpb);
     static thread_local std::vector<std::pair<const void*, int>> configured;      // per host thread and device
     const void* fn = reinterpret_cast<const void*>(kernel);
@@ -1130,7 +1135,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
     a.W = W; a.O = O_; a.hew_threshold = hew_threshold; a.score_only = score_only ? 1 : 0; a.sse = sse ? 1 : 0; a.reversed = reversed ? 1 : 0;
     a.ws = D.ws; a.g_ws_off = D.ws_off; a.runs = D.runs; a.g_runs_off = D.runs_off; a.g_runs_cap = D.runs_cap;
     a.o_score = O.score; a.o_hew = O.hew; a.o_nruns = O.nruns; a.o_nops = O.nops; a.o_edits = O.edits; a.o_steps = O.steps;
-    launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192);
+    launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192, /* chain */ true);
     if (d_score_out) *d_score_out = O.score;
     if (dev_out) *dev_out = O;
     if (dev_tasks) *dev_tasks = T;
