@@ -49,11 +49,12 @@ struct HipError { hipError_t e; const char* what; int line; };
 // (quicked_utils/src/mm_allocator.c:141-426) on this path.  No device-side
 // malloc, no per-pair hipMalloc.
 // ---------------------------------------------------------------------------
+static bool pool_trace() { static int v = -1; if (v < 0) v = getenv("QE_TRACE_POOL") ? 1 : 0; return v == 1; }
 struct DevicePool {
     // Chunks keep every pointer handed out during a run valid: when a run needs more than
     // the arena holds, another chunk is hipMalloc'ed.  The next run repeats the same request
     // sequence and fits the same chunks, so steady-state runs never allocate.
-    struct Chunk { uint8_t* base; size_t cap; };
+    struct Chunk { uint8_t* base; size_t cap; bool used; };     // used: something was carved from it since the last reset
     std::vector<Chunk> chunks;
     size_t cur = 0, top = 0, cap = 0;            // cap = total bytes over all chunks
     std::atomic<uint64_t> generation{0};         // bumped whenever handed-out pointers stop being valid (reset / release_all); read by fetching threads
@@ -64,14 +65,31 @@ struct DevicePool {
     // out of memory: the thread's other pools are asked to give theirs back (their runs are waited for first) and the
     // allocation is tried once more; set by Context
     static inline bool (*reclaim_fn)(DevicePool* keep) = nullptr;
+    // A request has to fit ONE chunk.  A pool whose chunks date from runs with smaller requests (another budget, other
+    // pairs) skips them and asks for a new one; when the device has no room for that next to them, the chunks this run has
+    // not touched go back first -- their slots stay in the list (empty), so marks taken earlier in the run stay valid.
+    bool drop_unused_chunks() {
+        bool any = false;
+        for (auto& c : chunks)
+            if (!c.used && c.base) {
+                if (pool_trace()) fprintf(stderr, "[qe-pool %p] drop unused chunk %.2f GB\n", (void*)this, c.cap / 1e9);
+                (void)hipFree(c.base); cap -= c.cap; c.base = nullptr; c.cap = 0; any = true;
+            }
+        return any;
+    }
     void add_chunk(size_t bytes) {
-        Chunk c; c.cap = bytes; c.base = nullptr;
+        Chunk c; c.cap = bytes; c.base = nullptr; c.used = false;
         hipError_t e = hipMalloc((void**)&c.base, bytes);
+        if (e == hipErrorOutOfMemory && drop_unused_chunks()) {
+            (void)hipGetLastError();
+            e = hipMalloc((void**)&c.base, bytes);
+        }
         if (e == hipErrorOutOfMemory && reclaim_fn && reclaim_fn(this)) {
             (void)hipGetLastError();
             e = hipMalloc((void**)&c.base, bytes);
         }
         if (e != hipSuccess) throw HipError{e, "hipMalloc((void**)&c.base, bytes)", __LINE__};
+        if (pool_trace()) fprintf(stderr, "[qe-pool %p] + chunk %.2f GB (pool %.2f GB, %zu chunks)\n", (void*)this, bytes / 1e9, (cap + bytes) / 1e9, chunks.size() + 1);
         chunks.push_back(c);
         cap += bytes;
     }
@@ -84,6 +102,8 @@ struct DevicePool {
             add_chunk(total);
         }
         std::lock_guard<std::mutex> lk(fetching);
+        chunks.erase(std::remove_if(chunks.begin(), chunks.end(), [](const Chunk& c) { return c.cap == 0; }), chunks.end());
+        for (auto& c : chunks) c.used = false;
         cur = 0; top = 0; ++generation;
     }
     struct Mark { size_t cur, top; };
@@ -97,6 +117,7 @@ struct DevicePool {
                 add_chunk(std::max(bytes + ((size_t)1 << 20), std::min(std::max(cap / 4, (size_t)1 << 26), (size_t)1 << 32)));
             ++cur; top = 0;
         }
+        chunks[cur].used = true;
         T* p = (T*)(chunks[cur].base + top);
         top += bytes;
         return p;
@@ -114,12 +135,14 @@ struct DevicePool {
     void mirror(const DevicePool& o) {
         for (size_t i = chunks.size(); i < o.chunks.size(); ++i) {
             size_t free_b = 0, total_b = 0;
+            if (o.chunks[i].cap == 0) continue;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * o.chunks[i].cap) return;
             add_chunk(o.chunks[i].cap);
         }
     }
     void release_all() {
         std::lock_guard<std::mutex> lk(fetching);
+        if (pool_trace() && cap) fprintf(stderr, "[qe-pool %p] release_all %.2f GB\n", (void*)this, cap / 1e9);
         for (auto& c : chunks) if (c.base) (void)hipFree(c.base);
         chunks.clear(); cap = 0; cur = 0; top = 0; ++generation;
     }
@@ -1788,9 +1811,10 @@ static void stash_results(quicked_batch& B, Context& C, PendingFetch& F) {
 }
 
 // sets of {streams, pools, planes} that rotate for a batch of n pairs: enough runs in flight for ~2048 waves (two per SIMD)
-static int rotation_depth(int64_t n) {
+static int rotation_depth(int64_t n, int floor_sets = 5) {
     const int64_t groups = std::max<int64_t>(1, (n + 63) / 64);
-    return (int)std::max<int64_t>(3, std::min<int64_t>(Context::NA, (2048 + groups - 1) / groups));
+    static const int min_env = env_int("QE_NP_MIN", 0);           // experiments
+    return (int)std::max<int64_t>(min_env > 0 ? min_env : floor_sets, std::min<int64_t>(Context::NA, (2048 + groups - 1) / groups));
 }
 
 static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
@@ -1839,16 +1863,31 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     const size_t min_set = need_fixed + (size_t)((double)need_mat * frac);
     // depth of the rotation: three sets for batches that fill the chip; a small batch (12.5 k pairs = 196 waves of ~11 ms)
     // needs more runs in flight to keep two waves on every SIMD.  A synchronous run is alone on the device anyway.
-    const int depth_wanted = fetch ? 3 : rotation_depth(B.n);
+    // (large batches: three sets for the one-kernel flows -- a 100 k-pair BandEd kernel nearly fills the chip, a fourth run only
+    // queues; five for QuickEd / Hirschberg, whose runs are chains of kernels of different shapes: 5.96 -> 6.24 M alignments/s)
+    static const int deep_env = env_int("QE_DEPTH_CHAIN", 5);
+    const int depth_wanted = fetch ? 3 : rotation_depth(B.n, serial ? 3 : std::max(3, deep_env));
     // what the A pools of this thread may hold together: the device's free memory plus what they hold already, less what
     // the process's other threads have planned for theirs (the ledger above)
     const size_t avail = ledger_plan(&C.ledger, free0, pools_held,
                                      (size_t)(1.05 * (double)std::min(depth_wanted, B.np_alloc) * (double)(need_fixed + need_mat)) + ((size_t)256 << 20));
     int na = 1;
-    for (int k = std::min(depth_wanted, B.np_alloc); k >= 1; --k) if ((double)min_set * k <= (double)avail) { na = k; break; }
+    // beyond three sets only with room to spare: the plan does not see the W pools, the batches' result arenas or what the
+    // caller allocates next
+    int sets_held = 0;                                    // sets whose pools exist already: rotating over them costs nothing
+    for (int q = 0; q < Context::NA; ++q) if (C.pool_a2[q].cap > ((size_t)1 << 28)) sets_held = q + 1;
+    for (int k = std::min(depth_wanted, B.np_alloc); k >= 1; --k)
+        if ((double)min_set * k <= ((k > 3 && k > sets_held) ? 0.6 : 1.0) * (double)avail) { na = k; break; }
     if (na_env > 0) na = std::min(std::min(na_env, (int)Context::NA), B.np_alloc);
     if (C.memory_tight) na = 1;
-    C.pool_budget = avail / (size_t)na;
+    // Sets outside the rotation keep their pools while this run's plan works without that memory -- the next batch may
+    // widen the rotation again, and freeing / re-allocating tens of GB per run costs more than any of this saves (a stream
+    // of batches whose plans alternated between 3 and 5 sets ran at 0.7 M alignments/s) -- and give them back when it does not
+    size_t idle_held = 0;
+    for (int q = na; q < Context::NA; ++q) idle_held += C.pool_a2[q].cap + C.pool_w2[q].cap;
+    // (a fill that does not fit its pool's budget is cut into sub-batches; that is cheaper than giving pools back too)
+    const bool keep_idle = idle_held > 0 && (avail > idle_held) && (avail - idle_held) / (size_t)na > need_fixed + ((size_t)4 << 30);
+    C.pool_budget = (keep_idle ? avail - idle_held : avail) / (size_t)na;
     C.last_na = na;
     C.in_flight = fetch ? 1 : na;
     B.np_used = na;
@@ -1857,28 +1896,13 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             if (C.stream_a2[q]) HIP_CHECK(hipStreamSynchronize(C.stream_a2[q]));
             C.pool_a2[q].release_all();
         }
-    for (int q = na; q < Context::NA; ++q) {            // a set that left the rotation gives its memory back
+    for (int q = na; q < Context::NA && !keep_idle; ++q) {      // a set that left the rotation gives its memory back
         if (C.stream_a2[q] && (C.pool_a2[q].cap > ((size_t)1 << 30) || C.pool_w2[q].cap > ((size_t)1 << 30))) HIP_CHECK(hipStreamSynchronize(C.stream_a2[q]));
         if (C.pool_a2[q].cap > ((size_t)1 << 30)) C.pool_a2[q].release_all();
         if (C.pool_w2[q].cap > ((size_t)1 << 30)) C.pool_w2[q].release_all();
     }
     C.ai = (C.ai + 1) % na;
     C.ensure_set(C.ai);
-    {
-        // A pool is a list of chunks and a request has to fit ONE of them.  When this run's largest request (a sub-batch of
-        // fill checkpoints) is larger than any chunk the pool has, and the pool could not keep its chunks AND get a new one
-        // inside its budget, it starts over with one allocation of the right size (reserve() in run_align) instead of
-        // running out of memory with tens of GB of too-small chunks in hand (100 k indel-heavy pairs: 157 GB of matrices)
-        DevicePool& P = C.pa();
-        // ... the run's largest request: everything but the matrices plus one of its equal fill sub-batches (run_align)
-        const size_t room = C.pool_budget > need_fixed + ((size_t)64 << 20) ? C.pool_budget - need_fixed : (size_t)64 << 20;
-        const size_t nsub = std::max<size_t>(1, (need_mat + room - 1) / room);
-        const size_t want = need_fixed + need_mat / nsub;
-        if (P.cap > ((size_t)1 << 30) && (double)P.largest_chunk() < 0.9 * (double)want && (double)P.cap + (double)want > (double)C.pool_budget) {
-            HIP_CHECK(hipStreamSynchronize(C.sa()));
-            P.release_all();
-        }
-    }
     const int par = B.parity = (B.parity + 1) % B.np_used;
     C.si = (C.si + 1) % (2 * na);
     {
@@ -2254,6 +2278,10 @@ static void batch_load(quicked_batch* B, Context& C, int64_t n,
     auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
     // plane sets: one per run of this batch that may be on the device at once (run_batch's rotation depth)
     B->np_alloc = rotation_depth(n);
+    {   // five plane sets only while they are small change (100 k pairs of 10 kb: 1.5 GB each); a 400 k-pair batch keeps three
+        const size_t set_bytes = 2 * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8));
+        if (B->np_alloc <= 5 && set_bytes * 5 > ((size_t)16 << 30)) B->np_alloc = 3;
+    }
     const size_t need = pad(p_bytes + 64) + pad(t_bytes + 64) + 4 * pad((size_t)n * 8) + 2 * pad((size_t)n * 4) +
                         2 * (size_t)B->np_alloc * (pad((B->pl_p_words + 8) * 8) + pad((B->pl_t_words + 8) * 8)) + (size_t)B->np_alloc * pad((size_t)n * 4) + 4096;
     batch_arena(B, need);

@@ -972,6 +972,12 @@ __global__ __launch_bounds__(512) void k_banded_coop(CoopArgs A) {
         }
         if (g == 0) { CF[0] = (int16_t)prolog; CL[0] = (int16_t)(nsl - 1); *KF = 1; *KL = 1; }
     }
+    // The lanes of a group hand band state, scores and band edges to each other through the group's workspace: a store by
+    // one lane, a load by another in a LATER instruction of the same wave -- ordered by the hardware (one wave's memory
+    // operations to an address reach the cache in program order), and kept in that order by the compiler through
+    // wavefront-scope fences between the passes of a step and around the decision rounds
+#define QE_COOP_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+    QE_COOP_FENCE();
     const int nfull = tfin >> 6, tail = tfin & 63;
     const int my_chunks = valid ? nfull + (tail ? 1 : 0) : 0;
     const int nsteps = wave_max(my_chunks > 0 ? my_chunks + G - 1 : 0);
@@ -1032,12 +1038,14 @@ __global__ __launch_bounds__(512) void k_banded_coop(CoopArgs A) {
                     slots_pass<4>(all4, i, r, Pv, Mv, Srd, Swr, NA, pp, p0, T0, T1, hinP, hinM, adv);
                     if (all4) { lastP = hinP; lastM = hinM; }
                     it += 3;
+                    QE_COOP_FENCE();
                     continue;
                 }
                 if (it + 1 < maxit && uniform(2)) {
                     slots_pass<2>(all2, i, r, Pv, Mv, Srd, Swr, NA, pp, p0, T0, T1, hinP, hinM, adv);
                     if (all2) { lastP = hinP; lastM = hinM; }
                     it += 1;
+                    QE_COOP_FENCE();
                     continue;
                 }
             }
@@ -1069,6 +1077,7 @@ __global__ __launch_bounds__(512) void k_banded_coop(CoopArgs A) {
                 hinP = houtP; hinM = houtM;
                 lastP = houtP; lastM = houtM;
             }
+            QE_COOP_FENCE();          // lane g+1 stored the slot lane g loads in a later iteration of this step
         }
         // ---- band-edge decisions of every chunk that completed its deciding slot in this step.
         // Two rounds: a decision made in round 1 can enable the lane above (one chunk ahead) in round 2.
@@ -1122,6 +1131,7 @@ __global__ __launch_bounds__(512) void k_banded_coop(CoopArgs A) {
                     }
                 }
             }
+            QE_COOP_FENCE();
             if (!__any(decided)) break;
         }
         // a wrong "no cut" guess before the end of the prologue put the carry chain on the wrong top slot
@@ -1130,6 +1140,7 @@ __global__ __launch_bounds__(512) void k_banded_coop(CoopArgs A) {
             if (kf > k && CF[(int64_t)k * NA] != fk) aborted = 1;
         }
     }
+    QE_COOP_FENCE();
     // group reductions: adv (sum), maxrow (max), aborted (or)
     for (int o = 1; o < G; o <<= 1) {
         adv += __shfl_xor(adv, o);
@@ -1164,6 +1175,7 @@ __global__ __launch_bounds__(512) void k_banded_coop(CoopArgs A) {
         A.o_abort[t] = aborted;
     }
 }
+#undef QE_COOP_FENCE
 
 // ===========================================================================
 // The cooperative form with the band state ON CHIP (k_banded_coop_lds).  Same systolic pipeline as k_banded_coop --

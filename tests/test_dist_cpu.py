@@ -29,7 +29,9 @@ WORKER = textwrap.dedent("""
             ref = [O.oracle_align(p, t, algo=2, only_score=True)[1] for p, t in whole.pairs()]
             out[scaling] = {'pairs': tp, 'cells': tc, 'checksum': ts, 'max_elapsed': te, 'extra': ext, 'total': total,
                             'ref_checksum': sum(ref), 'ref_cells': whole.cells()}
+    seen = shard.count_ranks(dist, torch, None)                 # bench.py's ranks_seen
     if rank == 0:
+        out['ranks_seen'] = seen
         print(json.dumps(out))
     dist.destroy_process_group()
 """) % (ROOT, ROOT)
@@ -45,6 +47,7 @@ def test_two_rank_sharding_and_reduction(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
+    assert r["ranks_seen"] == 2
     assert r["weak"]["pairs"] == 12 and r["weak"]["total"] == 12 and r["weak"]["max_elapsed"] == 2.0
     assert r["strong"]["pairs"] == 9 and r["strong"]["total"] == 9
     for k in ("weak", "strong"):
@@ -65,6 +68,28 @@ def test_shard_ranges_partition_the_dataset():
     assert shard.plan(100, 3, 8, "weak") == (300, 100, 800)
     assert shard.plan(100, 7, 8, "strong") == (87, 13, 100)
     assert shard.reduce_totals(None, None, None, 5, 6, 7, 0.5) == (5, 6, 7, 0.5, [])
+    assert shard.count_ranks(None, None, None) == 1
+
+
+def test_launcher_counts_gpus_without_touching_hip(tmp_path, monkeypatch):
+    """`bench.py --gpus N` without a launcher decides whether the node has N GPUs from sysfs (KFD topology / DRM render
+    nodes) -- the parent of the ranks must not initialise the GPU -- and honours HIP_VISIBLE_DEVICES"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert "torch" not in bench.visible_gpus.__code__.co_names
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 1024, 1024, 1024)):           # node 0 is the CPU
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\nmem_banks_count 1\n")
+    real_glob = bench.glob.glob
+    monkeypatch.setattr(bench.glob, "glob", lambda pat: real_glob(str(nodes / "*" / "properties")) if "kfd" in pat else [])
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2
 
 
 def test_bench_refuses_to_run_fewer_ranks_than_asked():
