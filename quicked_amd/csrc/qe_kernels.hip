@@ -2520,23 +2520,33 @@ template __global__ void k_format_segs<true>(SegFormatArgs);
 // ---------------------------------------------------------------------------
 struct SegCursor {
     const SegFormatArgs* A; int64_t s0, s1;      // segments of this alignment
-    int64_t seg; int k;                          // current segment; runs left in it (counting down) / 1 for a literal
+    int64_t seg; int k;                          // current segment; index of the current run in it (string order)
+    // what the current segment is, loaded once on entering it (a walk used to re-read the segment arrays, the leaf's run
+    // count and its group's layout for every run: nine dependent loads per element, and those were the kernel's time)
+    int n = 0, kind = 0, la = 0, lb = 0, nr = 0;
+    RunView rv;
     __device__ __forceinline__ int seg_runs(int64_t sg) const { return A->seg_kind[sg] == 1 ? (A->seg_b[sg] > 0 ? 1 : 0) : max(A->nruns[A->seg_a[sg]], 0); }
+    __device__ __forceinline__ void load() {
+        n = 0;
+        if (seg >= s1) return;
+        kind = A->seg_kind[seg]; la = A->seg_a[seg];
+        if (kind == 1) { lb = A->seg_b[seg]; n = lb > 0 ? 1 : 0; }
+        else { nr = max(A->nruns[la], 0); n = nr; rv = run_view(*A, la); }
+    }
     __device__ __forceinline__ void seek(int64_t idx) {      // position on run `idx` of the sequence (or past the end)
-        seg = s0;
-        while (seg < s1) { const int n = seg_runs(seg); if (idx < n) break; idx -= n; ++seg; }
+        seg = s0; load();
+        while (seg < s1 && idx >= n) { idx -= n; ++seg; load(); }
         k = (int)idx;
     }
     __device__ __forceinline__ bool valid() const { return seg < s1; }
     __device__ __forceinline__ void get(int& op, int& len) const {
-        if (A->seg_kind[seg] == 1) { op = A->seg_a[seg]; len = A->seg_b[seg]; return; }
-        const int t = A->seg_a[seg];
-        const u32 r = run_view(*A, t).at(A->nruns[t] - 1 - k);
+        if (kind == 1) { op = la; len = lb; return; }
+        const u32 r = rv.at(nr - 1 - k);
         op = (int)(r & 3); len = (int)(r >> 2);
     }
     __device__ __forceinline__ void next() {
         ++k;
-        while (seg < s1 && k >= seg_runs(seg)) { ++seg; k = 0; }
+        while (seg < s1 && k >= n) { ++seg; k = 0; load(); }
     }
 };
 
