@@ -61,6 +61,7 @@ INSTR_PER_BLOCK_COLUMN = 26.1
 ISSUE_CYCLES_PER_BLOCK_COLUMN = 61.0     # (2 766 x 2 + 570 x 4) / 128 block-columns of the unrolled 4-slot loop
 # reference anchors of BASELINE.md section 2 (one core of the survey container's 2.1 GHz Xeon, AVX2 build)
 CPU_ANCHOR_PER_CORE = {"banded_score": 2463.0, "quicked": 1680.0}
+FILL_BYTES_PER_BLOCK_COLUMN = 1.25       # 16 B of {Pv, Mv} per 16 columns + 16 B of carry words per 64 (qe_types.h: QE_CP_COLS)
 STRONG_SHARE_PAIRS = 12500       # 100 k pairs over 8 GPUs (BASELINE.json north_star)
 
 
@@ -516,13 +517,13 @@ class Bench:
             # B_so = plen + tlen + 4 per pair (ASCII in, int32 score out)
             kernel, alg_bytes, work_blocks = "k_banded<false> (BandEd score-only)", per_launch_bytes, int(counters[0])
         else:
-            # The fill stores a 16-byte checkpoint per (slot, 8 columns) and the 16-byte carry words per (slot, chunk):
-            # 2.25 B per block-column, and reads its inputs as bit-planes (3 bits per base); the traceback recomputes
-            # 16-column tiles from those.  SURVEY 8(d)'s figure (every column stored, 16 B per block-column and per
+            # The fill stores a 16-byte checkpoint per (slot, 16 columns) and the 16-byte carry words per (slot, chunk):
+            # 1.25 B per block-column (round 2: a checkpoint every 8 columns, 2.25 B), and reads its inputs as bit-planes
+            # (3 bits per base); the traceback recomputes 16-column tiles from those.  SURVEY 8(d)'s figure (every column stored, 16 B per block-column and per
             # traceback step) is what the reference's layout would move: kept as survey_equivalent_bytes, never divided
             # by the time of a kernel that does not move those bytes
             planes_in = 0.375 * float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64)).sum())
-            alg_bytes = planes_in + 2.25 * float(counters[1])
+            alg_bytes = planes_in + FILL_BYTES_PER_BLOCK_COLUMN * float(counters[1])
             extra["survey_equivalent_bytes"] = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
             kernel, work_blocks = "k_banded<true> (BandEd fill, checkpointed)", int(counters[1])
         traffic, traffic_src = None, None

@@ -733,7 +733,7 @@ static BandLayout band_layout(const TaskList& L, bool fill, bool want_runs, bool
         size_t bytes = (size_t)2 * (ns + 1) * 64 * 8 + (size_t)nr * 64 * 4 + (size_t)2 * nch * 64 * 2;
         B.ws_bytes += (bytes + 255) & ~(size_t)255;
         B.mat_off[g] = (int64_t)B.mat_u4;
-        if (fill) B.mat_u4 += (size_t)9 * nch * ns * 64;                   // checkpoints cp[8 nch][ns][64] + carry words hw[nch][ns][64]
+        if (fill) B.mat_u4 += (size_t)(QE_CPC + 1) * nch * ns * 64;        // checkpoints cp[QE_CPC nch][ns][64] + carry words hw[nch][ns][64]
         B.runs_off[g] = (int64_t)B.runs_u32;
         if (want_runs) B.runs_u32 += (size_t)cap * 64;
     }
@@ -1649,7 +1649,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
             est_t[t] = std::max(bound[t], quicked_task_estimate(B.est_bound, std::max(L.m[t], L.n[t])));
             const HGeom G = host_geometry(L.m[t], L.n[t], est_t[t]);
             if ((uint64_t)G.ebb * (uint64_t)L.n[t] * 16u > split) est_sized = false;
-            mat_bytes += (uint64_t)9 * (uint64_t)(L.n[t] / 64 + 3) * (uint64_t)G.ebb * 16u;     // band_layout's checkpoints
+            mat_bytes += (uint64_t)(QE_CPC + 1) * (uint64_t)(L.n[t] / 64 + 3) * (uint64_t)G.ebb * 16u;     // band_layout's checkpoints
         }
         // Buffers for the estimate are wider than buffers for the bounds (every group is as wide as the batch's widest
         // pair, plus the margin; 400 k pairs of 10 kb: 115 instead of 92 GB per run, cut into fill sub-batches by the
@@ -1852,7 +1852,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             const int m = B.p_len[(size_t)i], n = B.t_len[(size_t)i];
             if (m == 0 || n == 0) continue;
             const HGeom G = host_geometry(m, n, max_cutoff(p.bandwidth, m, n));
-            const uint64_t full = (uint64_t)9 * (uint64_t)(n / 64 + 3) * (uint64_t)G.ebb * 16;
+            const uint64_t full = (uint64_t)(QE_CPC + 1) * (uint64_t)(n / 64 + 3) * (uint64_t)G.ebb * 16;
             need_mat += (size_t)std::min<uint64_t>(full, (uint64_t)18 << 20);             // per pair; splits cap a leaf at 16 MiB of matrix
             need_fixed += (size_t)(p.algo == QUICKED ? std::min<int64_t>((int64_t)m + n + 2, (int64_t)2 * G.cutoff + 8) : (int64_t)m + n + 2) * 15 + 512;
         }

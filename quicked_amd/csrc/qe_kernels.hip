@@ -372,9 +372,9 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
                         *q = make_uint4(Plo, Phi, Mblo, Mbhi);
                     }
                 }
-                if (STORE == 2 && (c & 7) == 7) {
+                if (STORE == 2 && (c & (QE_CP_COLS - 1)) == QE_CP_COLS - 1) {
                     if (act) {
-                        uint4* q = st + (int64_t)(4 * half + (c >> 3) + 1) * st_stride;
+                        uint4* q = st + (int64_t)((QE_CPC / 2) * half + (c / QE_CP_COLS) + 1) * st_stride;
                         if (c == 31 && half == 1) q = st_last;
                         *q = make_uint4(Plo, Phi, Mlo, Mhi);
                     }
@@ -417,9 +417,9 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
                 }
             }
             if (STORE == 2 && j == 7) {
-                if (act) {
-                    // checkpoint of stored column 64k + 8 (grp + 1): st addresses checkpoint column 8k of this slot
-                    uint4* q = (grp == 7) ? st_last : st + (grp + 1) * st_stride;
+                if (act && ((8 * grp + 8) % QE_CP_COLS) == 0) {
+                    // checkpoint after chunk column 8 (grp + 1) - 1: st addresses the chunk's checkpoint 0 of this slot
+                    uint4* q = (grp == 7) ? st_last : st + ((8 * grp + 8) / QE_CP_COLS) * st_stride;
                     *q = make_uint4(Plo, Phi, Mlo, Mhi);     // {Pv, Mv} after this column
                 }
             }
@@ -463,8 +463,8 @@ __device__ __forceinline__ void run64_general(u64& P, u64& M, u64 a, u64 b, u64 
                 uint4* q = (c == 63) ? st_last : st + (int64_t)((c + 1) >> 3) * st_stride + ((c + 1) & 7);
                 *q = make_uint4(lo32(P), hi32(P), lo32(Min), hi32(Min));
             }
-            if (STORE == 2 && st_on && (c & 7) == 7) {
-                uint4* q = (c == 63) ? st_last : st + (int64_t)((c >> 3) + 1) * st_stride;
+            if (STORE == 2 && st_on && (c & (QE_CP_COLS - 1)) == QE_CP_COLS - 1) {
+                uint4* q = (c == 63) ? st_last : st + (int64_t)((c / QE_CP_COLS) + 1) * st_stride;
                 *q = make_uint4(lo32(P), hi32(P), lo32(M), hi32(M));
             }
         }
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
     // chunk that starts at / contains it), then  hw[nch][ns][64] = the carry-in words of every (chunk, slot)
     uint4* const cp = FILL ? A.mat + A.g_mat_off[g] + lane : nullptr;
     const int64_t cps = (int64_t)gns * 64;                         // uint4 units between checkpoint columns
-    uint4* const hw = FILL ? cp + (int64_t)8 * gnch * cps : nullptr;
+    uint4* const hw = FILL ? cp + (int64_t)QE_CPC * gnch * cps : nullptr;
 
     // bpm_reset_search (bpm_banded.c:180-197)
     for (int s = 0; s < gns; ++s) {
@@ -832,9 +832,9 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
             uint4* st = nullptr; uint4* st_last = nullptr;
             if (FILL) {
                 // the chunk's last column belongs to the NEXT chunk's slot numbering (bpm_banded.c:279-287)
-                st = cp + (int64_t)(8 * k) * cps + (int64_t)i * 64;
-                st_last = cp + (int64_t)(8 * k + 8) * cps + (int64_t)(i - 1) * 64;
-                if (i == 0) st_last = st + 8 * cps;                // slot -1 does not exist; dropped row, never read
+                st = cp + (int64_t)(QE_CPC * k) * cps + (int64_t)i * 64;
+                st_last = cp + (int64_t)(QE_CPC * k + QE_CPC) * cps + (int64_t)(i - 1) * 64;
+                if (i == 0) st_last = st + QE_CPC * cps;           // slot -1 does not exist; dropped row, never read
                 if (act) hw[((int64_t)k * gns + i) * 64] = make_uint4(lo32(hinP), hi32(hinP), lo32(hinM), hi32(hinM));
             }
             u64 houtP, houtM, sP, sM;
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
             else if (!cut_lo && pos_h < G.prolog) first--;
             Pv[(int64_t)last * 64] = QE_ONES;
             Mv[(int64_t)last * 64] = 0;
-            if (FILL) cp[(int64_t)(8 * k + 8) * cps + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+            if (FILL) cp[(int64_t)(QE_CPC * k + QE_CPC) * cps + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
             const int pos = last + pos_v;
             S[(int64_t)(pos + 1) * 64] = S[(int64_t)pos * 64] + 64;
             max_row_init = max(max_row_init, pos + 1);
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
         gcf = GW.cf + lane_t; gcl = GW.cl + lane_t;
         FS.cp = X.mat + X.g_mat_off[grp] + lane_t;
         FS.cps = (int64_t)gns * 64; FS.gns = gns;
-        FS.hw = FS.cp + (int64_t)8 * gnch * FS.cps;
+        FS.hw = FS.cp + (int64_t)QE_CPC * gnch * FS.cps;
     }
 
     // bpm_reset_search (bpm_banded.c:180-197): slots 0 .. nsl-1, block rows 0 .. nsl-1 (row r at ring index r + prolog)
@@ -1389,9 +1389,9 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
                     uint4* st = nullptr; uint4* st_last = nullptr;
                     if (FILL) {
                         // the chunk's last column belongs to the NEXT chunk's slot numbering (bpm_banded.c:279-287)
-                        st = FS.cp + (int64_t)(8 * k) * FS.cps + (int64_t)i * 64;
-                        st_last = FS.cp + (int64_t)(8 * k + 8) * FS.cps + (int64_t)(i - 1) * 64;
-                        if (i == 0) st_last = st + 8 * FS.cps;                 // slot -1 does not exist; dropped row, never read
+                        st = FS.cp + (int64_t)(QE_CPC * k) * FS.cps + (int64_t)i * 64;
+                        st_last = FS.cp + (int64_t)(QE_CPC * k + QE_CPC) * FS.cps + (int64_t)(i - 1) * 64;
+                        if (i == 0) st_last = st + QE_CPC * FS.cps;            // slot -1 does not exist; dropped row, never read
                         if (act) FS.hw[((int64_t)k * FS.gns + i) * 64] = make_uint4(lo32(hP), hi32(hP), lo32(hM), hi32(hM));
                     }
                     const bool slow = act && (ncols != 64 || hasN || lastblk);
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
                         const int fnew = CF[((k + 1) & crm) * NA];
                         Pv[l * NA] = QE_ONES;
                         Mv[l * NA] = 0;
-                        if (FILL) FS.cp[(int64_t)(8 * k + 8) * FS.cps + (int64_t)l * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+                        if (FILL) FS.cp[(int64_t)(QE_CPC * k + QE_CPC) * FS.cps + (int64_t)l * 64] = make_uint4(~0u, ~0u, 0u, 0u);
                         const int pos = l + pos_v;
                         Swr[R.at(l + 1) * NA] = Swr[R.at(l) * NA] + 64;
                         maxrow = max(maxrow, pos + 1);
@@ -1903,7 +1903,7 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     const int16_t* cl = W.cl + lane;
     const uint4* cp = A.mat + A.g_mat_off[g] + lane;
     const int64_t cps = (int64_t)gns * 64;
-    const uint4* hw = cp + (int64_t)8 * gnch * cps;
+    const uint4* hw = cp + (int64_t)QE_CPC * gnch * cps;
     RunSink R;
     {
         const int cap = valid ? A.g_runs_cap[g] : 0;
@@ -1918,7 +1918,7 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     u64 T0 = 0, T1 = 0, TN = 0, hinP = 0, hinM = 0, pa = 0, pb = 0, pn = 0;
     while (__any(valid && v >= 0 && h >= 0)) {
         const bool act = valid && v >= 0 && h >= 0;
-        constexpr int TW = 16;             // tile width: two checkpoint intervals per round halve the rounds' fixed cost
+        constexpr int TW = QE_CP_COLS;     // tile width = the fill's checkpoint interval
         const int q = h / TW, Rb = v >> 6, k = q / (64 / TW);
         // the tile: per column {Pv after, Mv before, Eq}, in registers (the loops over its columns are unrolled)
         u64 tP[TW], tM[TW], tE[TW];
@@ -1945,7 +1945,7 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
             const int pos_v = k - G.prolog, s = Rb - pos_v;
             computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
             if (computed) {
-                const uint4 c0 = cp[(int64_t)(q * (TW / 8)) * cps + (int64_t)s * 64];
+                const uint4 c0 = cp[(int64_t)(q * (TW / QE_CP_COLS)) * cps + (int64_t)s * 64];
                 if (s != cs) {
                     cs = s;
                     const uint4 w0 = hw[((int64_t)k * gns + s) * 64];

@@ -22,6 +22,10 @@ typedef uint64_t u64;
 typedef uint32_t u32;
 
 enum : u32 { FLAG_HAS_N = 1u, FLAG_NONCANON = 2u };
+// The BandEd fill leaves a checkpoint {Pv, Mv} every QE_CP_COLS columns of every band slot, QE_CPC per 64-column chunk: the
+// width of the tile the traceback rebuilds in one round (k_traceback's TW).  Round 2 stored one every 8 columns and the
+// traceback read every other one.
+enum : int { QE_CP_COLS = 16, QE_CPC = 64 / QE_CP_COLS };
 enum : u32 { OP_M = 0, OP_X = 1, OP_I = 2, OP_D = 3 };
 
 struct PairView {
@@ -71,7 +75,8 @@ struct BandedArgs {
     TaskView T;
     // per-group workspace: Pv[(ns+1)][64] u64 | Mv[(ns+1)][64] u64 | S[nrows][64] i32 | cf[nch][64] i16 | cl[nch][64] i16
     uint8_t* ws;  const int64_t* g_ws_off;  const int32_t* g_nslots;  const int32_t* g_nrows;  const int32_t* g_nch;
-    // fill only: {Pv,Mv} of every column, [(col * g_nslots + slot)][64] x 16 B
+    // fill only: checkpoints {Pv,Mv} every QE_CP_COLS columns [(QE_CPC chunk + j) * g_nslots + slot][64] x 16 B, then the carry-in
+    // words of every (chunk, slot) [(chunk * g_nslots + slot)][64] x 16 B
     uint4* mat;  const int64_t* g_mat_off;
     // outputs per task
     int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;  int32_t* o_maxrow;
