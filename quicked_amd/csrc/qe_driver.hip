@@ -1158,7 +1158,10 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
     a.W = W; a.O = O_; a.hew_threshold = hew_threshold; a.score_only = score_only ? 1 : 0; a.sse = sse ? 1 : 0; a.reversed = reversed ? 1 : 0;
     a.ws = D.ws; a.g_ws_off = D.ws_off; a.runs = D.runs; a.g_runs_off = D.runs_off; a.g_runs_cap = D.runs_cap;
     a.o_score = O.score; a.o_hew = O.hew; a.o_nruns = O.nruns; a.o_nops = O.nops; a.o_edits = O.edits; a.o_steps = O.steps;
-    launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192, /* chain */ true);
+    // (2, 1) windows stay on chip (k_windowed); every other shape runs the checkpointed general path
+    a.cp_path = env_int("QE_WINDOWED_CP", 1);
+    if (W == 2 && O_ == 1) launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192, /* chain */ true);
+    else launch_groups(C, k_windowed_cp, a, (size_t)ng, 8, 8192, /* chain */ true);
     if (d_score_out) *d_score_out = O.score;
     if (dev_out) *dev_out = O;
     if (dev_tasks) *dev_tasks = T;

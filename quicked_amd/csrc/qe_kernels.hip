@@ -236,6 +236,69 @@ __device__ __forceinline__ void run64_skew(u64 (&P)[K], u64 (&M)[K], const u64 (
     houtM = mk64(oMlo, oMhi);
 }
 
+// run64_skew for a WindowEd window (general W): every slot also leaves what the in-window traceback needs to recompute
+// any 8-column tile of it -- {Pv, Mv} BEFORE every 8th column (st[group * gstride + k * 64], where keep[k]) and the 64
+// carry-outs of EVERY slot (oP / oM[k]: slot k + 1's carry-in word).  Same arithmetic per cell as run64_fast.
+template <int K>
+__device__ __forceinline__ void run64_skew_cp(u64 (&P)[K], u64 (&M)[K], const u64 (&a)[K], const u64 (&b)[K],
+                                              u64 T0, u64 T1, u64 hinP, u64 hinM, u64 (&oP)[K], u64 (&oM)[K],
+                                              const bool (&keep)[K], uint4* st, int64_t gstride) {
+    u32 alo[K], ahi[K], blo[K], bhi[K], Plo[K], Phi[K], Mlo[K], Mhi[K];
+    u32 oPlo[K], oPhi[K], oMlo[K], oMhi[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        alo[k] = lo32(a[k]); ahi[k] = hi32(a[k]); blo[k] = lo32(b[k]); bhi[k] = hi32(b[k]);
+        Plo[k] = lo32(P[k]); Phi[k] = hi32(P[k]); Mlo[k] = lo32(M[k]); Mhi[k] = hi32(M[k]);
+        oPlo[k] = 0; oPhi[k] = 0; oMlo[k] = 0; oMhi[k] = 0;
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const u32 t0 = half ? hi32(T0) : lo32(T0), t1 = half ? hi32(T1) : lo32(T1);
+        const u32 hp = half ? hi32(hinP) : lo32(hinP), hm = half ? hi32(hinM) : lo32(hinM);
+        u32 gP[K], gM[K], cP[K], cM[K];
+        u32 m0[32], m1[32];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { gP[k] = 0; gM[k] = 0; cP[k] = 0; cM[k] = 0; }
+#pragma unroll
+        for (int s = 0; s < 32 + K - 1; ++s) {
+            if (s < 32) {
+                m0[s] = (u32)__builtin_amdgcn_sbfe((int)t0, s, 1);
+                m1[s] = (u32)__builtin_amdgcn_sbfe((int)t1, s, 1);
+            }
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {           // lower slots first: they consume the carries of the previous step
+                const int c = s - k;
+                if (c < 0 || c >= 32) continue;
+                if ((c & 7) == 0) {
+                    if (keep[k]) st[(int64_t)(4 * half + (c >> 3)) * gstride + k * 64] = make_uint4(Plo[k], Phi[k], Mlo[k], Mhi[k]);
+                }
+                const u32 elo = bitop3<0x90>(~(alo[k] ^ m0[c]), blo[k], m1[c]), ehi = bitop3<0x90>(~(ahi[k] ^ m0[c]), bhi[k], m1[c]);
+                u32 inP, inM;
+                if (k == 0) { inP = __builtin_amdgcn_ubfe(hp, c, 1); inM = __builtin_amdgcn_ubfe(hm, c, 1); }
+                else { inP = cP[k]; inM = cM[k]; }
+                u32 phhi, mhhi;
+                block_step_core(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, phhi, mhhi);
+                gP[k] = __builtin_amdgcn_alignbit(gP[k], phhi, 31);
+                gM[k] = __builtin_amdgcn_alignbit(gM[k], mhhi, 31);
+                // the slot below takes its carry-in from the collected word: that keeps the collection on the critical path
+                // (left to itself the scheduler parks all 32 x 2 deltas of every slot in registers until the end of the pass)
+                if (k + 1 < K) { cP[k + 1] = gP[k] & 1u; cM[k + 1] = gM[k] & 1u; }
+                else asm("" : "+v"(Plo[k]) : "v"(gP[k]), "v"(gM[k]));      // the lowest slot's collection: pinned to its own next step
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const u32 rP = __builtin_bitreverse32(gP[k]), rM = __builtin_bitreverse32(gM[k]);
+            if (half) { oPhi[k] = rP; oMhi[k] = rM; } else { oPlo[k] = rP; oMlo[k] = rM; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        P[k] = mk64(Plo[k], Phi[k]); M[k] = mk64(Mlo[k], Mhi[k]);
+        oP[k] = mk64(oPlo[k], oPhi[k]); oM[k] = mk64(oMlo[k], oMhi[k]);
+    }
+}
+
 // K adjacent band slots i .. i+K-1 of one chunk in one pass, with the loads, score bookkeeping and the in-place band
 // shift around it.  scores[] of the lowest row from its own bottom-row deltas, as always; of every row above from
 //   sum_c hout_k(c) = sum_c hin_(k+1)(c) = sum_c hout_(k+1)(c) - (v_(k+1) after - v_(k+1) before),
@@ -2040,12 +2103,79 @@ __device__ __forceinline__ void window_walk_tile(const u64 (&tP)[8], const u64 (
     }
 }
 
+// The same walk for any window shape (bpm_windowed.c:448-561): the tile is 8 columns of window block row Rb; the lane
+// leaves it to the left, upwards (the next round recomputes the tile above) or by leaving the traceback region
+// (v < v_ov or h < h_ov: the window is done).  v / h are alignment coordinates, v0 / h0 the window's origin.
+template <bool SCORE_ONLY>
+__device__ __forceinline__ void window_walk_tile_g(const u64 (&tP)[8], const u64 (&tM)[8], const u64 (&tE)[8], bool inw, int Rb,
+                                                   int v0, int h0, int v_ov, int h_ov, int& v, int& h, int& wscore, RunSink& R) {
+    bool in_tile = inw;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const bool mine = in_tile && ((h - h0) & 7) == j;
+        const int bit = (v - v0) & 63;
+        const u64 del = SCORE_ONLY ? tP[j] : (tP[j] & ~tE[j]);       // cells that take a deletion
+        int r = min(__clzll((long long)~(del << (63 - bit))), bit + 1);
+        r = min(r, v - v_ov + 1);                                      // the region ends at row v_ov
+        if (!mine) r = 0;
+        const bool up = r == bit + 1;                                 // the run left the block row
+        const bool go = mine && !up && (v - r) >= v_ov;
+        const int b1 = (bit - r) & 63;
+        const u32 mb = (u32)((tM[j] >> b1) & 1), eq = (u32)((tE[j] >> b1) & 1);
+        u32 isI;
+        if (SCORE_ONLY) {
+            isI = mb;
+            wscore += r + (go ? (int)(isI | (eq ^ 1u)) : 0);
+        } else {
+            isI = mb & (eq ^ 1u);
+            R.emit((int)OP_D, r, r > 0);
+            R.emit(eq ? (int)OP_M : (isI ? (int)OP_I : (int)OP_X), 1, go);
+        }
+        v -= r + ((go && !isI) ? 1 : 0);
+        h -= go ? 1 : 0;
+        in_tile = in_tile && !(mine && up) && v >= v_ov && h >= h_ov && ((v - v0) >> 6) == Rb;
+    }
+}
+
+// K vertically adjacent blocks i .. i + K - 1 of a window over the 64 columns of chunk j (window_cp_* state: see the
+// checkpointed general path of k_windowed)
+template <int K>
+__device__ __forceinline__ void window_cp_pass(int i, int j, int W, int steps_v, int blk_min, bool chunk_on, bool chunk_keep,
+                                               u64* Pv, u64* Mv, const u64* pp, int prow0, u64 pinit, u64 T0, u64 T1,
+                                               u64& hinP, u64& hinM, uint4* cpb, uint4* hwb) {
+    u64 P[K], M[K], a[K], b[K], oP[K], oM[K];
+    bool act[K], keep[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        act[k] = chunk_on && (i + k) < steps_v;
+        keep[k] = act[k] && chunk_keep && (i + k) >= blk_min;
+        P[k] = pinit; M[k] = 0; a[k] = 0; b[k] = 0;
+        if (act[k]) {
+            u64 nn;
+            if (j > 0) { P[k] = Pv[(int64_t)(i + k) * 64]; M[k] = Mv[(int64_t)(i + k) * 64]; }
+            load_planes(pp, prow0 + 64 * (i + k), a[k], b[k], nn);
+        }
+    }
+    run64_skew_cp<K>(P, M, a, b, T0, T1, hinP, hinM, oP, oM, keep, cpb + ((int64_t)(8 * j) * W + i) * 64, (int64_t)W * 64);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (act[k]) { Pv[(int64_t)(i + k) * 64] = P[k]; Mv[(int64_t)(i + k) * 64] = M[k]; }
+        if (keep[k]) {
+            const u64 iP = (k == 0) ? hinP : oP[k > 0 ? k - 1 : 0], iM = (k == 0) ? hinM : oM[k > 0 ? k - 1 : 0];
+            hwb[((int64_t)j * W + (i + k)) * 64] = make_uint4(lo32(iP), hi32(iP), lo32(iM), hi32(iM));
+        }
+    }
+    hinP = oP[K - 1]; hinM = oM[K - 1];
+}
+
 // ===========================================================================
 // WindowEd chain (bpm_windowed.c:563-628): windows of W x W blocks anchored at
 // the current traceback position, filled (202-280; SSE semantics 283-445 when
 // sse && W == 2), traced back inside the non-overlap region (448-561).
 // ===========================================================================
-__global__ __launch_bounds__(512) void k_windowed(WindowArgs A) {
+// CP: the general path (any W, O; partial windows) keeps checkpoints + carry words instead of every column's history
+template <bool CP>
+__device__ __forceinline__ void windowed_body(const WindowArgs& A) {
     uint4 (*wck)[64] = (uint4 (*)[64])(qe_dyn_lds + QE_WAVE_IN_BLOCK() * 512);    // [8][64] per wave
     const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
     if (g * 64 >= A.T.ntasks) return;
@@ -2079,6 +2209,89 @@ __global__ __launch_bounds__(512) void k_windowed(WindowArgs A) {
     u32 steps = 0;
 
     const bool w2 = W == 2 && O == 1 && !__any(valid && (hasN || E.raw));
+    const bool cp_ok = CP && !sse && A.cp_path != 0 && !__any(valid && (hasN || E.raw));
+    // the checkpointed general path has a loop of its own: nothing of the paths below (match test, history pointers)
+    // stays live across its windows
+    if (CP && cp_ok) {
+        while (__any(valid && pos_v >= 0 && pos_h >= 0)) {
+            const bool on = valid && pos_v >= 0 && pos_h >= 0;
+            // ---- general window, checkpointed: the fill runs K = 3 blocks per skewed pass and leaves {Pv, Mv} before
+            // every 8th column of every block the traceback may visit plus the carry-in words per (chunk, block) -- 2.25
+            // instead of 16 B per block-column -- and the traceback recomputes the 8-column tile it is in (same
+            // arithmetic, same bits as the stored history of the path below; tested against it: QE_WINDOWED_CP = 0)
+            const int v_fi = pos_v, h_fi = pos_h;
+            const int v0 = max(v_fi - 64 * W + 1, 0), h0 = max(h_fi - 64 * W + 1, 0);
+            const int steps_v = on ? (v_fi - v0) / 64 + 1 : 0;
+            const int ncols_total = on ? h_fi - h0 + 1 : 0;
+            const u64 ph_first = (v0 == 0) ? QE_ONES : 0;
+            const u64 pinit = (h0 == 0) ? QE_ONES : 0;
+            const int v_ov = max(v_fi - 64 * (W - O) + 1, 0), h_ov = max(h_fi - 64 * (W - O) + 1, 0);
+            const int blk_min = (v_ov - v0) >> 6;
+            const int nchunk = wave_max((ncols_total + 63) >> 6), nblk = wave_max(steps_v);
+            uint4* const cpb = (uint4*)(wsb + (int64_t)2 * W * 64 * 8) + lane;     // [8 x chunks][W][64]: {Pv, Mv} before column 8 q
+            uint4* const hwb = cpb + (int64_t)8 * W * W * 64;                      // [chunks][W][64]: carry-in words
+            for (int j = 0; j < nchunk; ++j) {
+                const bool chunk_on = ncols_total > 64 * j;
+                const bool chunk_keep = 64 * j + 63 >= h_ov - h0;
+                u64 T0 = 0, T1 = 0, TN = 0;
+                if (chunk_on) load_planes(tp, t0 + h0 + 64 * j, T0, T1, TN);
+                u64 hinP = ph_first, hinM = 0;
+                for (int i = 0; i < nblk;) {
+                    const int rem = nblk - i;
+                    if (rem >= 3) { window_cp_pass<3>(i, j, W, steps_v, blk_min, chunk_on, chunk_keep, Pv, Mv, pp, p0 + v0, pinit, T0, T1, hinP, hinM, cpb, hwb); i += 3; }
+                    else if (rem == 2) { window_cp_pass<2>(i, j, W, steps_v, blk_min, chunk_on, chunk_keep, Pv, Mv, pp, p0 + v0, pinit, T0, T1, hinP, hinM, cpb, hwb); i += 2; }
+                    else { window_cp_pass<1>(i, j, W, steps_v, blk_min, chunk_on, chunk_keep, Pv, Mv, pp, p0 + v0, pinit, T0, T1, hinP, hinM, cpb, hwb); i += 1; }
+                }
+            }
+            if (on) steps += (u32)steps_v * (u32)ncols_total;
+            // in-window traceback (bpm_windowed.c:448-561) over recomputed tiles
+            int v = pos_v, h = pos_h, wscore = 0;
+            int cRb = -1, cj = -1;
+            u64 pa = 0, pb = 0, X0 = 0, X1 = 0, hP = 0, hM = 0;
+            while (__any(on && v >= v_ov && h >= h_ov)) {
+                const bool inw = on && v >= v_ov && h >= h_ov;
+                const int Rb = inw ? (v - v0) >> 6 : 0, q = inw ? (h - h0) >> 3 : 0, j = q >> 3;
+                u32 Plo = 0, Phi = 0, Mlo = 0, Mhi = 0;
+                if (inw) {
+                    u64 nn;
+                    const bool nr = Rb != cRb, nj = j != cj;
+                    if (nr) load_planes(pp, p0 + v0 + 64 * Rb, pa, pb, nn);
+                    if (nj) load_planes(tp, t0 + h0 + 64 * j, X0, X1, nn);
+                    if (nr | nj) {
+                        const uint4 w0 = hwb[((int64_t)j * W + Rb) * 64];
+                        hP = mk64(w0.x, w0.y); hM = mk64(w0.z, w0.w);
+                    }
+                    cRb = Rb; cj = j;
+                    const uint4 c0 = cpb[((int64_t)q * W + Rb) * 64];
+                    Plo = c0.x; Phi = c0.y; Mlo = c0.z; Mhi = c0.w;
+                }
+                const int sh = 8 * (q & 7);
+                const u32 alo = lo32(pa), ahi = hi32(pa), blo = lo32(pb), bhi = hi32(pb);
+                const u32 t0s = (u32)(X0 >> sh), t1s = (u32)(X1 >> sh);
+                const u32 hp = (u32)(hP >> sh), hm = (u32)(hM >> sh);
+                u32 aP = 0, aM = 0;
+                u64 tP[8], tM[8], tE[8];
+    #pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0s, c, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1s, c, 1);
+                    const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1), ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
+                    tE[c] = mk64(elo, ehi);
+                    tM[c] = mk64(Mlo, Mhi);
+                    block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, __builtin_amdgcn_ubfe(hp, c, 1), __builtin_amdgcn_ubfe(hm, c, 1), aP, aM);
+                    tP[c] = mk64(Plo, Phi);
+                }
+                if (A.score_only) window_walk_tile_g<true>(tP, tM, tE, inw, Rb, v0, h0, v_ov, h_ov, v, h, wscore, R);
+                else window_walk_tile_g<false>(tP, tM, tE, inw, Rb, v0, h0, v_ov, h_ov, v, h, wscore, R);
+            }
+            if (on) {
+                if (A.score_only) {
+                    if (wscore > (W - O) * 64 * A.hew_threshold / 100) ++hew;
+                    score += wscore;
+                }
+                pos_h = h; pos_v = v;
+            }
+        }
+    } else
     while (__any(valid && pos_v >= 0 && pos_h >= 0)) {
         const bool on = valid && pos_v >= 0 && pos_h >= 0;
         if (w2 && !__any(on && (pos_v < 127 || pos_h < 127))) {
@@ -2272,6 +2485,8 @@ __global__ __launch_bounds__(512) void k_windowed(WindowArgs A) {
         A.o_steps[t] = steps;
     }
 }
+__global__ __launch_bounds__(512) void k_windowed(WindowArgs A) { windowed_body<false>(A); }
+__global__ __launch_bounds__(512) void k_windowed_cp(WindowArgs A) { windowed_body<true>(A); }
 
 // ===========================================================================
 // QuickEd without a host round trip after stage 1 (the common case: no pair leaves stage 1).  k_stage1_decide applies

@@ -126,7 +126,9 @@ struct WindowArgs {
     PairView P;
     TaskView T;
     int32_t W, O, hew_threshold, score_only, sse, reversed;
-    // per-group workspace: Pv[W][64] u64 | Mv[W][64] u64 ; history {Pv,Mv}[(64W+3)*W][64] x 16 B
+    int32_t cp_path;       // k_windowed_cp: checkpoints + carry words instead of the full history (0: the history path, for tests)
+    // per-group workspace: Pv[W][64] u64 | Mv[W][64] u64 ; history {Pv,Mv}[(64W+3)*W][64] x 16 B (k_windowed_cp uses a prefix:
+    // checkpoints [8W][W][64] + carry words [W][W][64], 16 B each)
     uint8_t* ws;  const int64_t* g_ws_off;
     u32* runs;  const int64_t* g_runs_off;  const int32_t* g_runs_cap;
     int32_t* o_score;  int32_t* o_hew;  int32_t* o_nruns;  int32_t* o_nops;  int32_t* o_edits;  u32* o_steps;
