@@ -131,6 +131,16 @@ __device__ __forceinline__ void block_step_fused(u32 elo, u32 ehi, u32& Plo, u32
     accM = __builtin_amdgcn_alignbit(accM, mhhi, 31);
 }
 
+// block_step_fused for a pass that keeps the collected carries: the collection is tied to the block's own next step (an
+// empty asm that "needs" accP / accM to hand Plo on).  Left to itself the scheduler parks the 2 x 32 deltas of an unrolled
+// pass in registers and runs the v_alignbit chain at the end of it (k_windowed_cp's K = 3 pass: 256 VGPRs + 772 B of
+// scratch without the tie, 211 VGPRs with it).
+__device__ __forceinline__ void block_step_collect(u32 elo, u32 ehi, u32& Plo, u32& Phi, u32& Mlo, u32& Mhi,
+                                                   u32 PHin, u32 MHin, u32& accP, u32& accM) {
+    block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, accP, accM);
+    asm("" : "+v"(Plo) : "v"(accP), "v"(accM));
+}
+
 // ---------------------------------------------------------------------------
 // K vertically adjacent blocks (band slots i .. i+K-1) over 64 columns in one pass: the text masks are extracted
 // once per column, every block below the first takes its carry-in straight from the horizontal deltas of the block
@@ -168,7 +178,7 @@ __device__ __forceinline__ void run64_multi(u64 (&P)[K], u64 (&M)[K], const u64 
                     block_step_core(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], cP, cM, phhi, mhhi);
                     cP = phhi >> 31; cM = mhhi >> 31;
                 } else {
-                    block_step_fused(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], cP, cM, gP, gM);
+                    block_step_collect(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], cP, cM, gP, gM);
                 }
             }
         }
@@ -223,7 +233,7 @@ __device__ __forceinline__ void run64_skew(u64 (&P)[K], u64 (&M)[K], const u64 (
                     block_step_core(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, phhi, mhhi);
                     cP[k + 1] = phhi >> 31; cM[k + 1] = mhhi >> 31;
                 } else {
-                    block_step_fused(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, gP, gM);
+                    block_step_collect(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, gP, gM);
                 }
             }
         }
@@ -426,7 +436,7 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
                 const u32 MHin = __builtin_amdgcn_ubfe(hm, c, 1);
                 const u32 Mblo = Mlo, Mbhi = Mhi;
                 if (STORE == 3 && (c & 7) == 0) st[(4 * half + (c >> 3)) * st_stride] = make_uint4(Plo, Phi, Mlo, Mhi);
-                block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, gP, gM);
+                block_step_collect(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, gP, gM);
                 if (STORE == 1) {
                     if (act) {
                         // chunk column 32 half + c is stored column (64k) + 32 half + c + 1
@@ -470,7 +480,7 @@ __device__ __forceinline__ void run64_fast(u64& P, u64& M, u64 a, u64 b, u64 T0,
             const u32 PHin = __builtin_amdgcn_ubfe(hp, j, 1);
             const u32 MHin = __builtin_amdgcn_ubfe(hm, j, 1);
             const u32 Mblo = Mlo, Mbhi = Mhi;
-            block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, gP, gM);
+            block_step_collect(elo, ehi, Plo, Phi, Mlo, Mhi, PHin, MHin, gP, gM);
             if (STORE == 1) {
                 if (act) {
                     // chunk column c = 8 grp + j is stored column (64k) + c + 1
