@@ -1461,6 +1461,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
                 a.only_if = O.hew + o;
             }
         }
+        a.fill_multi = env_int("QE_FILL_MULTI", 1);
         launch_groups(C, k_banded<true>, a, (size_t)(g1 - g0), 8, 0);     // everything, or what the cooperative fill flagged
         if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
         TraceArgs tr;

@@ -309,6 +309,79 @@ __device__ __forceinline__ void run64_skew_cp(u64 (&P)[K], u64 (&M)[K], const u6
     }
 }
 
+// run64_skew for the BandEd fill: K adjacent band slots of one chunk, each lane taking part with the slots inside ITS band
+// (tight QuickEd bands start and end at a different slot in every lane).  top[k] = 1 where slot k is the lane's topmost
+// band slot: its carry-in is (1, 0) whatever the slot above computed (bpm_banded.c:236-238).  Every slot leaves its
+// checkpoints {Pv, Mv} AFTER columns 15, 31, 47, 63 (run64_fast's STORE == 2 layout: st + k * 64 is slot k's checkpoint 0
+// of this chunk, column 63 goes to the next chunk's numbering at stl) and collects its 64 carry-outs (oP / oM[k]).
+template <int K>
+__device__ __forceinline__ void run64_skew_fill(u64 (&P)[K], u64 (&M)[K], const u64 (&a)[K], const u64 (&b)[K],
+                                                u64 T0, u64 T1, u64 hinP, u64 hinM, u64 (&oP)[K], u64 (&oM)[K],
+                                                const bool (&act)[K], const u32 (&top)[K],
+                                                uint4* st, int64_t st_stride, uint4* stl_first, uint4* stl) {
+    static_assert(QE_CP_COLS == 16, "checkpoint columns are literal here");
+    u32 alo[K], ahi[K], blo[K], bhi[K], Plo[K], Phi[K], Mlo[K], Mhi[K];
+    u32 oPlo[K], oPhi[K], oMlo[K], oMhi[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        alo[k] = lo32(a[k]); ahi[k] = hi32(a[k]); blo[k] = lo32(b[k]); bhi[k] = hi32(b[k]);
+        Plo[k] = lo32(P[k]); Phi[k] = hi32(P[k]); Mlo[k] = lo32(M[k]); Mhi[k] = hi32(M[k]);
+        oPlo[k] = 0; oPhi[k] = 0; oMlo[k] = 0; oMhi[k] = 0;
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const u32 t0 = half ? hi32(T0) : lo32(T0), t1 = half ? hi32(T1) : lo32(T1);
+        const u32 hp = half ? hi32(hinP) : lo32(hinP), hm = half ? hi32(hinM) : lo32(hinM);
+        u32 gP[K], gM[K];
+        u32 m0[32], m1[32];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { gP[k] = 0; gM[k] = 0; }
+#pragma unroll
+        for (int s = 0; s < 32 + K - 1; ++s) {
+            if (s < 32) {
+                m0[s] = (u32)__builtin_amdgcn_sbfe((int)t0, s, 1);
+                m1[s] = (u32)__builtin_amdgcn_sbfe((int)t1, s, 1);
+            }
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {           // lower slots first: they consume the carries of the previous step
+                const int c = s - k;
+                if (c < 0 || c >= 32) continue;
+                const u32 elo = bitop3<0x90>(~(alo[k] ^ m0[c]), blo[k], m1[c]), ehi = bitop3<0x90>(~(ahi[k] ^ m0[c]), bhi[k], m1[c]);
+                u32 inP, inM;
+                if (k == 0) { inP = __builtin_amdgcn_ubfe(hp, c, 1); inM = __builtin_amdgcn_ubfe(hm, c, 1); }
+                else {
+                    // the carry the slot above collected one step ago (taking it from the collected word keeps the
+                    // collection on the critical path, see block_step_collect) -- or (1, 0) at the top of the lane's band
+                    inP = (gP[k - 1] & 1u) | top[k];
+                    inM = (gM[k - 1] & 1u) & ~top[k];
+                }
+                u32 phhi, mhhi;
+                block_step_core(elo, ehi, Plo[k], Phi[k], Mlo[k], Mhi[k], inP, inM, phhi, mhhi);
+                gP[k] = __builtin_amdgcn_alignbit(gP[k], phhi, 31);
+                gM[k] = __builtin_amdgcn_alignbit(gM[k], mhhi, 31);
+                if (k + 1 == K) asm("" : "+v"(Plo[k]) : "v"(gP[k]), "v"(gM[k]));
+                if ((c & 15) == 15) {
+                    if (act[k]) {
+                        uint4* q = st + (int64_t)(2 * half + (c >> 4) + 1) * st_stride + k * 64;
+                        if (c == 31 && half == 1) q = (k == 0) ? stl_first : stl + k * 64;
+                        *q = make_uint4(Plo[k], Phi[k], Mlo[k], Mhi[k]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const u32 rP = __builtin_bitreverse32(gP[k]), rM = __builtin_bitreverse32(gM[k]);
+            if (half) { oPhi[k] = rP; oMhi[k] = rM; } else { oPlo[k] = rP; oMlo[k] = rM; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        P[k] = mk64(Plo[k], Phi[k]); M[k] = mk64(Mlo[k], Mhi[k]);
+        oP[k] = mk64(oPlo[k], oPhi[k]); oM[k] = mk64(oMlo[k], oMhi[k]);
+    }
+}
+
 // K adjacent band slots i .. i+K-1 of one chunk in one pass, with the loads, score bookkeeping and the in-place band
 // shift around it.  scores[] of the lowest row from its own bottom-row deltas, as always; of every row above from
 //   sum_c hout_k(c) = sum_c hin_(k+1)(c) = sum_c hout_(k+1)(c) - (v_(k+1) after - v_(k+1) before),
@@ -785,6 +858,9 @@ __device__ __forceinline__ GroupWs group_ws(uint8_t* ws, int64_t off, int ns, in
 // BandEd: score-only (FILL = false, bpm_banded.c:791-964) or full-matrix fill
 // (FILL = true, bpm_banded.c:199-316).  One lane per task.
 // ===========================================================================
+#ifndef QE_FILL_K
+#define QE_FILL_K 3          // slots per skewed pass of the fill (1: single-slot passes only)
+#endif
 template <bool FILL>
 __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
     const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
@@ -882,6 +958,51 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
                 if (i == first) { hinP = QE_ONES; hinM = 0; }
                 if (i + 3 <= i1 && uniform(4)) { slots_pass<4>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); i += 3; continue; }
                 if (i + 1 <= i1 && uniform(2)) { slots_pass<2>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); i += 1; continue; }
+            }
+            if (FILL && QE_FILL_K > 1 && A.fill_multi && i + QE_FILL_K - 1 <= i1) {
+                // K slots in one skewed pass, every lane with the slots inside its own band, unless a lane needs the
+                // general form for one of them (partial chunk, N, the pattern's last block row)
+                constexpr int K = QE_FILL_K;
+                bool actk[K], slowk = false;
+                u32 topk[K];
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    actk[q] = on && (i + q) >= first && (i + q) <= rhi;
+                    topk[q] = ((i + q) == first) ? 1u : 0u;
+                    slowk |= actk[q] && (ncols != 64 || hasN || (i + q + pos_v) == nw - 1);
+                }
+                if (!__any(slowk)) {
+                    u64 P[K], M[K], a[K], b[K], oP[K], oM[K];
+                    int sc[K];
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        P[q] = 0; M[q] = 0; a[q] = 0; b[q] = 0; sc[q] = 0;
+                        if (actk[q]) {
+                            u64 nn;
+                            P[q] = Pv[(int64_t)(i + q) * 64]; M[q] = Mv[(int64_t)(i + q) * 64]; sc[q] = S[(int64_t)(r + q) * 64];
+                            load_planes(pp, p0 + 64 * (r + q), a[q], b[q], nn);
+                        }
+                    }
+                    if (i == first) { hinP = QE_ONES; hinM = 0; }
+                    uint4* const st0 = cp + (int64_t)(QE_CPC * k) * cps + (int64_t)i * 64;
+                    uint4* const stl0 = cp + (int64_t)(QE_CPC * k + QE_CPC) * cps + (int64_t)(i - 1) * 64;
+                    run64_skew_fill<K>(P, M, a, b, T0, T1, hinP, hinM, oP, oM, actk, topk, st0, cps,
+                                       (i == 0) ? st0 + QE_CPC * cps : stl0, stl0);
+#pragma unroll
+                    for (int q = 0; q < K; ++q) {
+                        if (actk[q]) {
+                            const u64 iP = (q == 0) ? hinP : (topk[q] ? QE_ONES : oP[q > 0 ? q - 1 : 0]);
+                            const u64 iM = (q == 0) ? hinM : (topk[q] ? (u64)0 : oM[q > 0 ? q - 1 : 0]);
+                            hw[((int64_t)k * gns + (i + q)) * 64] = make_uint4(lo32(iP), hi32(iP), lo32(iM), hi32(iM));
+                            S[(int64_t)(r + q) * 64] = sc[q] + __popcll(oP[q]) - __popcll(oM[q]);
+                            Pv[(int64_t)(i + q - 1) * 64] = P[q]; Mv[(int64_t)(i + q - 1) * 64] = M[q];   // band shift (bpm_banded.c:903-909)
+                            adv += 64u;
+                        }
+                    }
+                    hinP = oP[K - 1]; hinM = oM[K - 1];
+                    i += K - 1;
+                    continue;
+                }
             }
             u64 P = 0, M = 0, a = 0, b = 0, nn = 0;
             int sc = 0;

@@ -81,6 +81,7 @@ struct BandedArgs {
     // outputs per task
     int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;  int32_t* o_maxrow;
     const int32_t* only_if;  // run only tasks whose flag is non-zero (fallback pass after k_banded_coop); may be null
+    int32_t fill_multi = 1;  // fill: K-slot skewed passes where no lane needs the general form (0: single-slot passes only; tests)
 };
 
 // BandEd score-only, G lanes per alignment (cooperative form of k_banded<false>)

@@ -259,3 +259,14 @@ def test_wire_pack_pool_equals_the_per_sequence_serializer():
             assert L.quicked_wire_pack_isa(best + 1) == -1 or best == 2
     finally:
         L.quicked_wire_pack_isa(-1)
+
+
+def test_readme_numbers_are_generated_from_the_committed_bench_line():
+    """README.md's measured paragraph is tools/readme_numbers.py's output for the newest profiles/<tag>_bench_line.json"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("readme_numbers", os.path.join(ROOT, "tools", "readme_numbers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(ROOT, "README.md")).read()
+    held = text[text.index(mod.BEGIN) + len(mod.BEGIN):text.index(mod.END)].strip()
+    assert held == mod.paragraph().strip()

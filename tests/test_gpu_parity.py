@@ -980,6 +980,9 @@ def test_planner_cuts_a_large_cigar_batch_before_it_runs_out_of_memory():
     p = capi.make_params(algo=capi.QUICKED)
     assert rb.run(p, sync=True) >= 0                      # sizes the pools
     first = capi.pool_stats()
+    for _ in range(3):                                    # every set of the rotation allocates its pools once (tens of GB each)
+        assert rb.run(p, sync=False) >= 0
+    rb.sync()
     t0 = time.perf_counter()
     steps = 4
     for _ in range(steps):
