@@ -67,7 +67,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = build.HIP_LIB
+    path = os.environ.get("QUICKED_HIP_LIB") or build.HIP_LIB       # A/B runs of two builds: QUICKED_HIP_LIB=<other .so>
     if not os.path.exists(path):
         try:
             build.build_hip()            # hipcc --offload-arch=gfx950, in-tree

@@ -269,6 +269,67 @@ def test_randomised_shapes_and_params(seed, monkeypatch):
                 assert out[i][2] == ecg, (kw, i)
 
 
+@pytest.mark.parametrize("cp", ["1", "0"])
+def test_windowed_checkpoint_and_history_paths(cp, monkeypatch):
+    """WindowEd for any window shape but (2, 1): k_windowed_cp keeps checkpoints + carry words and recomputes the tile the
+    in-window traceback is in (QE_WINDOWED_CP = 1, the default); QE_WINDOWED_CP = 0 is the path that stores every column's
+    history (what waves with N / non-ACGT input still use).  Both equal the oracle: scores, HEW-driven QuickEd stages,
+    CIGARs, work counters -- on ragged lengths, partial windows and pairs with large indels."""
+    monkeypatch.setenv("QE_WINDOWED_CP", cp)
+    rng = np.random.default_rng(77)
+    pairs = []
+    for i in range(80):
+        L = int(rng.choice([1, 63, 64, 65, 300, 575, 576, 577, 1200, 3000, 5000]))
+        e = float(rng.choice([0.0, 0.03, 0.1, 0.25]))
+        b = datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=7700 + i,
+                             indels_num=int(rng.integers(0, 3)) if L >= 3000 else 0, indels_len=200)
+        p, t = next(b.pairs())
+        if rng.random() < 0.2:
+            t = t[: max(1, len(t) - int(rng.integers(0, max(1, len(t) // 3))))]
+        pairs.append((p, t))
+    for kw in (dict(algo=1, only_score=True), dict(algo=1), dict(algo=1, window_size=3, overlap_size=1),
+               dict(algo=1, only_score=True, window_size=4, overlap_size=2), dict(algo=1, window_size=7, overlap_size=5),
+               dict(algo=1, window_size=2, overlap_size=1, force_scalar=True),
+               dict(algo=0, hew_threshold=(10, 10), hew_percentage=(1, 1)), dict(algo=0, window_size=5, overlap_size=2, hew_threshold=(10, 40), hew_percentage=(1, 15))):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            if k in ("hew_threshold", "hew_percentage"):
+                getattr(al._params, k)[0], getattr(al._params, k)[1] = v
+            else:
+                setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            assert out[i] == O.oracle_align(p, t, **kw), (cp, kw, i, len(p), len(t))
+    # work counters: block-advances of the windows (SURVEY 8d) are the oracle's whichever path ran
+    b = datagen.generate(64, 3000, 0.1, seed=78, indels_num=1, indels_len=300)
+    _, _, _, cnt = gpu_batch(b, algo=1, only_score=True)
+    assert cnt[2] == sum(O.oracle_align(p, t, trace=True, algo=1, only_score=True)[3]["window_block_steps"] for p, t in b.pairs())
+
+
+@pytest.mark.parametrize("multi", ["1", "0"])
+def test_fill_multi_slot_passes_forced(multi, monkeypatch):
+    """the BandEd fill runs K = 3 band slots per skewed pass, every lane masked to its own band (QE_FILL_MULTI = 1, default),
+    or one slot per pass (0): same checkpoints, same CIGARs -- tight QuickEd bands, loose BandEd bands, Hirschberg leaves"""
+    monkeypatch.setenv("QE_FILL_MULTI", multi)
+    rng = np.random.default_rng(5)
+    pairs = []
+    for i in range(72):
+        L = int(rng.choice([64, 200, 1000, 2500, 6000]))
+        e = float(rng.choice([0.01, 0.05, 0.2]))
+        p, t = next(datagen.generate(1, L, e, seed=9100 + i, indels_num=int(rng.integers(0, 2)) if L >= 2500 else 0, indels_len=150).pairs())
+        pairs.append((p, t))
+    for kw in (dict(algo=0), dict(algo=2, bandwidth=30), dict(algo=3, bandwidth=30), dict(algo=2, bandwidth=60)):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            want = O.oracle_align(p, t, **kw)
+            in_domain = kw["algo"] == 0 or O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+            if in_domain:
+                assert out[i] == want, (multi, kw, i, len(p), len(t))
+
+
 @pytest.mark.parametrize("lds", ["1", "0"])
 def test_cooperative_kernel_forced(lds, monkeypatch):
     """QE_COOP_G forces the G-lanes-per-alignment kernel (and its fallback pass) on shapes the host would not pick it for:

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects what profiles/ holds for one milestone (run on the GPU box through gpurun):
-#   tools/collect_profiles.sh <tag> [banded_score quicked cfg4 share]   -> gpurun_out/<tag>/...
+#   tools/collect_profiles.sh <tag> [banded_score quicked cfg4 share indels]   -> gpurun_out/<tag>/...
 # kernel-trace/stats and every PMC counter set in separate passes, as MI355X_MICROARCH.md prescribes.
 tag=${1:-r03_x}; shift
-wls=${@:-banded_score quicked cfg4 share}
+wls=${@:-banded_score quicked cfg4 share indels}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; mkdir -p $out
 one="--no-workloads --no-strong --indel-pairs 0 --no-cpu-baseline --no-e2e"
@@ -13,6 +13,7 @@ for wl in $wls; do
     quicked)      args="--workload quicked"; steps=10;;
     cfg4)         args="--workload quicked --pairs 10000 --length 100000 --error 0.1"; steps=8;;
     share)        args="--workload banded_score --pairs 12500"; steps=40;;
+    indels)       args="--workload quicked --pairs 20000 --indels-num 4 --indels-len 800"; steps=6;;
   esac
   common="$args $one"
   # overlapped (as benchmarked) and solo (--sync-each-step: a kernel's own duration) kernel stats
@@ -51,3 +52,6 @@ python3 tools/summarise_pmc.py $out $tag $wls > /dev/null
 # the full line (what the driver runs) and config 4 on its own
 ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_line.json 2> $out/bench_line.err ) 2> $out/${tag}_bench_line_time.txt
 python3 bench.py --workload quicked --pairs 10000 --length 100000 --error 0.1 --steps 20 --warmup 3 --no-workloads --no-strong --indel-pairs 0 > $out/${tag}_bench_cfg4.json 2> $out/bench_cfg4.err
+python3 tools/single_call_latency.py > $out/${tag}_single_call_latency.txt 2> $out/single_call_latency.err
+# WindowEd on its own (the WINDOWED algorithm's default shape is 9 / 1: k_windowed_cp), history path against checkpoint path
+for cp in 0 1; do echo "== QE_WINDOWED_CP=$cp"; QE_WINDOWED_CP=$cp python3 tools/probe_windowed_n.py 2>&1; done > $out/${tag}_windowed_rates.txt

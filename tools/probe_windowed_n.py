@@ -5,11 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from quicked_amd import capi, datagen
 cases = [("WindowEd(9,1) score-only", capi.make_params(algo=capi.WINDOWED, window_size=9, overlap_size=1, only_score=True)),
-         ("WindowEd(2,1) score-only", capi.make_params(algo=capi.WINDOWED, window_size=2, overlap_size=1, only_score=True)),
-         ("BandEd 40 % score-only", capi.make_params(algo=capi.BANDED, bandwidth=40, only_score=True)),
-         ("BandEd 40 % + CIGAR", capi.make_params(algo=capi.BANDED, bandwidth=40))]
-for n in (500, 5000, 15000, 100000):
-    b = datagen.generate(n, 10000, 0.05, seed=0x51CED, indels_num=4, indels_len=800)
+         ("WindowEd(9,1) + CIGAR", capi.make_params(algo=capi.WINDOWED, window_size=9, overlap_size=1)),
+         ("WindowEd(4,2) score-only", capi.make_params(algo=capi.WINDOWED, window_size=4, overlap_size=2, only_score=True)),
+         ("WindowEd(2,1) score-only", capi.make_params(algo=capi.WINDOWED, window_size=2, overlap_size=1, only_score=True))]
+for n, indels in ((500, 4), (15000, 4), (100000, 4), (100000, 0)):
+    b = datagen.generate(n, 10000, 0.05, seed=0x51CED, indels_num=indels, indels_len=800 if indels else 0)
     rb = capi.ResidentBatch(b)
     for name, p in cases:
         for _ in range(2):
@@ -18,5 +18,5 @@ for n in (500, 5000, 15000, 100000):
         for _ in range(3):
             rb.run(p, sync=True)
         dt = (time.perf_counter() - t0) / 3
-        print(f"n {n:6d} {name:26s}: {dt * 1e3:8.2f} ms per run  {n / dt / 1e6:7.3f} M pairs/s", flush=True)
+        print(f"n {n:6d} indels {indels} {name:26s}: {dt * 1e3:8.2f} ms per run  {n / dt / 1e6:7.3f} M pairs/s", flush=True)
     rb.close()
