@@ -1,5 +1,6 @@
 """One-off soak (not collected by pytest): long reads through every CIGAR path -- QuickEd (device-side stage 1 where no
-pair may split, classic where one may), Hirschberg with real splits, BandEd -- against the oracle.
+pair may split, classic where one may; forced through stages 2 / 3 by HEW parameters), Hirschberg with real splits, BandEd,
+WindowEd (9 / 1 and 5 / 2 windows: k_windowed_cp) -- against the oracle.
    python tests/soak_long.py FIRST_SEED COUNT"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -25,14 +26,15 @@ for seed in range(first, first + count):
         pairs.append((p, t))
     batch = datagen.PairBatch(*_pools(pairs))
     rb = capi.ResidentBatch(batch)
-    for algo, kwp in ((0, {}), (0, {}), (3, dict(bandwidth=20)), (2, dict(bandwidth=20))):
+    for algo, kwp in ((0, {}), (0, {}), (3, dict(bandwidth=20)), (2, dict(bandwidth=20)), (1, {}), (1, dict(window_size=5, overlap_size=2)),
+                      (0, dict(hew_threshold=(10, 10), hew_percentage=(1, 1)))):
         prm = capi.make_params(algo=algo, **kwp)
         assert rb.run(prm, sync=False) >= 0
         assert rb.fetch() >= 0
         s, st = rb.scores(); cg = rb.cigars()
         for i, (p, t) in enumerate(pairs):
             est, esc, ecg = O.oracle_align(p, t, algo=algo, **kwp)
-            dist_ok = algo == 0 or O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * 20 // 100
+            dist_ok = algo in (0, 1) or O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * 20 // 100
             if not dist_ok or est < 0:
                 continue
             if (st[i], s[i], cg[i]) != (est, esc, ecg):
