@@ -10,7 +10,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <csignal>
 #include <cstdio>
+#include <execinfo.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -262,11 +265,15 @@ struct Context {
     // quicked_free, quicked.c:371-375; here the pools belong to the thread, not to an aligner).  The Context object itself
     // stays: a run this thread queued may still be fetched by another thread, whose PendingFetch points at one of the
     // pools -- it finds the pool empty and a newer generation, and fails cleanly.
-    void retire() {
+    void leave_ledger() {
         if (registered) {
             std::lock_guard<std::mutex> lk(g_ledger_mu);
             g_ledger.erase(std::remove(g_ledger.begin(), g_ledger.end(), &ledger), g_ledger.end());
+            registered = false;
         }
+    }
+    void retire() {
+        leave_ledger();
         if (!stream) return;
         if (hipSetDevice(device) != hipSuccess) return;
         (void)hipStreamSynchronize(stream_w);
@@ -382,12 +389,36 @@ static thread_local int tl_device = 0;
 // one Context per (host thread, device): a thread that alternates between devices keeps both (streams, pools and
 // pinned stages of the device it left stay where they are)
 static const std::thread::id g_main_thread = std::this_thread::get_id();
+// Contexts of host threads that have ended.  A thread_local destructor must not call into HIP -- the runtime's own per-thread
+// state may have been destroyed before ours (destruction order follows construction order, which depends on which HIP
+// call of the thread came first): hipEventDestroy from ~ContextList crashed once in a few runs.  So an ending thread only
+// takes its contexts out of the ledger and parks them here; the next live thread that creates a context, plans a run,
+// trims its pools or runs out of memory releases what they hold (reap_orphans).
+static std::mutex g_orphans_mu;
+static std::vector<Context*> g_orphans;
 struct ContextList {
     std::vector<Context*> v;
-    // worker threads release their contexts when they end; the main thread's live until the process does (tearing HIP
-    // objects down during static destruction races the runtime's own shutdown)
-    ~ContextList() { if (std::this_thread::get_id() != g_main_thread) for (Context* c : v) c->retire(); }
+    // the main thread's contexts live until the process ends (tearing HIP objects down during static destruction races the
+    // runtime's own shutdown)
+    ~ContextList() {
+        if (std::this_thread::get_id() == g_main_thread) return;
+        for (Context* c : v) c->leave_ledger();
+        std::lock_guard<std::mutex> lk(g_orphans_mu);
+        g_orphans.insert(g_orphans.end(), v.begin(), v.end());
+    }
 };
+static void reap_orphans() {
+    std::vector<Context*> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_orphans_mu);
+        if (g_orphans.empty()) return;
+        dead.swap(g_orphans);
+    }
+    int dev = 0;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess;
+    for (Context* c : dead) c->retire();          // waits for whatever the thread left queued, then frees pools / stages / streams
+    if (have_dev) (void)hipSetDevice(dev);
+}
 static thread_local ContextList tl_ctx_list;
 #define tl_ctx_all tl_ctx_list.v
 static thread_local int tl_bound_device = -1;
@@ -396,6 +427,7 @@ static Context& ctx() {
         tl_ctx = nullptr;
         for (Context* c : tl_ctx_all) if (c->device == tl_device) tl_ctx = c;
         if (!tl_ctx) {
+            reap_orphans();
             tl_ctx = new Context();   // lives for the thread; one per device it uses
             tl_ctx->device = tl_device;
             tl_ctx_all.push_back(tl_ctx);
@@ -413,6 +445,11 @@ static bool reclaim_pools(DevicePool* keep) {
     Context* C = tl_ctx;
     if (!C) return false;
     bool freed = false;
+    {   // what ended threads left behind comes first
+        bool any;
+        { std::lock_guard<std::mutex> lk(g_orphans_mu); any = !g_orphans.empty(); }
+        if (any) { reap_orphans(); if (C->device != tl_bound_device) (void)hipSetDevice(C->device); freed = true; }
+    }
     C->memory_tight = true;
     ++g_reclaim_events;
     for (int q = 0; q < Context::NA; ++q) {
@@ -439,6 +476,19 @@ static bool reclaim_pools(DevicePool* keep) {
 // initialises (the first HIP call of the process), so this has to happen at load time; a process that has already
 // initialised HIP keeps what it has.
 __attribute__((constructor)) static void qe_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// QE_SEGV_TRACE=1: a native backtrace (module + offset: addr2line -e libquicked_hip.so) on SIGSEGV / SIGABRT, then the default action
+static void qe_segv_trace(int sig) {
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "[quicked_hip] fatal signal, native backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+__attribute__((constructor)) static void qe_install_segv_trace() {
+    if (getenv("QE_SEGV_TRACE")) { signal(SIGSEGV, qe_segv_trace); signal(SIGABRT, qe_segv_trace); }
+}
 
 // one in-stream copy as a kernel (see k_copy_multi); both buffers are padded to 16 bytes (pool / arena / stage allocations are)
 static void copy_kernel(void* dst, const void* src, size_t bytes, hipStream_t s) {
@@ -1839,6 +1889,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // small batches (single quicked_align calls) plan with the last reading: the query costs tens of microseconds
     size_t free0 = C.seen_free, total0 = C.seen_total;
     if (C.seen_total == 0 || B.arena_bytes > ((size_t)64 << 20)) {
+        reap_orphans();                     // pools of host threads that have ended count as free
         HIP_CHECK(hipMemGetInfo(&free0, &total0));
         C.seen_free = free0; C.seen_total = total0;
     }
@@ -2625,6 +2676,7 @@ QE_API quicked_status_t quicked_pool_stats(int64_t stats_out[8]) {
 QE_API quicked_status_t quicked_pool_trim(void) {
     try {
         Context& C = ctx();
+        reap_orphans();
         C.sync_all();
         for (auto& q : C.pool_a2) q.release_all();
         for (auto& q : C.pool_w2) q.release_all();

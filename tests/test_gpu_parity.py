@@ -1086,6 +1086,9 @@ def test_two_host_threads_plan_hbm_together():
             p = capi.make_params(algo=capi.QUICKED)
             gate.wait()
             assert rb.run(p, sync=True) >= 0
+            for _ in range(3):                        # every set of the rotation allocates its pools once (tens of GB each, seconds)
+                assert rb.run(p, sync=False) >= 0
+            rb.sync()
             gate.wait()
             t0 = time.perf_counter()
             for _ in range(4):
@@ -1122,9 +1125,49 @@ def test_two_host_threads_plan_hbm_together():
     assert sum(stats[k]["pool_budget"] * stats[k]["sets"] for k in ("a", "b")) < total, stats
     assert sum(stats[k]["pool_bytes"] for k in ("a", "b")) < total, stats
     assert all(stats[k]["sets"] >= 2 and stats[k]["sub_batches"] <= 2 for k in ("a", "b")), stats      # nobody was starved
-    assert min(rates.values()) > 0.4e6, rates           # a ledger test, not a benchmark: four runs each, pools growing, two threads on one chip
+    assert min(rates.values()) > 0.4e6, rates           # a ledger test, not a benchmark: four runs each, two threads on one chip
     # the threads trimmed their pools before they ended: the device is free again
     import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free_b, total_b = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0
+    assert free_b.value > 0.8 * total_b.value, (free_b.value, total_b.value)
+
+
+def test_threads_that_end_without_trimming_leave_no_pools_behind():
+    """A host thread that just ends (no quicked_pool_trim, batches closed) must neither crash in its thread-local
+    destructors -- HIP may not be called from there -- nor keep its device pools: its contexts are parked, and the next live
+    thread that plans a run / trims / creates a context releases them.  Ten rounds of short-lived threads with pools of a
+    few GB each, then the device is free again."""
+    import ctypes as C
+    import threading
+    assert capi.pool_trim() == 0
+    batch = datagen.generate(count=20000, length=4000, error=0.05, seed=321)
+    want = [O.oracle_align(p, t, algo=0) for p, t in list(batch.pairs())[:8]]
+    errors = []
+
+    def worker():
+        try:
+            rb = capi.ResidentBatch(batch)
+            prm = capi.make_params(algo=capi.QUICKED)
+            for _ in range(2):
+                assert rb.run(prm, sync=False) >= 0
+            assert rb.fetch() >= 0
+            s, st = rb.scores(); cg = rb.cigars()
+            for i in range(8):
+                assert (st[i], s[i], cg[i]) == want[i]
+            rb.close()                            # ... and the thread ends with its pools allocated
+        except Exception as e:                    # noqa: BLE001
+            errors.append(e)
+
+    for _ in range(10):
+        ths = [threading.Thread(target=worker) for _ in range(3)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+    assert not errors, errors
+    assert capi.pool_trim() == 0                  # a live thread: releases what the ended ones held
     hip = C.CDLL("libamdhip64.so")
     free_b, total_b = C.c_size_t(), C.c_size_t()
     assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0
