@@ -480,7 +480,7 @@ __device__ __forceinline__ void run64_win2(u64& P0, u64& M0, u64& P1, u64& M1, u
 //           column 64k + c + 1 = st + ((c+1) >> 3) * tstride + ((c+1) & 7); c == 63 goes to st_last
 // ---------------------------------------------------------------------------
 // STORE: 0 nothing | 1 every column's {Pv after, Mv before} (tiled; WindowEd history) |
-//        2 a checkpoint {Pv, Mv after} every 8th column (BandEd fill: the traceback recomputes the 8 columns between)
+//        2 a checkpoint {Pv, Mv after} every QE_CP_COLS-th column (BandEd fill: the traceback recomputes the columns between)
 //        3 the same checkpoints, taken before each group of 8 columns, to st[grp * st_stride] (on-chip WindowEd windows)
 // WIDE: two rolled passes over 32 literal columns instead of eight over 8.  The text / carry words are then
 // addressed as 32-bit halves with literal bit positions: the per-group 64-bit shifts (6 SIMD cycles each, seven per
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
     u64* const Pv = W.Pv + 64 + lane;        // slot s lives at Pv[s * 64]; slot -1 is addressable
     u64* const Mv = W.Mv + 64 + lane;
     int32_t* const S = W.S + lane;           // scores[] indexed by absolute block row (bpm_banded.c:180-197)
-    // fill: per group  cp[8 nch][ns][64] = {Pv, Mv} after every 8th stored column (in the slot numbering of the
+    // fill: per group  cp[QE_CPC nch][ns][64] = {Pv, Mv} after every QE_CP_COLS-th stored column (in the slot numbering of the
     // chunk that starts at / contains it), then  hw[nch][ns][64] = the carry-in words of every (chunk, slot)
     uint4* const cp = FILL ? A.mat + A.g_mat_off[g] + lane : nullptr;
     const int64_t cps = (int64_t)gns * 64;                         // uint4 units between checkpoint columns
@@ -2033,7 +2033,7 @@ struct EqTest {
     }
 };
 
-// One traceback round over an 8-column tile held in registers: tP/tM/tE[j] = {Pv after, Mv before, Eq}
+// One traceback round over a TW-column tile held in registers: tP/tM/tE[j] = {Pv after, Mv before, Eq}
 // of tile column j for the lane's block row Rb.  Priority D -> I -> M/X (bpm_banded.c:994-1020).  A lane
 // enters at column h & 7, and leaves to the left (h < 8 q), upwards (v leaves block Rb) or at an edge.
 template <bool RAW, int TW>
@@ -2066,11 +2066,11 @@ __device__ __forceinline__ void walk_tile(const u64 (&tP)[TW], const u64 (&tM)[T
 
 // ===========================================================================
 // BandEd traceback (bpm_banded.c:967-1036): priority D -> I -> M/X.  One lane per task walks its own
-// path.  The fill left a checkpoint {Pv, Mv} every 8th column and the carry-in words of every
-// (chunk, slot); a round of this kernel recomputes, for every lane at once, the 8 columns of the
-// (column tile, block row) its path is in -- 8 block steps from the checkpoint, the same arithmetic as
-// the fill, so the same bits -- into LDS as {Pv after, Mv before} per column, then lets every lane walk
-// while it stays inside that tile.  HBM sees 2 B per block-column instead of 16.
+// path.  The fill left a checkpoint {Pv, Mv} every QE_CP_COLS (16) columns and the carry-in words of every
+// (chunk, slot); a round of this kernel recomputes, for every lane at once, the 16 columns of the
+// (column tile, block row) its path is in -- 16 block steps from the checkpoint, the same arithmetic as
+// the fill, so the same bits -- into registers as {Pv after, Mv before, Eq} per column, then lets every lane walk
+// while it stays inside that tile.  HBM sees 1.25 B per block-column instead of 16.
 // Cells the fill did not compute read as P = 0, M = 0 (see oracle header).
 // ===========================================================================
 __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
