@@ -1,6 +1,12 @@
 #!/bin/bash
-# the two soaks of tests/ (not collected by pytest) on the GPU box: gpurun --timeout 1500 -- bash tools/soak.sh <tag> <first seed> <fuzz seeds> <long seeds>
+# the two soaks of tests/ (not collected by pytest) on the GPU box, default kernel forms and forced ones:
+#   gpurun --timeout 2700 -- bash tools/soak.sh <tag> <first seed> <fuzz seeds> <long seeds>
 out=gpurun_out/$1; mkdir -p $out
 timeout 1200 python tests/soak_fuzz.py $2 $3 > $out/soak_fuzz.txt 2>&1
 timeout 1200 python tests/soak_long.py $2 $4 > $out/soak_long.txt 2>&1
-grep -h "MISMATCH\|^soak" $out/soak_fuzz.txt $out/soak_long.txt | tail -20
+n=$(( $3 / 3 )); m=$(( $4 / 3 ))
+QE_WINDOWED_CP=0 QE_FILL_MULTI=0 timeout 900 python tests/soak_fuzz.py $(( $2 + 1000 )) $n > $out/soak_fuzz_history_single.txt 2>&1
+QE_COOP_G=1 QE_QUICKED_EST=40 timeout 900 python tests/soak_fuzz.py $(( $2 + 2000 )) $n > $out/soak_fuzz_onelane_smallest.txt 2>&1
+QE_FILL_MULTI=0 timeout 900 python tests/soak_long.py $(( $2 + 1000 )) $m > $out/soak_long_single.txt 2>&1
+QE_WINDOWED_CP=0 timeout 900 python tests/soak_long.py $(( $2 + 2000 )) $m > $out/soak_long_history.txt 2>&1
+grep -h "MISMATCH\|^soak" $out/soak_*.txt | tail -30
