@@ -10,7 +10,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <csignal>
+#include <deque>
 #include <cstdio>
 #include <execinfo.h>
 #include <unistd.h>
@@ -470,6 +472,17 @@ static bool reclaim_pools(DevicePool* keep) {
     return freed;
 }
 
+// hipMalloc outside the pools (a batch's arena, its result arena): out of memory gets the same second chance as a pool's
+// chunk -- this thread's other pools (all but `keep`) and what ended threads left behind go back first
+static void device_malloc_retry(void** p, size_t bytes, DevicePool* keep, const char* what, int line) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        if (DevicePool::reclaim_fn && DevicePool::reclaim_fn(keep)) e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) throw HipError{e, what, line};
+}
+
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that
 // share a queue serialise.  A thread's runs rotate over up to NA sets of two streams, so that small batches can have many
 // runs on the device at once: ask for more queues unless the user has chosen a value.  Read by the runtime when it
@@ -612,6 +625,13 @@ struct quicked_batch {
     int64_t *d_wire_p_off = nullptr, *d_wire_t_off = nullptr;
     bool unpack_pending = false, unpack_event_set = false;
     hipEvent_t ev_unpacked = nullptr;
+    // Early finish (qe::finisher_*): a QuickEd run queued with sync == 0 may leave pairs that need the host-driven stages;
+    // a library thread aligns them as soon as the run is over instead of the caller's quicked_batch_fetch.  fin_mu is held
+    // by whoever works on the batch object: an API call of the caller, or the finisher.
+    std::mutex fin_mu;
+    std::condition_variable fin_cv;
+    int fin_jobs = 0;                             // finisher jobs submitted for this batch and not retired yet (under fin_mu)
+    quicked_status_t fin_status = QUICKED_OK;     // what an early finish of the current results returned
 
     ~quicked_batch() {
         if (arena) (void)hipFree(arena);
@@ -1582,6 +1602,17 @@ static void scatter_scores(quicked_batch& B, const TaskList& L, const std::vecto
 // QuickEd sizes the align step's buffers for an ESTIMATE of the bounds that is the same whether the bounds are known on
 // the host (classic flow) or still being computed on the device (fast flow): the pools then see one request sequence.
 static int quicked_estimate(int top) { return top + top / 8 + 16; }
+// ... of a run's bounds: the largest plus a margin -- unless a few pairs lie far above the rest (reads with large indels among
+// ordinary ones: bound 3 700 against 480), where sizing EVERY pair's buffers for them costs 8 x the memory (100 k pairs:
+// 170 GB per run) to keep 1 % of the pairs in the fast flow.  Those go through the overflow path instead: the estimate
+// stays within twice the median bound.
+static int quicked_estimate(std::vector<int32_t>& bounds) {
+    if (bounds.empty()) return quicked_estimate(0);
+    const int top = *std::max_element(bounds.begin(), bounds.end());
+    std::nth_element(bounds.begin(), bounds.begin() + bounds.size() / 2, bounds.end());
+    const int median = bounds[bounds.size() / 2];
+    return std::min(quicked_estimate(top), 2 * median + 64);
+}
 // per task: no bound exceeds max(m, n) (the bandwidth percentage only enters stage 3, quicked.c:246)
 static int quicked_task_estimate(int est_bound, int longest) { return std::max(1, std::min(est_bound, std::max(longest, 65))); }
 static bool quicked_fast_enabled(const Context& C) { return !C.memory_tight && env_int("QE_QUICKED_FAST", 1) != 0; }
@@ -1604,15 +1635,15 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
         bound = S1.score;
         // stage 2 for the pairs with too many high-error windows (quicked.c:201-202)
         TaskList L2; std::vector<size_t> idx2;
-        int top = 0;
+        std::vector<int32_t> stage1_bounds;
         for (size_t t = 0; t < L.pair.size(); ++t) {
             if (L.pair[t] < 0) continue;
             const unsigned mx = (unsigned)std::max(L.m[t], L.n[t]);
             if ((uint64_t)S1.hew[t] * 64u > (uint64_t)(mx * p.hew_percentage[0] / 100u)) {
                 L2.push(L.pair[t], 0, L.m[t], 0, L.n[t], 0, L.n[t]); idx2.push_back(t);
-            } else top = std::max(top, S1.score[t]);
+            } else stage1_bounds.push_back(S1.score[t]);
         }
-        if (whole_batch && B.est_bound >= 0) B.est_bound = quicked_estimate(top);      // what the fast path sizes the next run's align step for
+        if (whole_batch && B.est_bound >= 0) B.est_bound = quicked_estimate(stage1_bounds);      // what the fast path sizes the next run's align step for
         B.counters[6] = (int64_t)idx2.size();
         if (!idx2.empty()) {
             L2.pad();
@@ -1772,14 +1803,14 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     d2h(cut, d_cut, nt, C.stream); d2h(skip, d_skip, nt, C.stream); d2h(steps, d_steps, nt, C.stream);
     HIP_CHECK(hipStreamSynchronize(C.stream));
     TaskList Ls;
-    int top = 0;
+    std::vector<int32_t> stage1_bounds;
     for (size_t t = 0; t < nt; ++t) {
         if (L.pair[t] < 0) continue;
-        if (!(skip[t] & 1)) top = std::max(top, cut[t]);
+        if (!(skip[t] & 1)) stage1_bounds.push_back(cut[t]);
         if (skip[t]) Ls.push(L.pair[t], 0, L.m[t], 0, L.n[t], L.cutoff[t], L.n[t]);
         else B.counters[2] += steps[t];            // the classic flow below counts its own pairs' stage 1
     }
-    B.est_bound = quicked_estimate(top);
+    B.est_bound = quicked_estimate(stage1_bounds);
     B.deferred_pairs = (int64_t)Ls.pair.size();
     if (Ls.pair.empty()) return;
     Ls.pad();
@@ -1828,7 +1859,7 @@ static void stash_results(quicked_batch& B, Context& C, PendingFetch& F) {
     if (B.result_bytes < need) {
         if (B.result_arena) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(B.result_arena)); B.result_arena = nullptr; B.result_bytes = 0; }
         const size_t cap = need + need / 8;
-        HIP_CHECK(hipMalloc((void**)&B.result_arena, cap));
+        device_malloc_retry((void**)&B.result_arena, cap, &C.pa(), "hipMalloc((void**)&B.result_arena, cap)", __LINE__);
         B.result_bytes = cap;
     }
     size_t top = 0;
@@ -1870,6 +1901,8 @@ static int rotation_depth(int64_t n, int floor_sets = 5) {
     static const int min_env = env_int("QE_NP_MIN", 0);           // experiments
     return (int)std::max<int64_t>(min_env > 0 ? min_env : floor_sets, std::min<int64_t>(Context::NA, (2048 + groups - 1) / groups));
 }
+
+static void finisher_submit(quicked_batch& B, const std::shared_ptr<void>& pf);
 
 static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fetch) {
     double tr_last = now_ms();
@@ -2120,6 +2153,8 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         pf->pool = &C.pa(); pf->generation = C.pa().generation.load(); pf->parity = par;
         for (int q = 0; q < 8; ++q) pf->counters[q] = B.counters[q];
         B.pending_fetch = pfp;
+        B.fin_status = QUICKED_OK;
+        if (pf->fast && pf->stashed) finisher_submit(B, pfp);         // pairs that left stage 1 are finished as soon as the run is over
     }
     C.phase_u();
     B.pending = true;
@@ -2194,6 +2229,93 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
     return QUICKED_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Early finish.  A QuickEd run queued with sync == 0 goes through the fast flow; the pairs that leave stage 1 (or outgrow
+// the estimate) are aligned through the host-driven flow when the run's results are fetched -- a chain of small launches,
+// ~70 ms for a few hundred pairs of 10 kb whatever their number.  Left to the caller's fetch, a stream of batches with 1 %
+// of such pairs ran at one batch per chain (0.25-1 M alignments/s against 6 M without them) unless the caller fetched
+// from several threads.  So a few library threads do it as soon as a run is over: a job waits for the run's event, looks
+// at the skip flags in the batch's result arena and, when there are pairs to finish, does what quicked_batch_fetch would
+// (results to the host-side arrays, the deferred pairs through quicked_classic in the finisher's own context).  The
+// caller's fetch then finds the work done.  Runs without deferred pairs are left alone (one 4-byte-per-pair read).
+// QE_FINISHERS = 0 switches it off; default 3 threads, started on demand, detached (they sleep on the queue).
+// ---------------------------------------------------------------------------
+struct FinishJob { quicked_batch* B; std::shared_ptr<void> pf; };
+static std::mutex& g_fin_mu = *new std::mutex;                      // never destroyed: detached threads wait on them at exit
+static std::condition_variable& g_fin_cv = *new std::condition_variable;
+static std::deque<FinishJob>& g_fin_q = *new std::deque<FinishJob>;
+static int g_fin_threads = 0, g_fin_idle = 0;
+
+static void finisher_work(const FinishJob& job) {
+    quicked_batch& B = *job.B;
+    PendingFetch& F = *static_cast<PendingFetch*>(job.pf.get());
+    tl_device = B.device;
+    Context& C = ctx();
+    HIP_CHECK(hipEventSynchronize(B.ev_done[F.parity]));            // the run is over (the batch is alive: destroy waits for fin_jobs)
+    std::unique_lock<std::mutex> lk(B.fin_mu);
+    if (B.pending_fetch.get() != job.pf.get()) { if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p already fetched / superseded\n", (void*)&B); return; }
+    std::vector<int32_t> skip;
+    d2h(skip, F.d_skip, F.L.pair.size(), C.stream);
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+    bool any = false;
+    for (size_t t = 0; t < skip.size() && !any; ++t) any = skip[t] != 0 && F.L.pair[t] >= 0;
+    if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p deferred pairs %s\n", (void*)&B, any ? "yes" : "none");
+    if (!any) return;                                                // nothing to finish: the caller's fetch is a copy
+    // the finishers' pools are not in anybody's plan: with little HBM left the work stays with the caller's fetch, and this
+    // thread gives back what it holds
+    auto trim_own = [&]() { C.sync_all(); for (auto& q : C.pool_a2) q.release_all(); for (auto& q : C.pool_w2) q.release_all(); C.pool_w.release_all(); };
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < ((size_t)32 << 30)) { trim_own(); return; }
+    const std::shared_ptr<void> keep = B.pending_fetch;
+    try { B.fin_status = fetch_pending(B); }
+    catch (const HipError&) {
+        // e.g. out of memory next to the other threads' pools: nothing is lost -- the run's results are still in the batch's
+        // result arena, and the caller's fetch does the same work in its own context
+        (void)hipGetLastError();
+        B.pending_fetch = keep; B.pending = true; B.fin_status = QUICKED_OK;
+        try { trim_own(); } catch (const HipError&) { (void)hipGetLastError(); }
+        throw;
+    }
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < ((size_t)48 << 30)) trim_own();
+}
+
+static void finisher_main() {
+    for (;;) {
+        FinishJob job;
+        {
+            std::unique_lock<std::mutex> lk(g_fin_mu);
+            ++g_fin_idle;
+            g_fin_cv.wait(lk, [] { return !g_fin_q.empty(); });
+            --g_fin_idle;
+            job = std::move(g_fin_q.front());
+            g_fin_q.pop_front();
+        }
+        try { finisher_work(job); }
+        catch (const HipError& e) {
+            fprintf(stderr, "[quicked_hip] early finish: HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
+            (void)hipGetLastError();
+        }
+        catch (const std::exception& e) { fprintf(stderr, "[quicked_hip] early finish: %s\n", e.what()); }
+        {
+            std::lock_guard<std::mutex> lk(job.B->fin_mu);
+            --job.B->fin_jobs;
+        }
+        job.B->fin_cv.notify_all();
+    }
+}
+
+// called by run_batch with B.fin_mu held
+static void finisher_submit(quicked_batch& B, const std::shared_ptr<void>& pf) {
+    static const int max_threads = env_int("QE_FINISHERS", 3);
+    if (max_threads <= 0) return;
+    ++B.fin_jobs;
+    std::lock_guard<std::mutex> lk(g_fin_mu);
+    g_fin_q.push_back(FinishJob{&B, pf});
+    if (g_fin_idle == 0 && g_fin_threads < max_threads) { ++g_fin_threads; std::thread(finisher_main).detach(); }
+    g_fin_cv.notify_one();
+}
+
 }  // namespace qe
 
 // ---------------------------------------------------------------------------
@@ -2264,7 +2386,11 @@ QE_API quicked_status_t quicked_set_device(int device) {
     return QUICKED_OK;
 }
 
+// every call that works on a batch object holds its fin_mu: an early finish of the batch's last run (qe::finisher_work) is
+// waited for, and cannot start in the middle of the call
 static quicked_status_t guard(quicked_batch* B, quicked_status_t (*fn)(quicked_batch*, void*), void* arg) {
+    std::unique_lock<std::mutex> lk;
+    if (B) lk = std::unique_lock<std::mutex>(B->fin_mu);
     try { return fn(B, arg); }
     catch (const HipError& e) {
         fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
@@ -2287,7 +2413,7 @@ static void batch_reset_state(quicked_batch* B) {
 static void batch_arena(quicked_batch* B, size_t need) {
     if (B->arena && B->arena_bytes >= need) return;
     if (B->arena) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(B->arena)); B->arena = nullptr; B->arena_bytes = 0; }
-    HIP_CHECK(hipMalloc((void**)&B->arena, need));
+    device_malloc_retry((void**)&B->arena, need, nullptr, "hipMalloc((void**)&B->arena, need)", __LINE__);
     B->arena_bytes = need;
 }
 static void batch_load(quicked_batch* B, Context& C, int64_t n,
@@ -2545,7 +2671,10 @@ QE_API quicked_status_t quicked_batch_reload_packed(quicked_batch_t* batch, int6
 
 QE_API quicked_status_t quicked_batch_fetch(quicked_batch_t* batch) {
     if (!batch) return QUICKED_ERROR;
-    return guard(batch, [](quicked_batch* B, void*) { return fetch_pending(*B); }, nullptr);
+    return guard(batch, [](quicked_batch* B, void*) {
+        if (!B->pending_fetch && B->fin_status < 0) return B->fin_status;      // an early finish did the work, and failed
+        return fetch_pending(*B);
+    }, nullptr);
 }
 
 QE_API void quicked_batch_destroy(quicked_batch_t* batch) {
@@ -2555,6 +2684,11 @@ QE_API void quicked_batch_destroy(quicked_batch_t* batch) {
         (void)ctx();                           // binds the batch's device to this thread
         batch_quiesce(batch);                  // runs queued by any thread; hipFree then synchronises the device itself
     } catch (const HipError&) { (void)hipGetLastError(); }
+    {   // early-finish jobs still queued for this batch find nothing to do and retire
+        std::unique_lock<std::mutex> lk(batch->fin_mu);
+        batch->pending_fetch.reset();
+        batch->fin_cv.wait(lk, [&] { return batch->fin_jobs == 0; });
+    }
     delete batch;
 }
 

@@ -1134,6 +1134,42 @@ def test_two_host_threads_plan_hbm_together():
     assert free_b.value > 0.8 * total_b.value, (free_b.value, total_b.value)
 
 
+@pytest.mark.parametrize("finishers", ["3", "0"])
+def test_mixed_batches_finish_early(finishers, monkeypatch):
+    """ordinary reads with a few large-indel pairs among them: the QuickEd fast flow sizes its align step for the ordinary
+    ones (estimate within twice the median bound), the others leave it and are aligned through the host-driven stages -- by
+    the library's early-finish threads as soon as the run is over (QE_FINISHERS = 3, default) or by the caller's fetch
+    (0).  A stream of queued runs over several batch objects, fetched by one thread: every result equal to the oracle's,
+    the deferred pairs counted, no pool grown to the outliers' size."""
+    monkeypatch.setenv("QE_FINISHERS", finishers)
+    import numpy as np
+    easy = datagen.generate(count=6000, length=4000, error=0.05, seed=555)
+    hard = datagen.generate(count=120, length=4000, error=0.05, seed=556, indels_num=3, indels_len=400)
+    pairs = list(easy.pairs()) + list(hard.pairs())
+    batch = datagen.PairBatch(*_pools(pairs))
+    want = {i: O.oracle_align(*pairs[i], algo=0) for i in list(range(0, 6000, 500)) + list(range(6000, 6120, 7))}
+    prm = capi.make_params(algo=capi.QUICKED)
+    rbs = [capi.ResidentBatch(batch) for _ in range(3)]
+    for rb in rbs:
+        assert rb.run(prm, sync=True) >= 0
+    deferred = []
+    for rnd in range(4):
+        for rb in rbs:
+            assert rb.run(prm, sync=False) >= 0
+        for rb in rbs:
+            assert rb.fetch() >= 0
+            deferred.append(rb.deferred_pairs())
+            s, st = rb.scores(); cg = rb.cigars()
+            for i, w in want.items():
+                assert (st[i], s[i], cg[i]) == w, (finishers, rnd, i)
+    assert min(deferred) > 0, deferred                    # the outliers did leave the fast flow ...
+    assert max(deferred) < 600, deferred                  # ... and only they (and the few ordinary pairs above the estimate)
+    stats = capi.pool_stats()
+    for rb in rbs:
+        rb.close()
+    assert stats["pool_bytes"] < 40 * 2**30, stats        # this thread's pools: sized for the ordinary pairs
+
+
 def test_threads_that_end_without_trimming_leave_no_pools_behind():
     """A host thread that just ends (no quicked_pool_trim, batches closed) must neither crash in its thread-local
     destructors -- HIP may not be called from there -- nor keep its device pools: its contexts are parked, and the next live
