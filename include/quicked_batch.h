@@ -108,7 +108,11 @@ quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
  * queueing thread's rotating pools into memory of the batch object (device to device), so the thread may queue any number
  * of runs of OTHER batch objects before this one is fetched; the batch's own next run, reload or destroy discards them.
  * Any thread may fetch (bench.py's end-to-end leg fetches on a thread of its own) as long as no other call on this batch
- * object runs at the same time; what the fetch itself has to compute runs on the calling thread's streams and pools. */
+ * object runs at the same time; what the fetch itself has to compute runs on the calling thread's streams and pools.
+ * QUICKED: the pairs a queued run left for the host-driven stages (those past stage 1, those above the bound estimate)
+ * are aligned by library threads as soon as the run is over ("early finish": up to QE_FINISHERS = 3 threads with streams
+ * and pools of their own, started when first needed); the fetch then only waits for that.  Calls on one batch object are
+ * serialised against such a thread by the library. */
 quicked_status_t quicked_batch_fetch(quicked_batch_t* batch);
 
 /* results of the last sync != 0 run or of the last quicked_batch_fetch (host copies) */
