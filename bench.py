@@ -384,6 +384,69 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
     return out
 
 
+def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4):
+    """QuickEd + CIGAR on a MIXED batch: `pairs` ordinary pairs of which `share` carry 4 x 800-base indels (they leave the
+    fast flow and go through the host-driven stages 2 / 3).  `slots` resident batch objects of the same data, runs queued
+    with sync == 0 by this thread, every run fetched by ONE other thread -- the pattern of the end-to-end legs without the
+    copies in.  The library's early-finish threads (QE_FINISHERS) align the pairs that left the fast flow."""
+    import queue
+    hard = max(1, int(pairs * share))
+    batch = datagen.generate(pairs - hard, length, error, seed=datagen.DEFAULT_SEED).concat(
+        datagen.generate(hard, length, error, seed=datagen.DEFAULT_SEED, first=pairs, indels_num=4, indels_len=800))
+    p = capi.make_params(algo=capi.QUICKED)
+    rbs = [capi.ResidentBatch(batch) for _ in range(slots)]
+    try:
+        checks = []
+        for rb in rbs:
+            if rb.run(p, sync=True) < 0:
+                raise RuntimeError("quicked_batch_run failed")
+            checks.append(int(rb.scores()[0].astype("int64").sum()))
+        for rb in rbs:                                      # the fast flow, once, outside the clock (pools, estimates)
+            rb.run(p, sync=False)
+        for rb in rbs:
+            rb.fetch()
+        todo, free, deferred, bad = queue.Queue(), queue.Queue(), [], []
+        for rb in rbs:
+            free.put(rb)
+
+        def fetcher():
+            while True:
+                rb = todo.get()
+                if rb is None:
+                    return
+                if rb.fetch() < 0:
+                    bad.append("fetch")
+                deferred.append(int(rb.deferred_pairs()))
+                if int(rb.scores()[0].astype("int64").sum()) != checks[0]:
+                    bad.append("checksum")
+                free.put(rb)
+
+        th = threading.Thread(target=fetcher)
+        th.start()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rb = free.get()
+            if rb.run(p, sync=False) < 0:
+                bad.append("run")
+            todo.put(rb)
+        todo.put(None)
+        th.join()
+        dt = time.perf_counter() - t0
+    finally:
+        for rb in rbs:
+            rb.close()
+    if bad or len(set(checks)) != 1:
+        return {"error": f"mixed leg failed: {sorted(set(bad))}"}
+    return {"value": pairs * steps / dt, "unit": "alignments/s", "ms_per_batch": dt / steps * 1e3, "pairs_per_gpu": pairs, "batches": steps,
+            "hard_pairs": hard, "pairs_finished_outside_the_fast_flow_per_run": max(deferred) if deferred else 0,
+            "batch_objects": slots, "fetching_threads": 1, "early_finish_threads": int(os.environ.get("QE_FINISHERS", "3")),
+            "score_checksum": checks[0],
+            "data": f"{hard} of {pairs} pairs with 4 x 800-base indels on top of the {error * 100:g} % edits, the rest as in the headline",
+            "note": "a stream of queued runs over resident batch objects, every run fetched (results on the host side of the "
+                    "library, strings left in the batch's pinned pool); the pairs that leave the fast flow are aligned through "
+                    "the host-driven stages by the library's early-finish threads"}
+
+
 class Bench:
     """one rank's legs; every leg reduces over the ranks through quicked_amd/shard.py"""
 
@@ -646,6 +709,8 @@ def main():
     ap.add_argument("--e2e-uploaders", type=int, default=0, help="uploader threads (0: 2 for score-only BandEd, 3 for QuickEd)")
     ap.add_argument("--e2e-inflight", type=int, default=0, help="runs queued and not yet fetched (0: 2 for score-only BandEd, 3 for QuickEd)")
     ap.add_argument("--no-strong", action="store_true", help="no strong (N > 1) / strong_share (N = 1) legs")
+    ap.add_argument("--mixed-share", type=float, default=0.01,
+                    help="share of large-indel pairs in the mixed QuickEd leg (workloads.quicked_mixed; 0: no such leg)")
     ap.add_argument("--indel-pairs", type=int, default=20000,
                     help="pairs of the indel-heavy QuickEd leg (4 x 800-base indels per 10 kb pair: stages 2 / 3 and band doubling, "
                          "SURVEY's own trigger set); 0: no such leg")
@@ -740,6 +805,16 @@ def main():
                                                        "single_batch_value", "score_checksum")}
                 strong_share[wl]["aggregate_block_columns_per_s"] = o["valu"]["aggregate_block_columns_per_s"]
 
+    if default_shape and args.mixed_share > 0 and args.indels_num == 0 and world == 1:
+        # ordinary pairs with a few large-indel ones among them: what the fast flow's overflow path and the early-finish
+        # threads are for.  Last, and from empty pools: four more resident batches and buffers for twice the
+        # usual bounds next to everything the legs above have grown would be a leg about memory pressure
+        B._cache = None
+        B.capi.pool_trim()
+        try:
+            others["quicked_mixed"] = mixed_leg(B.capi, B.datagen, args.pairs, args.length, args.error, args.mixed_share)
+        except Exception as e:          # noqa: BLE001  (a leg of its own: the line survives it)
+            others["quicked_mixed"] = {"error": repr(e)}
     line = None
     if rank == 0:
         label = f"{args.length / 1000:g}kb x {args.length / 1000:g}kb {args.error * 100:g}%-error pairs"

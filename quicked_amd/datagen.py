@@ -65,6 +65,15 @@ class PairBatch:
     def cells(self):
         return int((self.pattern_len.astype(np.int64) * self.text_len.astype(np.int64)).sum())
 
+    def concat(self, other):
+        """the pairs of `self` followed by those of `other` (mixed data sets: ordinary reads + a few with large indels)"""
+        return PairBatch(np.concatenate([self.pattern_pool, other.pattern_pool]),
+                         np.concatenate([self.pattern_off, other.pattern_off + len(self.pattern_pool)]),
+                         np.concatenate([self.pattern_len, other.pattern_len]),
+                         np.concatenate([self.text_pool, other.text_pool]),
+                         np.concatenate([self.text_off, other.text_off + len(self.text_pool)]),
+                         np.concatenate([self.text_len, other.text_len]))
+
 
 def generate(count, length, error, seed=DEFAULT_SEED, first=0, indels_num=0, indels_len=0):
     """``count`` pairs: text = ``length`` uniform ACGT bases, pattern = text with

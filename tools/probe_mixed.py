@@ -14,16 +14,10 @@ steps = int(os.environ.get("STEPS", "12"))
 p = capi.make_params(algo=capi.QUICKED)
 
 
-def concat(a, b):
-    return datagen.PairBatch(np.concatenate([a.pattern_pool, b.pattern_pool]), np.concatenate([a.pattern_off, b.pattern_off + len(a.pattern_pool)]),
-                             np.concatenate([a.pattern_len, b.pattern_len]), np.concatenate([a.text_pool, b.text_pool]),
-                             np.concatenate([a.text_off, b.text_off + len(a.text_pool)]), np.concatenate([a.text_len, b.text_len]))
-
-
 for share in shares:
     hard = int(n * share)
     easy = datagen.generate(n - hard, 10000, 0.05, seed=0x51CED)
-    batch = concat(easy, datagen.generate(hard, 10000, 0.05, seed=0x51CED, first=n, indels_num=4, indels_len=800)) if hard else easy
+    batch = easy.concat(datagen.generate(hard, 10000, 0.05, seed=0x51CED, first=n, indels_num=4, indels_len=800)) if hard else easy
     for F in fetchers:
         slots = int(os.environ.get("SLOTS", max(4, F + 3)))
         rbs = [capi.ResidentBatch(batch) for _ in range(slots)]

@@ -55,7 +55,10 @@ def paragraph(tag=None):
         f"QuickEd + Hirschberg CIGAR on {c4['config']['pairs_per_gpu'] // 1000} k pairs of {c4['config']['length'] // 1000} kb / "
         f"{c4['config']['error'] * 100:.0f} % reads **{c4['value'] / 1e3:.1f} k alignments/s**; "
         f"QuickEd on pairs with 4 x 800-base indels (stages 2 / 3, band doubling) "
-        f"{d['workloads']['quicked_indels']['value'] / 1e6:.2f} M alignments/s. "
+        f"{d['workloads']['quicked_indels']['value'] / 1e6:.2f} M alignments/s"
+        + (f", on ordinary batches with {d['workloads']['quicked_mixed']['hard_pairs'] * 100 // d['workloads']['quicked_mixed']['pairs_per_gpu']} % of such pairs "
+           f"among them {d['workloads']['quicked_mixed']['value'] / 1e6:.1f} M" if "value" in d["workloads"].get("quicked_mixed", {}) else "")
+        + ". "
         f"The compiled reference on the same box, on the {d['cpu_baseline']['cores']} CPUs the process is allowed (one aligner per thread): "
         f"{d['cpu_baseline']['value'] / 1e3:.0f} k and {q['cpu_baseline']['value'] / 1e3:.0f} k alignments/s for the two 10 kb workloads, "
         f"identical scores on all pairs of the sample.")
