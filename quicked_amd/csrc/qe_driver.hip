@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <csignal>
 #include <deque>
@@ -2251,7 +2252,14 @@ static void finisher_work(const FinishJob& job) {
     PendingFetch& F = *static_cast<PendingFetch*>(job.pf.get());
     tl_device = B.device;
     Context& C = ctx();
-    HIP_CHECK(hipEventSynchronize(B.ev_done[F.parity]));            // the run is over (the batch is alive: destroy waits for fin_jobs)
+    // the run is over (the batch is alive: destroy waits for fin_jobs).  Polled with short sleeps: hipEventSynchronize spins,
+    // and these threads wait for every queued QuickEd run of the process
+    for (;;) {
+        const hipError_t e = hipEventQuery(B.ev_done[F.parity]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) throw HipError{e, "hipEventQuery(B.ev_done[F.parity])", __LINE__};
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
     std::unique_lock<std::mutex> lk(B.fin_mu);
     if (B.pending_fetch.get() != job.pf.get()) { if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p already fetched / superseded\n", (void*)&B); return; }
     std::vector<int32_t> skip;
