@@ -38,9 +38,9 @@ import threading
 import time
 
 # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one
-# serialise; the library asks for 16 when it is loaded, but under a launcher torch initialises HIP first -- so ask here too,
+# serialise; the library asks for 24 when it is loaded, but under a launcher torch initialises HIP first -- so ask here too,
 # before anything imports torch.  A value the user has set is left alone.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

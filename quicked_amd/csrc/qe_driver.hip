@@ -488,8 +488,11 @@ static void device_malloc_retry(void** p, size_t bytes, DevicePool* keep, const 
 // share a queue serialise.  A thread's runs rotate over up to NA sets of two streams, so that small batches can have many
 // runs on the device at once: ask for more queues unless the user has chosen a value.  Read by the runtime when it
 // initialises (the first HIP call of the process), so this has to happen at load time; a process that has already
-// initialised HIP keeps what it has.
-__attribute__((constructor)) static void qe_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// initialised HIP keeps what it has.  24: a thread's rotation is up to 14 streams (12 sets, the utility and
+// the side stream) and the three early-finish threads use three each -- with 16 queues, streams of the rotation that were
+// created after theirs landed on shared queues about every other process (a stream of 12.5 k-pair batches at 4.2 instead
+// of 6.2 M alignments/s); 32 and 64 are no better than 24.
+__attribute__((constructor)) static void qe_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 // QE_SEGV_TRACE=1: a native backtrace (module + offset: addr2line -e libquicked_hip.so) on SIGSEGV / SIGABRT, then the default action
 static void qe_segv_trace(int sig) {
     void* frames[64];
