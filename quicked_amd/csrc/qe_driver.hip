@@ -2249,6 +2249,8 @@ static std::mutex& g_fin_mu = *new std::mutex;                      // never des
 static std::condition_variable& g_fin_cv = *new std::condition_variable;
 static std::deque<FinishJob>& g_fin_q = *new std::deque<FinishJob>;
 static int g_fin_threads = 0, g_fin_idle = 0;
+static std::atomic<int> g_fin_busy{0};               // jobs being worked on
+static std::atomic<bool> g_fin_stop{false};          // the process is exiting: no new work
 
 static void finisher_work(const FinishJob& job) {
     quicked_batch& B = *job.B;
@@ -2301,19 +2303,29 @@ static void finisher_main() {
             --g_fin_idle;
             job = std::move(g_fin_q.front());
             g_fin_q.pop_front();
+            ++g_fin_busy;
         }
-        try { finisher_work(job); }
+        try { if (!g_fin_stop.load()) finisher_work(job); }
         catch (const HipError& e) {
             fprintf(stderr, "[quicked_hip] early finish: HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
             (void)hipGetLastError();
         }
         catch (const std::exception& e) { fprintf(stderr, "[quicked_hip] early finish: %s\n", e.what()); }
+        --g_fin_busy;
+        if (g_fin_stop.load()) continue;             // exiting: the batch object may be gone
         {
             std::lock_guard<std::mutex> lk(job.B->fin_mu);
             --job.B->fin_jobs;
         }
         job.B->fin_cv.notify_all();
     }
+}
+// at process exit (this library's destructors run before the HIP runtime's, which it depends on): no new early-finish work,
+// and a job in progress gets a few seconds to leave the runtime alone
+__attribute__((destructor)) static void finisher_shutdown() {
+    g_fin_stop.store(true);
+    { std::lock_guard<std::mutex> lk(g_fin_mu); g_fin_q.clear(); }
+    for (int i = 0; i < 5000 && g_fin_busy.load() > 0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(1));
 }
 
 // called by run_batch with B.fin_mu held
