@@ -2263,6 +2263,7 @@ static void finisher_work(const FinishJob& job) {
         const hipError_t e = hipEventQuery(B.ev_done[F.parity]);
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) throw HipError{e, "hipEventQuery(B.ev_done[F.parity])", __LINE__};
+        if (g_fin_stop.load()) return;                               // the process is exiting
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
     std::unique_lock<std::mutex> lk(B.fin_mu);
