@@ -390,9 +390,10 @@ def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4):
     with sync == 0 by this thread, every run fetched by ONE other thread -- the pattern of the end-to-end legs without the
     copies in.  The library's early-finish threads (QE_FINISHERS) align the pairs that left the fast flow."""
     import queue
-    hard = max(1, int(pairs * share))
-    batch = datagen.generate(pairs - hard, length, error, seed=datagen.DEFAULT_SEED).concat(
-        datagen.generate(hard, length, error, seed=datagen.DEFAULT_SEED, first=pairs, indels_num=4, indels_len=800))
+    hard = min(pairs, max(1, int(pairs * share)))
+    batch = datagen.generate(hard, length, error, seed=datagen.DEFAULT_SEED, first=pairs if hard < pairs else 0, indels_num=4, indels_len=800)
+    if hard < pairs:
+        batch = datagen.generate(pairs - hard, length, error, seed=datagen.DEFAULT_SEED).concat(batch)
     p = capi.make_params(algo=capi.QUICKED)
     rbs = [capi.ResidentBatch(batch) for _ in range(slots)]
     try:
@@ -815,6 +816,17 @@ def main():
             others["quicked_mixed"] = mixed_leg(B.capi, B.datagen, args.pairs, args.length, args.error, args.mixed_share)
         except Exception as e:          # noqa: BLE001  (a leg of its own: the line survives it)
             others["quicked_mixed"] = {"error": repr(e)}
+        if "quicked_indels" in others:
+            # the indel-heavy pairs once more, as such a fetched stream (fast flow for the pairs that stay in stage 1, the
+            # early-finish threads for the rest, several batches at a time) next to the host-driven resident loop above
+            try:
+                B.capi.pool_trim()
+                o = mixed_leg(B.capi, B.datagen, args.indel_pairs, args.length, args.error, 1.0, steps=16, slots=6)
+                others["quicked_indels"]["fetched_stream"] = {k: o[k] for k in ("value", "unit", "ms_per_batch", "batches", "batch_objects",
+                                                                                "fetching_threads", "early_finish_threads",
+                                                                                "pairs_finished_outside_the_fast_flow_per_run") if k in o} or o
+            except Exception as e:      # noqa: BLE001
+                others["quicked_indels"]["fetched_stream"] = {"error": repr(e)}
     line = None
     if rank == 0:
         label = f"{args.length / 1000:g}kb x {args.length / 1000:g}kb {args.error * 100:g}%-error pairs"
