@@ -60,7 +60,7 @@ struct DevicePool {
     // Chunks keep every pointer handed out during a run valid: when a run needs more than
     // the arena holds, another chunk is hipMalloc'ed.  The next run repeats the same request
     // sequence and fits the same chunks, so steady-state runs never allocate.
-    struct Chunk { uint8_t* base; size_t cap; bool used; };     // used: something was carved from it since the last reset
+    struct Chunk { uint8_t* base; size_t cap; bool used; int idle = 0; };     // used: something was carved from it since the last reset; idle: resets in a row it was not
     std::vector<Chunk> chunks;
     size_t cur = 0, top = 0, cap = 0;            // cap = total bytes over all chunks
     std::atomic<uint64_t> generation{0};         // bumped whenever handed-out pointers stop being valid (reset / release_all); read by fetching threads
@@ -84,7 +84,7 @@ struct DevicePool {
         return any;
     }
     void add_chunk(size_t bytes) {
-        Chunk c; c.cap = bytes; c.base = nullptr; c.used = false;
+        Chunk c; c.cap = bytes; c.base = nullptr; c.used = false; c.idle = 0;
         hipError_t e = hipMalloc((void**)&c.base, bytes);
         if (e == hipErrorOutOfMemory && drop_unused_chunks()) {
             (void)hipGetLastError();
@@ -108,6 +108,22 @@ struct DevicePool {
             add_chunk(total);
         }
         std::lock_guard<std::mutex> lk(fetching);
+        // Chunks that date from another workload (other pairs, another estimate: their sizes fit none of this run sequence's
+        // requests) go back to the device after QE_POOL_IDLE (8) runs in a row without use when memory is short -- before, they stayed until an
+        // out-of-memory reclaim found them (a pool set grew from 16 to 54 GB when mixed batches followed uniform ones).
+        // hipFree synchronises the device: once per stale chunk.
+        static const int idle_max = [] { const char* e = getenv("QE_POOL_IDLE"); return e ? atoi(e) : 8; }();
+        for (auto& c : chunks) {
+            if (c.used || !c.base) { c.idle = 0; continue; }
+            if (++c.idle >= idle_max && idle_max > 0 && chunks.size() > 1) {
+                // ... while the device is short of memory (less than a quarter free): hipFree waits for everything in
+                // flight, which a session with room to spare should not pay for
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= total_b / 4) { c.idle = idle_max / 2; continue; }
+                if (pool_trace()) fprintf(stderr, "[qe-pool %p] stale chunk %.2f GB goes back\n", (void*)this, c.cap / 1e9);
+                (void)hipFree(c.base); cap -= c.cap; c.base = nullptr; c.cap = 0;
+            }
+        }
         chunks.erase(std::remove_if(chunks.begin(), chunks.end(), [](const Chunk& c) { return c.cap == 0; }), chunks.end());
         for (auto& c : chunks) c.used = false;
         cur = 0; top = 0; ++generation;
@@ -323,7 +339,12 @@ struct Context {
     PinnedStage stage[2 * NA];               // see PinnedStage
     int si = 0;
     bool staging = false;                    // uploads on the current A stream go through stage[si]
-    bool memory_tight = false;               // a pool had to take the others' memory once: no more rotation on this thread
+    // a pool had to take the others' memory: no rotation and no fast flow on this thread -- for a while.  A workload change in
+    // the middle of a session (other pairs, another estimate: the pools' chunks stop fitting) ends in the same reclaim as a
+    // device that is really too small; only the second keeps coming back.  tight_left runs with one set, then the plan is
+    // tried again; every further event doubles the spell (16 .. 1024 runs).
+    bool memory_tight = false;
+    int tight_left = 0, tight_spell = 16;
     int last_na = 0, last_sub_batches = 0;   // what the planner chose for the last run (quicked_pool_stats)
     int in_flight = 1;                       // runs of this thread that may be on the device at once while the current one executes
     size_t pool_budget = 0;                  // bytes one A pool may hold in this run (plan_pools)
@@ -454,6 +475,8 @@ static bool reclaim_pools(DevicePool* keep) {
         if (any) { reap_orphans(); if (C->device != tl_bound_device) (void)hipSetDevice(C->device); freed = true; }
     }
     C->memory_tight = true;
+    C->tight_left = C->tight_spell;
+    C->tight_spell = std::min(2 * C->tight_spell, 1024);
     ++g_reclaim_events;
     for (int q = 0; q < Context::NA; ++q) {
         if (&C->pool_a2[q] != keep && &C->pool_a2[q] != tl_fetch_hold && C->pool_a2[q].cap != 0) {
@@ -1971,6 +1994,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     for (int k = std::min(depth_wanted, B.np_alloc); k >= 1; --k)
         if ((double)min_set * k <= ((k > 3 && k > sets_held) ? 0.6 : 1.0) * (double)avail) { na = k; break; }
     if (na_env > 0) na = std::min(std::min(na_env, (int)Context::NA), B.np_alloc);
+    if (C.memory_tight && C.tight_left-- <= 0) { C.memory_tight = false; C.tight_left = 0; }      // the spell is over: plan normally again
     if (C.memory_tight) na = 1;
     // Sets outside the rotation keep their pools while this run's plan works without that memory -- the next batch may
     // widen the rotation again, and freeing / re-allocating tens of GB per run costs more than any of this saves (a stream
