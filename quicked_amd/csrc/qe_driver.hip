@@ -2355,7 +2355,7 @@ __attribute__((destructor)) static void finisher_shutdown() {
 
 // called by run_batch with B.fin_mu held
 static void finisher_submit(quicked_batch& B, const std::shared_ptr<void>& pf) {
-    static const int max_threads = env_int("QE_FINISHERS", 3);
+    const int max_threads = env_int("QE_FINISHERS", 3);           // read per call: tests switch it
     if (max_threads <= 0) return;
     ++B.fin_jobs;
     std::lock_guard<std::mutex> lk(g_fin_mu);
