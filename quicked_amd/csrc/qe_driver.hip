@@ -1644,8 +1644,11 @@ static int quicked_estimate(std::vector<int32_t>& bounds) {
 static int quicked_task_estimate(int est_bound, int longest) { return std::max(1, std::min(est_bound, std::max(longest, 65))); }
 static bool quicked_fast_enabled(const Context& C) { return !C.memory_tight && env_int("QE_QUICKED_FAST", 1) != 0; }
 
+// known_s1: stage 1 is known already (the fast flow's leftovers: bound and "goes on to stage 2" per task) -- not run again
+struct KnownStage1 { std::vector<int32_t> score; std::vector<uint8_t> stage2; };
 static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t& p, const TaskList& L, bool fetch,
-                            size_t matrix_budget, PendingFetch* pf, const std::function<void()>& enter_a, bool whole_batch = true) {
+                            size_t matrix_budget, PendingFetch* pf, const std::function<void()>& enter_a, bool whole_batch = true,
+                            const KnownStage1* known_s1 = nullptr) {
     double tr_last = now_ms();
     const bool sse = !p.force_scalar;
     const bool want_cigar = !p.only_score;
@@ -1653,12 +1656,16 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
     std::vector<int32_t> bound(L.pair.size(), 0);
     if (p.algo == QUICKED) {
         StageResult S1;
-        qe_timer_start(tl_timers.windowed_s);
-        run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0],
-                     true, sse, &S1, true, false, nullptr);
-        qe_timer_stop(tl_timers.windowed_s);
-        QE_TRACE_POINT("stage 1 windowed");
-        B.counters[2] += (int64_t)sum_u32(S1.steps);
+        if (known_s1) {
+            S1.score = known_s1->score;               // the caller has counted these pairs' stage-1 steps
+        } else {
+            qe_timer_start(tl_timers.windowed_s);
+            run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0],
+                         true, sse, &S1, true, false, nullptr);
+            qe_timer_stop(tl_timers.windowed_s);
+            QE_TRACE_POINT("stage 1 windowed");
+            B.counters[2] += (int64_t)sum_u32(S1.steps);
+        }
         bound = S1.score;
         // stage 2 for the pairs with too many high-error windows (quicked.c:201-202)
         TaskList L2; std::vector<size_t> idx2;
@@ -1666,7 +1673,8 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
         for (size_t t = 0; t < L.pair.size(); ++t) {
             if (L.pair[t] < 0) continue;
             const unsigned mx = (unsigned)std::max(L.m[t], L.n[t]);
-            if ((uint64_t)S1.hew[t] * 64u > (uint64_t)(mx * p.hew_percentage[0] / 100u)) {
+            const bool stage2 = known_s1 ? known_s1->stage2[t] != 0 : (uint64_t)S1.hew[t] * 64u > (uint64_t)(mx * p.hew_percentage[0] / 100u);
+            if (stage2) {
                 L2.push(L.pair[t], 0, L.m[t], 0, L.n[t], 0, L.n[t]); idx2.push_back(t);
             } else stage1_bounds.push_back(S1.score[t]);
         }
@@ -1830,17 +1838,19 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     d2h(cut, d_cut, nt, C.stream); d2h(skip, d_skip, nt, C.stream); d2h(steps, d_steps, nt, C.stream);
     HIP_CHECK(hipStreamSynchronize(C.stream));
     TaskList Ls;
+    KnownStage1 K1;                                // the pairs left keep their stage-1 results: bound and whether stage 2 follows
     std::vector<int32_t> stage1_bounds;
     for (size_t t = 0; t < nt; ++t) {
         if (L.pair[t] < 0) continue;
         if (!(skip[t] & 1)) stage1_bounds.push_back(cut[t]);
-        if (skip[t]) Ls.push(L.pair[t], 0, L.m[t], 0, L.n[t], L.cutoff[t], L.n[t]);
-        else B.counters[2] += steps[t];            // the classic flow below counts its own pairs' stage 1
+        if (skip[t]) { Ls.push(L.pair[t], 0, L.m[t], 0, L.n[t], L.cutoff[t], L.n[t]); K1.score.push_back(cut[t]); K1.stage2.push_back((uint8_t)(skip[t] & 1)); }
+        B.counters[2] += steps[t];
     }
     B.est_bound = quicked_estimate(stage1_bounds);
     B.deferred_pairs = (int64_t)Ls.pair.size();
     if (Ls.pair.empty()) return;
     Ls.pad();
+    K1.score.resize(Ls.pair.size(), 0); K1.stage2.resize(Ls.pair.size(), 0);
     // the classic flow for the pairs left, on idle streams, above whatever the pools hold (a later run of this thread
     // may have its buffers there)
     C.sync_all();
@@ -1858,7 +1868,7 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     C.pa().release(DevicePool::Mark{0, 0});
     C.phase_w();
     auto enter_a = [&]() { C.phase_a(); };
-    quicked_classic(B, C, p, Ls, true, matrix_budget, nullptr, enter_a, false);
+    quicked_classic(B, C, p, Ls, true, matrix_budget, nullptr, enter_a, false, &K1);
     C.sync_all();
 }
 
