@@ -270,3 +270,15 @@ def test_readme_numbers_are_generated_from_the_committed_bench_line():
     text = open(os.path.join(ROOT, "README.md")).read()
     held = text[text.index(mod.BEGIN) + len(mod.BEGIN):text.index(mod.END)].strip()
     assert held == mod.paragraph().strip()
+
+
+def test_committed_kernel_resource_table_has_no_scratch():
+    """profiles/<newest tag>_kernel_resources.txt (tools/kernel_resources.sh): every kernel of the build it describes fits
+    its registers -- the fill's spills were a review item of round 2"""
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_resources.txt"))
+    assert files
+    lines = [l for l in open(os.path.join(ROOT, "profiles", files[-1])).read().splitlines() if l.strip()]
+    assert len(lines) >= 20
+    for l in lines:
+        assert "ScratchSize [bytes/lane]: 0" in l, l
+    assert any("k_banded<true>" in l for l in lines) and any("k_windowed_cp" in l for l in lines)
