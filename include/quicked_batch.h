@@ -149,7 +149,7 @@ quicked_status_t quicked_batch_validate(quicked_batch_t* batch, const char* ciga
  *   [6] pairs that went past stage 1   [7] pairs that went past stage 2 */
 quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]);
 /* QUICKED runs that queue stage 1 and the align step together (see quicked_batch_run) align the pairs that leave stage 1,
- * or whose bound exceeds the planned buffers, when the run's results are brought to the host: how many pairs of the last
+ * or whose bound exceeds the planned buffers, after the run (early-finish threads, or the fetch): how many pairs of the last
  * sync != 0 run / fetch that were (0 on data like BASELINE configs 2-3; a harness that times sync == 0 runs it never
  * fetches should check this, bench.py does) */
 int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch);
