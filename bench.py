@@ -415,23 +415,30 @@ def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4):
                 rb = todo.get()
                 if rb is None:
                     return
-                if rb.fetch() < 0:
-                    bad.append("fetch")
-                deferred.append(int(rb.deferred_pairs()))
-                if int(rb.scores()[0].astype("int64").sum()) != checks[0]:
-                    bad.append("checksum")
+                try:
+                    if rb.fetch() < 0:
+                        bad.append("fetch")
+                    deferred.append(int(rb.deferred_pairs()))
+                    if int(rb.scores()[0].astype("int64").sum()) != checks[0]:
+                        bad.append("checksum")
+                except Exception as e:      # noqa: BLE001  (the queueing thread must get its batch object back whatever happens)
+                    bad.append(repr(e))
                 free.put(rb)
 
         th = threading.Thread(target=fetcher)
         th.start()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            rb = free.get()
-            if rb.run(p, sync=False) < 0:
-                bad.append("run")
-            todo.put(rb)
-        todo.put(None)
-        th.join()
+        try:
+            for _ in range(steps):
+                rb = free.get(timeout=300)
+                if rb.run(p, sync=False) < 0:
+                    bad.append("run")
+                todo.put(rb)
+        except queue.Empty:
+            bad.append("no batch object came back within 300 s")
+        finally:
+            todo.put(None)
+            th.join(timeout=300)
         dt = time.perf_counter() - t0
     finally:
         for rb in rbs:
