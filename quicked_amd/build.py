@@ -127,7 +127,20 @@ def build_pmc_calib(force=False):
     return PMC_CALIB
 
 
+SEGV_TRACE = os.path.join(ROOT, "tools", "bin", "libsegvtrace.so")
+
+
+def build_segv_trace(force=False):
+    """tools/segv_trace.c: LD_PRELOAD backtrace helper for diagnosis runs on the GPU box (never linked into the library)"""
+    src = os.path.join(ROOT, "tools", "segv_trace.c")
+    os.makedirs(os.path.dirname(SEGV_TRACE), exist_ok=True)
+    if force or _newer(SEGV_TRACE, [src]):
+        _run(["gcc", "-O1", "-g", "-fPIC", "-shared", src, "-o", SEGV_TRACE])
+    return SEGV_TRACE
+
+
 def build_all(force=False):
+    build_segv_trace(force)
     build_datagen(force)
     build_hip(force)
     build_harness(force)

@@ -74,6 +74,10 @@ def lib():
         except Exception as e:           # noqa: BLE001
             raise RuntimeError(f"{path} is missing and could not be built ({e}): run "
                                "`python -c 'import __graft_entry__ as g; g.build()'`; there is no fallback path") from e
+    # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that
+    # share one serialise; a thread's runs rotate over up to 12 stream sets.  The runtime reads the variable when it
+    # initialises, so the embedding application sets it before its first HIP call; this binding is one.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     L = C.CDLL(path)
     L.quicked_check_error.restype = C.c_bool
     L.quicked_check_error.argtypes = [C.c_int]
@@ -134,10 +138,12 @@ def pool_trim():
 
 
 def pool_stats():
-    """quicked_pool_stats of the calling thread: dict(pool_bytes, reclaim_events, sets, sub_batches, pool_budget)"""
+    """quicked_pool_stats of the calling thread: dict(pool_bytes, reclaim_events, sets, sub_batches, pool_budget) plus the
+    process-wide book: bytes all pools of the thread's device hold, contexts in existence, contexts on lease"""
     v = np.zeros(8, dtype=np.int64)
     lib().quicked_pool_stats(v.ctypes.data)
-    return dict(pool_bytes=int(v[0]), reclaim_events=int(v[1]), sets=int(v[2]), sub_batches=int(v[3]), pool_budget=int(v[4]))
+    return dict(pool_bytes=int(v[0]), reclaim_events=int(v[1]), sets=int(v[2]), sub_batches=int(v[3]), pool_budget=int(v[4]),
+                device_pool_bytes=int(v[5]), contexts=int(v[6]), contexts_leased=int(v[7]))
 
 
 def make_params(**kw):

@@ -12,10 +12,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
-#include <csignal>
 #include <deque>
 #include <cstdio>
-#include <execinfo.h>
 #include <unistd.h>
 #include <cstdlib>
 #include <cstring>
@@ -31,504 +29,18 @@
 #include "quicked.h"
 #include "quicked_batch.h"
 #include "qe_types.h"
+#include "qe_pool.h"
 #include "qe_kernels.hip"
 
 #define QE_API extern "C" __attribute__((visibility("default")))
 
 namespace qe {
 
-// ---------------------------------------------------------------------------
-// errors: the C-ABI has no exception channel; a HIP failure is fatal for the
-// call and reported as QUICKED_ERROR with the reason on stderr.
-// ---------------------------------------------------------------------------
-struct HipError { hipError_t e; const char* what; int line; };
-#define HIP_CHECK(expr)                                                             \
-    do {                                                                            \
-        hipError_t e__ = (expr);                                                    \
-        if (e__ != hipSuccess) throw qe::HipError{e__, #expr, __LINE__};            \
-    } while (0)
-
-// ---------------------------------------------------------------------------
-// Device pool: one hipMalloc'd arena per thread and device, carved by a bump
-// pointer from host-side size arithmetic (all scratch sizes are closed-form in
-// plen / tlen / cutoff), reset per batch stage.  Replaces mm_allocator
-// (quicked_utils/src/mm_allocator.c:141-426) on this path.  No device-side
-// malloc, no per-pair hipMalloc.
-// ---------------------------------------------------------------------------
-static bool pool_trace() { static int v = -1; if (v < 0) v = getenv("QE_TRACE_POOL") ? 1 : 0; return v == 1; }
-struct DevicePool {
-    // Chunks keep every pointer handed out during a run valid: when a run needs more than
-    // the arena holds, another chunk is hipMalloc'ed.  The next run repeats the same request
-    // sequence and fits the same chunks, so steady-state runs never allocate.
-    struct Chunk { uint8_t* base; size_t cap; bool used; int idle = 0; };     // used: something was carved from it since the last reset; idle: resets in a row it was not
-    std::vector<Chunk> chunks;
-    size_t cur = 0, top = 0, cap = 0;            // cap = total bytes over all chunks
-    std::atomic<uint64_t> generation{0};         // bumped whenever handed-out pointers stop being valid (reset / release_all); read by fetching threads
-    // A fetch (any thread) copies a queued run's results out of this pool while holding `fetching`; whoever is about to
-    // recycle or free the pool's memory (the owner's next run on this set, the planner, the out-of-memory path) takes it
-    // first, so a fetch in progress finishes on valid memory and a fetch that comes too late sees the new generation
-    std::mutex fetching;
-    // out of memory: the thread's other pools are asked to give theirs back (their runs are waited for first) and the
-    // allocation is tried once more; set by Context
-    static inline bool (*reclaim_fn)(DevicePool* keep) = nullptr;
-    // A request has to fit ONE chunk.  A pool whose chunks date from runs with smaller requests (another budget, other
-    // pairs) skips them and asks for a new one; when the device has no room for that next to them, the chunks this run has
-    // not touched go back first -- their slots stay in the list (empty), so marks taken earlier in the run stay valid.
-    bool drop_unused_chunks() {
-        bool any = false;
-        for (auto& c : chunks)
-            if (!c.used && c.base) {
-                if (pool_trace()) fprintf(stderr, "[qe-pool %p] drop unused chunk %.2f GB\n", (void*)this, c.cap / 1e9);
-                (void)hipFree(c.base); cap -= c.cap; c.base = nullptr; c.cap = 0; any = true;
-            }
-        return any;
-    }
-    void add_chunk(size_t bytes) {
-        Chunk c; c.cap = bytes; c.base = nullptr; c.used = false; c.idle = 0;
-        hipError_t e = hipMalloc((void**)&c.base, bytes);
-        if (e == hipErrorOutOfMemory && drop_unused_chunks()) {
-            (void)hipGetLastError();
-            e = hipMalloc((void**)&c.base, bytes);
-        }
-        if (e == hipErrorOutOfMemory && reclaim_fn && reclaim_fn(this)) {
-            (void)hipGetLastError();
-            e = hipMalloc((void**)&c.base, bytes);
-        }
-        if (e != hipSuccess) throw HipError{e, "hipMalloc((void**)&c.base, bytes)", __LINE__};
-        if (pool_trace()) fprintf(stderr, "[qe-pool %p] + chunk %.2f GB (pool %.2f GB, %zu chunks)\n", (void*)this, bytes / 1e9, (cap + bytes) / 1e9, chunks.size() + 1);
-        chunks.push_back(c);
-        cap += bytes;
-    }
-    void reset() {
-        if (chunks.size() > 24) {     // a run repeats its request sequence, so the same chunks fit again: fold only on runaway growth
-            HIP_CHECK(hipDeviceSynchronize());
-            const size_t total = cap;
-            for (auto& c : chunks) HIP_CHECK(hipFree(c.base));
-            chunks.clear(); cap = 0;
-            add_chunk(total);
-        }
-        std::lock_guard<std::mutex> lk(fetching);
-        // Chunks that date from another workload (other pairs, another estimate: their sizes fit none of this run sequence's
-        // requests) go back to the device after QE_POOL_IDLE (8) runs in a row without use when memory is short -- before, they stayed until an
-        // out-of-memory reclaim found them (a pool set grew from 16 to 54 GB when mixed batches followed uniform ones).
-        // hipFree synchronises the device: once per stale chunk.
-        static const int idle_max = [] { const char* e = getenv("QE_POOL_IDLE"); return e ? atoi(e) : 8; }();
-        for (auto& c : chunks) {
-            if (c.used || !c.base) { c.idle = 0; continue; }
-            if (++c.idle >= idle_max && idle_max > 0 && chunks.size() > 1) {
-                // ... while the device is short of memory (less than a quarter free): hipFree waits for everything in
-                // flight, which a session with room to spare should not pay for
-                size_t free_b = 0, total_b = 0;
-                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= total_b / 4) { c.idle = idle_max / 2; continue; }
-                if (pool_trace()) fprintf(stderr, "[qe-pool %p] stale chunk %.2f GB goes back\n", (void*)this, c.cap / 1e9);
-                (void)hipFree(c.base); cap -= c.cap; c.base = nullptr; c.cap = 0;
-            }
-        }
-        chunks.erase(std::remove_if(chunks.begin(), chunks.end(), [](const Chunk& c) { return c.cap == 0; }), chunks.end());
-        for (auto& c : chunks) c.used = false;
-        cur = 0; top = 0; ++generation;
-    }
-    struct Mark { size_t cur, top; };
-    Mark mark() const { return Mark{cur, top}; }
-    void release(Mark m) { cur = m.cur; top = m.top; }
-    template <typename T> T* take(size_t count) {
-        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
-        if (chunks.empty()) add_chunk(std::max(bytes, (size_t)1 << 26));
-        while (chunks[cur].cap - top < bytes) {
-            if (cur + 1 == chunks.size())
-                add_chunk(std::max(bytes + ((size_t)1 << 20), std::min(std::max(cap / 4, (size_t)1 << 26), (size_t)1 << 32)));
-            ++cur; top = 0;
-        }
-        chunks[cur].used = true;
-        T* p = (T*)(chunks[cur].base + top);
-        top += bytes;
-        return p;
-    }
-    // One allocation up front for a run whose needs are known (the planner's figures): bump requests then never grow the
-    // pool 4 GB at a time (a 94 GB fill matrix used to cost ~25 hipMallocs and seconds on a batch's first runs)
-    void reserve(size_t bytes) {
-        size_t room = 0;
-        for (size_t i = cur; i < chunks.size(); ++i) room += (i == cur) ? chunks[i].cap - top : chunks[i].cap;
-        if (room >= bytes) return;
-        add_chunk(bytes - room + ((size_t)64 << 20));
-    }
-    // Grow to the chunk list of a pool that serves the same request sequence (the other A pool), so that the run
-    // which first uses this one does not pay for its allocations; skipped when memory is short.
-    void mirror(const DevicePool& o) {
-        for (size_t i = chunks.size(); i < o.chunks.size(); ++i) {
-            size_t free_b = 0, total_b = 0;
-            if (o.chunks[i].cap == 0) continue;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * o.chunks[i].cap) return;
-            add_chunk(o.chunks[i].cap);
-        }
-    }
-    void release_all() {
-        std::lock_guard<std::mutex> lk(fetching);
-        if (pool_trace() && cap) fprintf(stderr, "[qe-pool %p] release_all %.2f GB\n", (void*)this, cap / 1e9);
-        for (auto& c : chunks) if (c.base) (void)hipFree(c.base);
-        chunks.clear(); cap = 0; cur = 0; top = 0; ++generation;
-    }
-    // the out-of-memory path must not wait for a fetch that may itself be waiting for memory: skip a pool that is being read
-    bool try_release_all() {
-        std::unique_lock<std::mutex> lk(fetching, std::try_to_lock);
-        if (!lk.owns_lock()) return false;
-        for (auto& c : chunks) if (c.base) (void)hipFree(c.base);
-        chunks.clear(); cap = 0; cur = 0; top = 0; ++generation;
-        return true;
-    }
-    size_t used_hint() const { return cap; }
-    size_t largest_chunk() const { size_t m = 0; for (const auto& c : chunks) m = std::max(m, c.cap); return m; }
-    ~DevicePool() { for (auto& c : chunks) if (c.base) (void)hipFree(c.base); }
-};
-
-// carves a fixed arena (a batch's persistent buffers)
-struct ArenaCarver {
-    uint8_t* base; size_t top;
-    template <typename T> T* take(size_t count) {
-        T* p = (T*)(base + top);
-        top += (count * sizeof(T) + 255) & ~(size_t)255;
-        return p;
-    }
-};
-
-// Pinned host staging for the small per-run uploads (task lists, layouts).  A hipMemcpyAsync from pageable memory
-// returns only when the copy has been performed, i.e. when the stream has reached it -- which puts the host to sleep
-// behind run k-2 every time it queues run k.  Staged through pinned memory the copy is truly asynchronous; a stage is
-// reused only after the run that filled it is over (there are 2 x NA of them, so that run is NA runs back).
-struct PinnedStage {
-    struct Chunk { uint8_t* base; size_t cap; };
-    std::vector<Chunk> chunks;
-    size_t cur = 0, top = 0;
-    hipEvent_t done = nullptr;          // end of the run that used this stage last
-    bool pending = false;
-    void reset() {
-        if (pending) { HIP_CHECK(hipEventSynchronize(done)); pending = false; }
-        cur = 0; top = 0;
-    }
-    uint8_t* take(size_t bytes) {
-        bytes = (bytes + 63) & ~(size_t)63;
-        if (chunks.empty() || chunks[cur].cap - top < bytes) {
-            while (cur + 1 < chunks.size() && chunks[cur + 1].cap < bytes) ++cur;
-            if (!chunks.empty() && cur + 1 < chunks.size()) { ++cur; top = 0; }
-            else {
-                Chunk c; c.cap = std::max(bytes, (size_t)8 << 20); c.base = nullptr;
-                HIP_CHECK(hipHostMalloc((void**)&c.base, c.cap, hipHostMallocDefault));
-                chunks.push_back(c); cur = chunks.size() - 1; top = 0;
-            }
-        }
-        uint8_t* p = chunks[cur].base + top;
-        top += bytes;
-        return p;
-    }
-};
-
-// ---------------------------------------------------------------------------
-// Process-wide HBM ledger.  The reference runs one aligner per host thread (align_benchmark.c:246-249), each with an arena
-// that grows on demand (mm_allocator.c:251-334); here every thread's Context plans its device pools BEFORE a run, and two
-// threads that each plan against the whole device would meet in the out-of-memory path.  Every Context keeps an entry --
-// what its A pools hold, what it has planned to let them hold -- and a planning thread sees the others': it may plan with
-// what is free plus what it holds itself, minus what the others have planned but not allocated yet, where no other
-// context can claim more than an equal share of the device's pool space.
-// ---------------------------------------------------------------------------
-struct LedgerEntry { int device = 0; size_t held = 0, planned = 0, wanted = 0; uint64_t plans = 0; double last_plan_ms = -1e18, last_create_ms = -1e18; };
-static std::mutex g_ledger_mu;
-static std::vector<LedgerEntry*> g_ledger;
-static double ledger_now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
-// -> bytes this context's A pools may hold together.  `wanted`: what they would grow to if the device were this thread's
-// alone.  Another context counts as a claimant while it is at work (it planned a run within the last two seconds) or
-// about to be (it created a batch object within the last ten and has not run it yet); a claimant is granted what it
-// wants, up to an equal share of the device where the wishes add up to more than there is; an idle context keeps what
-// its pools hold and no more.  Contexts re-plan before every run, so a thread that had the device to itself is down to
-// its share one run after a second one shows up.
-static size_t ledger_plan(LedgerEntry* me, size_t free_now, size_t my_held, size_t wanted) {
-    std::lock_guard<std::mutex> lk(g_ledger_mu);
-    const double now = ledger_now_ms();
-    me->held = my_held;
-    me->wanted = wanted;
-    auto claimant = [&](const LedgerEntry* e) {
-        return (e->plans > 0 && now - e->last_plan_ms < 2000.0) || (now - e->last_create_ms < 10000.0 && e->last_create_ms > e->last_plan_ms);
-    };
-    size_t all_held = 0, n_active = 1;
-    for (const LedgerEntry* e : g_ledger) {
-        if (e->device != me->device) continue;
-        all_held += e->held;
-        if (e != me && claimant(e)) ++n_active;
-    }
-    const double space = 0.92 * (double)(free_now + all_held);          // what all pools of this device may hold together
-    double others = 0;
-    for (const LedgerEntry* e : g_ledger) {
-        if (e->device != me->device || e == me) continue;
-        double claim = 0;
-        if (claimant(e)) {
-            const bool knows = e->plans > 0 && e->last_plan_ms > e->last_create_ms;       // its wish is that of the batch it is running
-            claim = std::min(knows ? (double)e->wanted : space, space / (double)n_active);
-        }
-        others += std::max((double)e->held, claim);
-    }
-    const size_t mine = (size_t)std::max(space - others, (double)((size_t)2 << 30));
-    me->planned = std::min(mine, wanted);
-    ++me->plans;
-    me->last_plan_ms = now;
-    return mine;
-}
-static void ledger_note_create(LedgerEntry* me) {
-    std::lock_guard<std::mutex> lk(g_ledger_mu);
-    me->last_create_ms = ledger_now_ms();
-}
-
-struct Context {
-    int device = 0;
-    LedgerEntry ledger;
-    bool registered = false;
-    // a worker thread that ends gives its device memory back (the reference's per-thread aligner frees its arena in
-    // quicked_free, quicked.c:371-375; here the pools belong to the thread, not to an aligner).  The Context object itself
-    // stays: a run this thread queued may still be fetched by another thread, whose PendingFetch points at one of the
-    // pools -- it finds the pool empty and a newer generation, and fails cleanly.
-    void leave_ledger() {
-        if (registered) {
-            std::lock_guard<std::mutex> lk(g_ledger_mu);
-            g_ledger.erase(std::remove(g_ledger.begin(), g_ledger.end(), &ledger), g_ledger.end());
-            registered = false;
-        }
-    }
-    void retire() {
-        leave_ledger();
-        if (!stream) return;
-        if (hipSetDevice(device) != hipSuccess) return;
-        (void)hipStreamSynchronize(stream_w);
-        for (auto q : stream_a2) if (q) (void)hipStreamSynchronize(q);
-        for (auto& st : stage) { for (auto& c : st.chunks) (void)hipHostFree(c.base); if (st.done) (void)hipEventDestroy(st.done); }
-        for (auto& e : kev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-        for (auto e : {ev_pack, ev_stage, ev0, ev1}) if (e) (void)hipEventDestroy(e);
-        for (auto e : ev_decided) if (e) (void)hipEventDestroy(e);
-        for (auto& q : pool_a2) q.release_all();
-        for (auto& q : pool_w2) q.release_all();
-        pool_w.release_all();
-        for (auto q : stream_a2) if (q) (void)hipStreamDestroy(q);
-        (void)hipStreamDestroy(stream_w);
-        stream = nullptr; registered = false;
-    }
-    // Two phases of a run use two streams and two pools so that consecutive runs pipeline:
-    //   W: pack + bound stages (WindowEd, band doubling)      A: the BandEd kernels (score / fill / traceback / format)
-    // Run k+1's W phase overlaps run k's A phase (different resources: W is latency / VALU-light, A is
-    // VALU- or HBM-bound); a batch double-buffers its planes for that.
-    // Consecutive runs alternate between two A streams / pools: a 100 k-pair kernel fills 391 of the 512 workgroup
-    // slots launch_groups() allows, and the next run's kernel takes the other 121 at once instead of waiting.
-    // Up to NA sets of {W stream + pool, A stream + pool, pinned stages} rotate between the consecutive runs of a thread;
-    // a batch object has as many plane sets.  Large batches use three (a 100 k-pair kernel nearly fills the chip: more in
-    // flight only queue); small ones as many as it takes to keep ~2 waves on every SIMD (plan in run_batch): a 12.5 k-pair
-    // run is 196 waves of ~11 ms each, the chip holds 2048.
-    static constexpr int NA = 12;
-    hipStream_t stream_w = nullptr;          // utility stream: loads, fetches, the validator -- everything outside a run
-    hipStream_t stream_w2[NA] = {}, stream_a2[NA] = {};
-    hipStream_t stream = nullptr;            // where the current phase launches
-    // fork-join helper: the reverse half passes of a Hirschberg level run next to the forward ones (two 5000-wave launches
-    // on one stream each end in a tail of their own; side by side the chip stays full until both are nearly done)
-    hipStream_t stream_x = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t side_stream() {
-        if (!stream_x) {
-            HIP_CHECK(hipStreamCreateWithFlags(&stream_x, hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        }
-        return stream_x;
-    }
-    DevicePool pool_w, pool_w2[NA], pool_a2[NA];
-    int ai = 0;                              // which set the current run uses
-    PinnedStage stage[2 * NA];               // see PinnedStage
-    int si = 0;
-    bool staging = false;                    // uploads on the current A stream go through stage[si]
-    // a pool had to take the others' memory: no rotation and no fast flow on this thread -- for a while.  A workload change in
-    // the middle of a session (other pairs, another estimate: the pools' chunks stop fitting) ends in the same reclaim as a
-    // device that is really too small; only the second keeps coming back.  tight_left runs with one set, then the plan is
-    // tried again; every further event doubles the spell (16 .. 1024 runs).
-    bool memory_tight = false;
-    int tight_left = 0, tight_spell = 16;
-    int last_na = 0, last_sub_batches = 0;   // what the planner chose for the last run (quicked_pool_stats)
-    int in_flight = 1;                       // runs of this thread that may be on the device at once while the current one executes
-    size_t pool_budget = 0;                  // bytes one A pool may hold in this run (plan_pools)
-    size_t seen_free = 0, seen_total = 0;    // last hipMemGetInfo reading of this device
-    hipStream_t& sa() { return stream_a2[ai]; }
-    DevicePool& pa() { return pool_a2[ai]; }
-    hipStream_t& sw() { return stream_w2[ai]; }
-    DevicePool& pw() { return pool_w2[ai]; }
-    DevicePool* scratch_p = nullptr;         // the current phase's pool
-    hipEvent_t ev_pack = nullptr, ev_stage = nullptr, ev_decided[NA] = {};
-    bool decided_set[NA] = {};               // the set's last run's k_stage1_decide (stream A) still reads its W pool: the set's next W phase waits for it
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // HIP-event pairs around the dominant kernel of every run since the last collection (bench.py's roofline leg)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
-    size_t kev_used = 0;
-    std::pair<hipEvent_t, hipEvent_t>* kernel_events() {
-        if (kev_used >= 4096) return nullptr;
-        if (kev_used == kev.size()) {
-            hipEvent_t a, b;
-            HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-            kev.emplace_back(a, b);
-        }
-        return &kev[kev_used++];
-    }
-    void phase_w() { ensure_set(ai); stream = sw(); scratch_p = &pw(); }
-    void phase_a() { ensure_set(ai); stream = sa(); scratch_p = &pa(); }
-    void phase_u() { stream = stream_w; scratch_p = &pool_w; }
-    void sync_all() {
-        HIP_CHECK(hipStreamSynchronize(stream_w));
-        if (stream_x) HIP_CHECK(hipStreamSynchronize(stream_x));
-        for (auto q : stream_a2) if (q) HIP_CHECK(hipStreamSynchronize(q));
-    }
-    // A set's stream is created when the rotation first reaches it: a thread that only loads and fetches (an uploader, a
-    // fetcher) has the utility stream and nothing else, a thread that runs large batches four streams -- the runtime maps
-    // all streams of the process onto GPU_MAX_HW_QUEUES hardware queues, and streams that share one serialise.
-    // A run's W phase and A phase depend on each other (pack -> bound stages -> align step): one stream serves both;
-    // consecutive runs are on different sets, that is where the overlap comes from.
-    void ensure_set(int q) {
-        if (stream_a2[q]) return;
-        HIP_CHECK(hipStreamCreateWithFlags(&stream_a2[q], hipStreamNonBlocking));
-        stream_w2[q] = stream_a2[q];
-    }
-    void init() {
-        if (stream) return;
-        HIP_CHECK(hipSetDevice(device));
-        { std::lock_guard<std::mutex> lk(g_ledger_mu); ledger.device = device; g_ledger.push_back(&ledger); }
-        registered = true;
-        HIP_CHECK(hipStreamCreateWithFlags(&stream_w, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
-        for (auto& e : ev_decided) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        phase_u();
-        HIP_CHECK(hipEventCreate(&ev0));
-        HIP_CHECK(hipEventCreate(&ev1));
-    }
-};
 // the aligner's stage timers (quicked.h:61-66) while one of its calls is running
 struct HostTimers { profiler_timer_t *windowed_s = nullptr, *windowed_l = nullptr, *banded = nullptr, *align = nullptr; };
 static thread_local HostTimers tl_timers;
 static void qe_timer_start(profiler_timer_t* t);
 static void qe_timer_stop(profiler_timer_t* t);
-static thread_local Context* tl_ctx = nullptr;
-static bool reclaim_pools(DevicePool* keep);
-static thread_local DevicePool* tl_fetch_hold = nullptr;     // the pool whose `fetching` lock this thread holds (fetch_pending)
-static thread_local int tl_device = 0;
-// one Context per (host thread, device): a thread that alternates between devices keeps both (streams, pools and
-// pinned stages of the device it left stay where they are)
-static const std::thread::id g_main_thread = std::this_thread::get_id();
-// Contexts of host threads that have ended.  A thread_local destructor must not call into HIP -- the runtime's own per-thread
-// state may have been destroyed before ours (destruction order follows construction order, which depends on which HIP
-// call of the thread came first): hipEventDestroy from ~ContextList crashed once in a few runs.  So an ending thread only
-// takes its contexts out of the ledger and parks them here; the next live thread that creates a context, plans a run,
-// trims its pools or runs out of memory releases what they hold (reap_orphans).
-static std::mutex g_orphans_mu;
-static std::vector<Context*> g_orphans;
-struct ContextList {
-    std::vector<Context*> v;
-    // the main thread's contexts live until the process ends (tearing HIP objects down during static destruction races the
-    // runtime's own shutdown)
-    ~ContextList() {
-        if (std::this_thread::get_id() == g_main_thread) return;
-        for (Context* c : v) c->leave_ledger();
-        std::lock_guard<std::mutex> lk(g_orphans_mu);
-        g_orphans.insert(g_orphans.end(), v.begin(), v.end());
-    }
-};
-static void reap_orphans() {
-    std::vector<Context*> dead;
-    {
-        std::lock_guard<std::mutex> lk(g_orphans_mu);
-        if (g_orphans.empty()) return;
-        dead.swap(g_orphans);
-    }
-    int dev = 0;
-    const bool have_dev = hipGetDevice(&dev) == hipSuccess;
-    for (Context* c : dead) c->retire();          // waits for whatever the thread left queued, then frees pools / stages / streams
-    if (have_dev) (void)hipSetDevice(dev);
-}
-static thread_local ContextList tl_ctx_list;
-#define tl_ctx_all tl_ctx_list.v
-static thread_local int tl_bound_device = -1;
-static Context& ctx() {
-    if (!tl_ctx || tl_ctx->device != tl_device) {
-        tl_ctx = nullptr;
-        for (Context* c : tl_ctx_all) if (c->device == tl_device) tl_ctx = c;
-        if (!tl_ctx) {
-            reap_orphans();
-            tl_ctx = new Context();   // lives for the thread; one per device it uses
-            tl_ctx->device = tl_device;
-            tl_ctx_all.push_back(tl_ctx);
-        }
-    }
-    if (tl_bound_device != tl_device) { HIP_CHECK(hipSetDevice(tl_device)); tl_bound_device = tl_device; }
-    tl_ctx->init();
-    DevicePool::reclaim_fn = &reclaim_pools;
-    return *tl_ctx;
-}
-
-// DevicePool::reclaim_fn: every pool of this thread's context except `keep` is emptied after its stream has drained
-static std::atomic<int64_t> g_reclaim_events{0};
-static bool reclaim_pools(DevicePool* keep) {
-    Context* C = tl_ctx;
-    if (!C) return false;
-    bool freed = false;
-    {   // what ended threads left behind comes first
-        bool any;
-        { std::lock_guard<std::mutex> lk(g_orphans_mu); any = !g_orphans.empty(); }
-        if (any) { reap_orphans(); if (C->device != tl_bound_device) (void)hipSetDevice(C->device); freed = true; }
-    }
-    C->memory_tight = true;
-    C->tight_left = C->tight_spell;
-    C->tight_spell = std::min(2 * C->tight_spell, 1024);
-    ++g_reclaim_events;
-    for (int q = 0; q < Context::NA; ++q) {
-        if (&C->pool_a2[q] != keep && &C->pool_a2[q] != tl_fetch_hold && C->pool_a2[q].cap != 0) {
-            if (C->stream_a2[q] && hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
-            freed |= C->pool_a2[q].try_release_all();
-        }
-        // a W pool of another set (its run, if any, is waited for; the current run's own W pool is still being read)
-        if (&C->pool_w2[q] != keep && C->pool_w2[q].cap > ((size_t)1 << 28) && q != C->ai) {
-            if (C->stream_a2[q] && hipStreamSynchronize(C->stream_a2[q]) != hipSuccess) return false;
-            freed |= C->pool_w2[q].try_release_all();
-        }
-    }
-    if (&C->pool_w != keep && C->pool_w.cap > ((size_t)1 << 30) && C->scratch_p != &C->pool_w) {
-        if (hipStreamSynchronize(C->stream_w) != hipSuccess) return false;
-        freed |= C->pool_w.try_release_all();
-    }
-    return freed;
-}
-
-// hipMalloc outside the pools (a batch's arena, its result arena): out of memory gets the same second chance as a pool's
-// chunk -- this thread's other pools (all but `keep`) and what ended threads left behind go back first
-static void device_malloc_retry(void** p, size_t bytes, DevicePool* keep, const char* what, int line) {
-    hipError_t e = hipMalloc(p, bytes);
-    if (e == hipErrorOutOfMemory) {
-        (void)hipGetLastError();
-        if (DevicePool::reclaim_fn && DevicePool::reclaim_fn(keep)) e = hipMalloc(p, bytes);
-    }
-    if (e != hipSuccess) throw HipError{e, what, line};
-}
-
-// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that
-// share a queue serialise.  A thread's runs rotate over up to NA sets of two streams, so that small batches can have many
-// runs on the device at once: ask for more queues unless the user has chosen a value.  Read by the runtime when it
-// initialises (the first HIP call of the process), so this has to happen at load time; a process that has already
-// initialised HIP keeps what it has.  24: a thread's rotation is up to 14 streams (12 sets, the utility and
-// the side stream) and the three early-finish threads use three each -- with 16 queues, streams of the rotation that were
-// created after theirs landed on shared queues about every other process (a stream of 12.5 k-pair batches at 4.2 instead
-// of 6.2 M alignments/s); 32 and 64 are no better than 24.
-__attribute__((constructor)) static void qe_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
-// QE_SEGV_TRACE=1: a native backtrace (module + offset: addr2line -e libquicked_hip.so) on SIGSEGV / SIGABRT, then the default action
-static void qe_segv_trace(int sig) {
-    void* frames[64];
-    const int n = backtrace(frames, 64);
-    const char msg[] = "[quicked_hip] fatal signal, native backtrace:\n";
-    (void)!write(2, msg, sizeof(msg) - 1);
-    backtrace_symbols_fd(frames, n, 2);
-    signal(sig, SIG_DFL);
-    raise(sig);
-}
-__attribute__((constructor)) static void qe_install_segv_trace() {
-    if (getenv("QE_SEGV_TRACE")) { signal(SIGSEGV, qe_segv_trace); signal(SIGABRT, qe_segv_trace); }
-}
 
 // one in-stream copy as a kernel (see k_copy_multi); both buffers are padded to 16 bytes (pool / arena / stage allocations are)
 static void copy_kernel(void* dst, const void* src, size_t bytes, hipStream_t s) {
@@ -601,20 +113,21 @@ struct quicked_batch {
     u32* d_flags[NP] = {};
     int parity = 0;
     int np_used = 2;                              // plane sets in rotation = stream / pool sets in rotation (run_batch)
+    int last_parity = -1;                         // plane set of the last run queued (its end orders the next run's stash)
     size_t last_mat_bytes = 0;                    // fill matrices of this batch's last CIGAR run (all leaves at once)
     size_t last_fixed_bytes = 0;                  // everything else its align stage took from the pool (runs, strings, workspaces)
     int last_groups = 0;                          // 64-task groups of that stage
-    int64_t deferred_pairs = 0;                   // QuickEd: pairs of the last fetched run that were aligned at fetch time (quicked_batch_deferred_pairs)
     int est_bound = 0;                            // QuickEd: the cutoff the next run's align buffers are sized for (0: none yet, < 0: classic flow only)
     hipEvent_t ev_done[NP] = {};    // end of the A phase of the last run that used this parity
     bool ev_done_set[NP] = {};
     size_t pl_p_words = 0, pl_t_words = 0;
     bool have_rev[NP] = {};
-    // results of the last run, host side, indexed by pair
-    std::vector<int32_t> score, status;
-    std::vector<int64_t> cigar_off;
-    // the CIGAR strings of the last fetched run, in pinned host memory: one DMA from the device's string pool, no per-pair
-    // copies (a 100 k x 10 kb batch has ~400 MB of them)
+    // Results on the host, indexed by pair.  Two sets: the getters read res[vis]; whoever brings a run's results to the host
+    // writes through `wr` -- the caller's own sync run / fetch into the visible set, an early-finish thread (qe::finisher_*)
+    // into the other one, which the caller's quicked_batch_fetch then makes visible (shadow_ready).  So a queued run never
+    // changes what the getters and the zero-copy views show until the caller fetches.
+    // The CIGAR strings live in pinned host memory: one DMA from the device's string pool, no per-pair copies (a
+    // 100 k x 10 kb batch has ~400 MB of them)
     struct PinnedBuf {
         char* p = nullptr; size_t size = 0, cap = 0;
         void reserve(size_t n) {
@@ -627,13 +140,24 @@ struct quicked_batch {
             p = q; cap = ncap;
         }
         ~PinnedBuf() { if (p) (void)hipHostFree(p); }
-    } cigar_pool;
+    };
+    struct HostResults {
+        std::vector<int32_t> score, status;
+        std::vector<int64_t> cigar_off;
+        PinnedBuf cigar_pool;
+        std::vector<int32_t> check_ok;            // 1 valid, 0 not, -1 no alignment
+        int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t deferred_pairs = 0;               // QuickEd: pairs that were aligned after the run (quicked_batch_deferred_pairs)
+        void clear() { score.clear(); status.clear(); cigar_off.clear(); cigar_pool.size = 0; check_ok.clear(); deferred_pairs = 0; for (auto& c : counters) c = 0; }
+    } res[2];
+    int vis = 0;
+    HostResults* wr = &res[0];
+    bool shadow_ready = false;
     bool only_score_run = true;
     bool packed = false;                          // created from wire words: planes are the resident input, no ASCII, no k_pack
     int cigar_style = 0;                          // SegFormatArgs::style of the runs to come (quicked_batch_configure)
     bool check = false;                           // validate every CIGAR on the device (k_check_segs)
-    std::vector<int32_t> check_ok;                // last run: 1 valid, 0 not, -1 no alignment
-    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // of the run being queued / fetched (copied to wr->counters at its end)
     // results of the last run, device side, indexed by task (what a timed run leaves in HBM)
     int32_t* d_score = nullptr;
     bool pending = false;
@@ -661,8 +185,8 @@ struct quicked_batch {
     quicked_status_t fin_status = QUICKED_OK;     // what an early finish of the current results returned
 
     ~quicked_batch() {
-        if (arena) (void)hipFree(arena);
-        if (result_arena) (void)hipFree(result_arena);
+        qe::device_free(arena, device);
+        qe::device_free(result_arena, device);
         for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
         if (ev_unpacked) (void)hipEventDestroy(ev_unpacked);
     }
@@ -691,7 +215,6 @@ static PairView pair_view(const quicked_batch& B, bool reversed) {
 // kernels and streams they come from.  A second kernel on another stream then fills exactly the SIMD
 // slots the first one left empty, at no cost to either.  QE_WG_WAVES / QE_PIN_LDS override the shape.
 // ---------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 template <typename Kernel, typename Args>
 static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ngroups, int max_waves, size_t lds_per_wave, bool chain = false) {
     if (ngroups == 0) return;
@@ -1064,8 +587,7 @@ struct AlignOut {                             // device, per root
 };
 
 // Results of a sync == 0 run, still on the device: what quicked_batch_fetch() copies once the run is over.  The device
-// pointers live in the A pool of the thread that queued the run and stay valid until that pool comes round again in the
-// thread's rotation (`generation` tells): at most two more runs may be queued by that thread before the fetch.
+// pointers are those of the batch's result arena (stash_results): valid until the batch's next run, reload or destroy.
 struct PendingFetch {
     int kind = 0;                             // 1: one score per task (score-only BandEd / WindowEd); 2: alignments (segments)
     quicked_status_t ok_status = QUICKED_WIP;
@@ -1083,9 +605,7 @@ struct PendingFetch {
     bool fast = false;
     const int32_t* d_cut = nullptr; const int32_t* d_skip = nullptr; const u32* d_stage_steps = nullptr;
     quicked_params_t params; TaskList L; size_t matrix_budget = 0;
-    // validity
-    DevicePool* pool = nullptr; uint64_t generation = 0; int parity = 0;
-    bool stashed = false;                     // the results were moved to the batch's result arena: valid until the batch's next run
+    int parity = 0;                           // the plane set / ev_done slot of the run
 };
 
 // One wavefront per alignment (k_banded_wave) is for few, long alignments: up to ~1000 tasks every task gets a wave of its
@@ -1208,21 +728,21 @@ static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, co
     HIP_CHECK(hipStreamSynchronize(C.stream));
     int64_t total = 0;
     if (want_strings) for (size_t i = 0; i < A.nroots; ++i) total = std::max<int64_t>(total, off[i] + len[i] + 1);
-    const size_t base = B.cigar_pool.size;
+    const size_t base = B.wr->cigar_pool.size;
     if (total) {
-        B.cigar_pool.reserve(base + (size_t)total);
-        HIP_CHECK(hipMemcpyAsync(B.cigar_pool.p + base, A.pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
+        B.wr->cigar_pool.reserve(base + (size_t)total);
+        HIP_CHECK(hipMemcpyAsync(B.wr->cigar_pool.p + base, A.pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
         HIP_CHECK(hipStreamSynchronize(C.stream));
-        B.cigar_pool.size = base + (size_t)total;
+        B.wr->cigar_pool.size = base + (size_t)total;
     }
     for (size_t i = 0; i < A.nroots; ++i) {
         const int pr = SL.root_pair[i];
-        B.score[pr] = edits[i];
-        B.status[pr] = root_status ? (*root_status)[i] : ok_status;
-        if (edits[i] < 0) { B.score[pr] = -1; B.status[pr] = QUICKED_ERROR; }      // run-buffer overflow: cutoff below the distance
+        B.wr->score[pr] = edits[i];
+        B.wr->status[pr] = root_status ? (*root_status)[i] : ok_status;
+        if (edits[i] < 0) { B.wr->score[pr] = -1; B.wr->status[pr] = QUICKED_ERROR; }      // run-buffer overflow: cutoff below the distance
         B.counters[4] += nops[i];
-        if (A.ok) B.check_ok[pr] = okv[i];
-        if (want_strings && len[i] > 0) B.cigar_off[pr] = (int64_t)base + off[i];      // NUL-terminated in the pool
+        if (A.ok) B.wr->check_ok[pr] = okv[i];
+        if (want_strings && len[i] > 0) B.wr->cigar_off[pr] = (int64_t)base + off[i];      // NUL-terminated in the pool
     }
 }
 
@@ -1307,12 +827,12 @@ static bool trace_on() { static int v = -1; if (v < 0) v = getenv("QE_TRACE") ? 
 #define QE_TRACE_POINT(name) do { if (trace_on()) { double t__ = now_ms(); fprintf(stderr, "[qe] %-22s +%.3f ms\n", name, t__ - tr_last); tr_last = t__; } } while (0)
 
 static void reset_host_results(quicked_batch& B) {
-    B.score.assign((size_t)B.n, -1);
-    B.status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
-    B.cigar_off.assign((size_t)B.n, -1);
-    B.cigar_pool.size = 0;
-    B.check_ok.assign((size_t)B.n, -1);
-    B.deferred_pairs = 0;
+    B.wr->score.assign((size_t)B.n, -1);
+    B.wr->status.assign((size_t)B.n, QUICKED_EMPTY_SEQUENCE);
+    B.wr->cigar_off.assign((size_t)B.n, -1);
+    B.wr->cigar_pool.size = 0;
+    B.wr->check_ok.assign((size_t)B.n, -1);
+    B.wr->deferred_pairs = 0;
 }
 
 struct HNode { int32_t pair, p0, m, t0, n, cutoff, left, right, leaf_task; };
@@ -1615,8 +1135,8 @@ static void scatter_scores(quicked_batch& B, const TaskList& L, const std::vecto
     for (size_t t = 0; t < L.pair.size(); ++t) {
         const int pr = L.pair[t];
         if (pr < 0) continue;
-        B.score[pr] = s[t];
-        B.status[pr] = ok_status;
+        B.wr->score[pr] = s[t];
+        B.wr->status[pr] = ok_status;
     }
 }
 
@@ -1800,7 +1320,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
     QE_TRACE_POINT("align launch(+fetch)");
     B.counters[0] += (int64_t)AS.score_adv; B.counters[1] += (int64_t)AS.fill_adv; B.counters[3] += (int64_t)AS.tb_steps;
     if (fetch && p.algo == QUICKED)
-        for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+        for (auto& st : B.wr->status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
 }
 
 // ---------------------------------------------------------------------------
@@ -1847,7 +1367,7 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
         B.counters[2] += steps[t];
     }
     B.est_bound = quicked_estimate(stage1_bounds);
-    B.deferred_pairs = (int64_t)Ls.pair.size();
+    B.wr->deferred_pairs = (int64_t)Ls.pair.size();
     if (Ls.pair.empty()) return;
     Ls.pad();
     K1.score.resize(Ls.pair.size(), 0); K1.stage2.resize(Ls.pair.size(), 0);
@@ -1866,6 +1386,15 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     // on the fast flow's (76 k of 100 k indel-heavy pairs: 100 GB on top of 170 GB did not fit)
     C.pw().release(DevicePool::Mark{0, 0});
     C.pa().release(DevicePool::Mark{0, 0});
+    // the budget is planned again, in THIS context (the caller's fetch, or an early-finish thread's): what the queueing
+    // thread's plan allowed one of its pools is an upper limit, the book decides what is there now
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const size_t mine = ledger_plan(&C, free_b, matrix_budget + ((size_t)1 << 30));
+        const size_t other_pools = C.held.load() - std::min(C.held.load(), C.pa().cap + C.pw().cap);
+        matrix_budget = std::min(matrix_budget, std::max(mine > other_pools ? mine - other_pools : (size_t)0, (size_t)256 << 20));
+    }
     C.phase_w();
     auto enter_a = [&]() { C.phase_a(); };
     quicked_classic(B, C, p, Ls, true, matrix_budget, nullptr, enter_a, false, &K1);
@@ -1894,9 +1423,9 @@ static void stash_results(quicked_batch& B, Context& C, PendingFetch& F) {
     for (const StashItem& it : items) need += (it.bytes + 255) & ~(size_t)255;
     if (strings) need += ((F.AO.pool_bytes + 255) & ~(size_t)255) + 256;
     if (B.result_bytes < need) {
-        if (B.result_arena) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(B.result_arena)); B.result_arena = nullptr; B.result_bytes = 0; }
+        if (B.result_arena) { HIP_CHECK(hipDeviceSynchronize()); device_free(B.result_arena, B.device); B.result_arena = nullptr; B.result_bytes = 0; }
         const size_t cap = need + need / 8;
-        device_malloc_retry((void**)&B.result_arena, cap, &C.pa(), "hipMalloc((void**)&B.result_arena, cap)", __LINE__);
+        device_malloc((void**)&B.result_arena, cap, C.device, &C.pa(), "hipMalloc(batch result arena)", __LINE__);
         B.result_bytes = cap;
     }
     size_t top = 0;
@@ -1929,14 +1458,12 @@ static void stash_results(quicked_batch& B, Context& C, PendingFetch& F) {
         F.AO.total = d_total; F.AO.pool = dst;
     }
     flush();
-    F.stashed = true;
 }
 
 // sets of {streams, pools, planes} that rotate for a batch of n pairs: enough runs in flight for ~2048 waves (two per SIMD)
 static int rotation_depth(int64_t n, int floor_sets = 5) {
     const int64_t groups = std::max<int64_t>(1, (n + 63) / 64);
-    static const int min_env = env_int("QE_NP_MIN", 0);           // experiments
-    return (int)std::max<int64_t>(min_env > 0 ? min_env : floor_sets, std::min<int64_t>(Context::NA, (2048 + groups - 1) / groups));
+    return (int)std::max<int64_t>(floor_sets, std::min<int64_t>(Context::NA, (2048 + groups - 1) / groups));
 }
 
 static void finisher_submit(quicked_batch& B, const std::shared_ptr<void>& pf);
@@ -1956,12 +1483,21 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // BandEd, 4.70 -> 5.31 M/s QuickEd + CIGAR against two; four are slower again).  Two when three fill matrices of the
     // size this batch needed last time would not fit (config 4: 94 GB each): sub-batching the fill costs more.
     static const int na_env = env_int("QE_NA", 0);
-    // small batches (single quicked_align calls) plan with the last reading: the query costs tens of microseconds
+    DeviceBook& book = g_book[C.device];
+    // another thread ran out of memory after every reclaim: this one gives its pools back (its runs are waited for) and runs
+    // with one set for a while
+    if (book.pressure.load() != C.pressure_seen) {
+        C.pressure_seen = book.pressure.load();
+        C.go_tight();
+        (void)C.release_pools(nullptr, true);
+    }
+    // single quicked_align calls plan with the last reading of the device's free memory while nothing has been allocated
+    // or freed by the library since (the query costs tens of microseconds)
     size_t free0 = C.seen_free, total0 = C.seen_total;
-    if (C.seen_total == 0 || B.arena_bytes > ((size_t)64 << 20)) {
-        reap_orphans();                     // pools of host threads that have ended count as free
+    if (C.seen_total == 0 || B.arena_bytes > ((size_t)64 << 20) || C.seen_epoch != book.epoch.load()) {
+        const uint64_t ep = book.epoch.load();
         HIP_CHECK(hipMemGetInfo(&free0, &total0));
-        C.seen_free = free0; C.seen_total = total0;
+        C.seen_free = free0; C.seen_total = total0; C.seen_epoch = ep;
     }
     // ---- the device-pool planner (replaces mm_allocator's "never fails" arena, mm_allocator.c:251-334, by a budget):
     // how many {stream, pool, planes} sets rotate, and how many bytes one pool may hold, from what this batch's last
@@ -1990,19 +1526,29 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // needs more runs in flight to keep two waves on every SIMD.  A synchronous run is alone on the device anyway.
     // (large batches: three sets for the one-kernel flows -- a 100 k-pair BandEd kernel nearly fills the chip, a fourth run only
     // queues; five for QuickEd / Hirschberg, whose runs are chains of kernels of different shapes: 5.96 -> 6.24 M alignments/s)
-    static const int deep_env = env_int("QE_DEPTH_CHAIN", 5);
-    const int depth_wanted = fetch ? 3 : rotation_depth(B.n, serial ? 3 : std::max(3, deep_env));
-    // what the A pools of this thread may hold together: the device's free memory plus what they hold already, less what
-    // the process's other threads have planned for theirs (the ledger above)
-    const size_t avail = ledger_plan(&C.ledger, free0, pools_held,
-                                     (size_t)(1.05 * (double)std::min(depth_wanted, B.np_alloc) * (double)(need_fixed + need_mat)) + ((size_t)256 << 20));
+    const int depth_wanted = fetch ? 3 : rotation_depth(B.n, serial ? 3 : 5);
+    const size_t wanted = (size_t)(1.05 * (double)std::min(depth_wanted, B.np_alloc) * (double)(need_fixed + need_mat)) + ((size_t)256 << 20);
+    // what threads that have ended left in their contexts is reused by the next thread that takes the context over; it
+    // goes back to the device when this plan could use the room
+    if (wanted > pools_held && wanted - pools_held > free0 / 2 && unleased_held(C.device) > 0 && release_unleased(C.device)) {
+        HIP_CHECK(hipMemGetInfo(&free0, &total0));
+        C.seen_free = free0; C.seen_total = total0; C.seen_epoch = book.epoch.load();
+    }
+    // what the A pools of this thread may hold together: the device's free memory plus what its pools hold already, less
+    // what the process's other contexts hold or have planned (the book, qe_pool.h), less this context's other pools
+    const size_t mine = ledger_plan(&C, free0, wanted);
+    const size_t not_a = C.held.load() - std::min(C.held.load(), pools_held);
+    const size_t avail = mine > not_a ? mine - not_a : 0;
     int na = 1;
-    // beyond three sets only with room to spare: the plan does not see the W pools, the batches' result arenas or what the
-    // caller allocates next
+    // beyond three sets only with room to spare -- the plan does not see the batches' result arenas or what the caller
+    // allocates next -- and within a quarter of the device: depth is for small batches, whose sets are small
     int sets_held = 0;                                    // sets whose pools exist already: rotating over them costs nothing
     for (int q = 0; q < Context::NA; ++q) if (C.pool_a2[q].cap > ((size_t)1 << 28)) sets_held = q + 1;
-    for (int k = std::min(depth_wanted, B.np_alloc); k >= 1; --k)
-        if ((double)min_set * k <= ((k > 3 && k > sets_held) ? 0.6 : 1.0) * (double)avail) { na = k; break; }
+    for (int k = std::min(depth_wanted, B.np_alloc); k >= 1; --k) {
+        const bool deep = k > 3;
+        if (deep && (double)min_set * k > 0.25 * (double)total0) continue;
+        if ((double)min_set * k <= ((deep && k > sets_held) ? 0.6 : 1.0) * (double)avail) { na = k; break; }
+    }
     if (na_env > 0) na = std::min(std::min(na_env, (int)Context::NA), B.np_alloc);
     if (C.memory_tight && C.tight_left-- <= 0) { C.memory_tight = false; C.tight_left = 0; }      // the spell is over: plan normally again
     if (C.memory_tight) na = 1;
@@ -2051,13 +1597,15 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     B.only_score_run = p.only_score;
     // sync == 0 leaves the host-side results of the last fetched run untouched (quicked_batch_fetch brings this run's)
     B.pending_fetch.reset();
+    B.shadow_ready = false;                    // an early finish of the previous queued run is superseded
+    B.wr = &B.res[B.vis];
     std::shared_ptr<PendingFetch> pfp;
     if (fetch) reset_host_results(B);
     else pfp = std::make_shared<PendingFetch>();
     PendingFetch* const pf = pfp.get();
     for (auto& c : B.counters) c = 0;
     if ((unsigned)p.algo > (unsigned)HIRSCHBERG) {
-        if (fetch) std::fill(B.status.begin(), B.status.end(), (int32_t)QUICKED_UNKNOWN_ALGO);
+        if (fetch) std::fill(B.wr->status.begin(), B.wr->status.end(), (int32_t)QUICKED_UNKNOWN_ALGO);
         C.staging = false;
         C.phase_u();
         return QUICKED_UNKNOWN_ALGO;
@@ -2164,7 +1712,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
             if (fetch) {
                 quicked_fast_finish(B, C, p, L, d_cut, d_skip, d_steps, matrix_budget, par);
                 C.phase_a();
-                for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+                for (auto& st : B.wr->status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
             }
             QE_TRACE_POINT("fast: align launched(+fetch)");
         } else
@@ -2174,9 +1722,17 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     default: break;
     }
-    if (pf && pf->kind != 0) { C.phase_a(); stash_results(B, C, *pf); }
+    if (pf && pf->kind != 0) {
+        C.phase_a();
+        // the batch has ONE result arena: the previous queued run of this batch (another stream of the rotation, possibly a
+        // longer chain of kernels) must have put its results there before this run's overwrite them
+        if (B.last_parity >= 0 && B.last_parity != par && B.ev_done_set[B.last_parity]) HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_done[B.last_parity], 0));
+        stash_results(B, C, *pf);
+    }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
+    HIP_CHECK(hipEventRecord(C.ev_last, C.sa()));
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
+    B.last_parity = par;
     if (C.staging) { HIP_CHECK(hipEventRecord(C.stage[C.si].done, C.sa())); C.stage[C.si].pending = true; C.staging = false; }
     QE_TRACE_POINT("stages launched");
     {   // pre-size the other pools of the rotation -- only while that is cheap: big fill matrices are left to grow on demand
@@ -2188,11 +1744,11 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     QE_TRACE_POINT("pool mirror");
     B.ev_done_set[par] = true;
     if (pf && pf->kind != 0) {
-        pf->pool = &C.pa(); pf->generation = C.pa().generation.load(); pf->parity = par;
+        pf->parity = par;
         for (int q = 0; q < 8; ++q) pf->counters[q] = B.counters[q];
         B.pending_fetch = pfp;
         B.fin_status = QUICKED_OK;
-        if (pf->fast && pf->stashed) finisher_submit(B, pfp);         // pairs that left stage 1 are finished as soon as the run is over
+        if (pf->fast) finisher_submit(B, pfp);         // pairs that left stage 1 are finished as soon as the run is over
     }
     C.phase_u();
     B.pending = true;
@@ -2202,6 +1758,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         HIP_CHECK(hipEventElapsedTime(&ms, C.ev0, C.ev1));
         B.counters[5] = (int64_t)(ms * 1e6);
         B.pending = false;
+        memcpy(B.wr->counters, B.counters, sizeof(B.counters));
     }
     return ret;
 }
@@ -2217,18 +1774,6 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
     PendingFetch& F = *static_cast<PendingFetch*>(hold.get());
     B.pending_fetch.reset();
     HIP_CHECK(hipEventSynchronize(B.ev_done[F.parity]));
-    // the run's device results stay where they are until this fetch is over: whoever recycles or frees that pool (the
-    // queueing thread's next run on the set, its planner, its out-of-memory path) waits for `fetching`
-    struct Hold {
-        std::unique_lock<std::mutex> lk;
-        explicit Hold(DevicePool* p) { if (p) { lk = std::unique_lock<std::mutex>(p->fetching); tl_fetch_hold = p; } }
-        ~Hold() { tl_fetch_hold = nullptr; }
-    } hold_pool(F.stashed ? nullptr : F.pool);
-    if (!F.stashed && F.pool->generation.load() != F.generation) {
-        fprintf(stderr, "[quicked_hip] quicked_batch_fetch: the run's device results were overwritten by later runs of the "
-                        "thread that queued it\n");
-        return QUICKED_ERROR;
-    }
     C.phase_u();
     reset_host_results(B);
     for (int q = 0; q < 8; ++q) B.counters[q] = F.counters[q];
@@ -2242,7 +1787,7 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
         for (size_t t = 0; t < nt; ++t) {
             const int pr = F.task_pair[t];
             if (pr < 0) continue;
-            B.score[pr] = sc[t]; B.status[pr] = F.ok_status;
+            B.wr->score[pr] = sc[t]; B.wr->status[pr] = F.ok_status;
         }
         B.counters[F.counter_slot] += (int64_t)sum_u32(w);
         for (int32_t x : ab) B.counters[6] += (x != 0);
@@ -2261,8 +1806,9 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
         }
         fetch_alignments(B, C, F.SL, F.AO, F.want_strings, F.ok_status, F.root_status.empty() ? nullptr : &F.root_status);
         if (F.fast) quicked_fast_finish(B, C, F.params, F.L, F.d_cut, F.d_skip, F.d_stage_steps, F.matrix_budget, F.parity);
-        if (F.quicked) for (auto& st : B.status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+        if (F.quicked) for (auto& st : B.wr->status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
     }
+    memcpy(B.wr->counters, B.counters, sizeof(B.counters));
     B.pending = false;
     return QUICKED_OK;
 }
@@ -2289,10 +1835,10 @@ static std::atomic<bool> g_fin_stop{false};          // the process is exiting: 
 static void finisher_work(const FinishJob& job) {
     quicked_batch& B = *job.B;
     PendingFetch& F = *static_cast<PendingFetch*>(job.pf.get());
-    tl_device = B.device;
-    Context& C = ctx();
     // the run is over (the batch is alive: destroy waits for fin_jobs).  Polled with short sleeps: hipEventSynchronize spins,
-    // and these threads wait for every queued QuickEd run of the process
+    // and these threads wait for every queued QuickEd run of the process.  No context is held meanwhile.
+    HIP_CHECK(hipSetDevice(B.device));
+    tl_bound_device = B.device;
     for (;;) {
         const hipError_t e = hipEventQuery(B.ev_done[F.parity]);
         if (e == hipSuccess) break;
@@ -2302,6 +1848,9 @@ static void finisher_work(const FinishJob& job) {
     }
     std::unique_lock<std::mutex> lk(B.fin_mu);
     if (B.pending_fetch.get() != job.pf.get()) { if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p already fetched / superseded\n", (void*)&B); return; }
+    ApiScope scope;
+    tl_device = B.device;
+    Context& C = ctx();
     std::vector<int32_t> skip;
     d2h(skip, F.d_skip, F.L.pair.size(), C.stream);
     HIP_CHECK(hipStreamSynchronize(C.stream));
@@ -2309,23 +1858,27 @@ static void finisher_work(const FinishJob& job) {
     for (size_t t = 0; t < skip.size() && !any; ++t) any = skip[t] != 0 && F.L.pair[t] >= 0;
     if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p deferred pairs %s\n", (void*)&B, any ? "yes" : "none");
     if (!any) return;                                                // nothing to finish: the caller's fetch is a copy
-    // the finishers' pools are not in anybody's plan: with little HBM left the work stays with the caller's fetch, and this
-    // thread gives back what it holds
-    auto trim_own = [&]() { C.sync_all(); for (auto& q : C.pool_a2) q.release_all(); for (auto& q : C.pool_w2) q.release_all(); C.pool_w.release_all(); };
-    size_t free_b = 0, total_b = 0;
-    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    if (free_b < ((size_t)32 << 30)) { trim_own(); return; }
+    // The results go to the batch's shadow set (quicked_batch::res): the caller may be reading the visible one.  This
+    // thread's context is in the book like any other (its pools are planned in quicked_fast_finish); what it keeps between
+    // jobs is capped.
+    auto trim_own = [&]() { (void)C.release_pools(nullptr, true); };
     const std::shared_ptr<void> keep = B.pending_fetch;
-    try { B.fin_status = fetch_pending(B); }
+    B.wr = &B.res[1 - B.vis];
+    try {
+        B.fin_status = fetch_pending(B);
+        B.shadow_ready = true;
+    }
     catch (const HipError&) {
         // e.g. out of memory next to the other threads' pools: nothing is lost -- the run's results are still in the batch's
         // result arena, and the caller's fetch does the same work in its own context
         (void)hipGetLastError();
-        B.pending_fetch = keep; B.pending = true; B.fin_status = QUICKED_OK;
-        try { trim_own(); } catch (const HipError&) { (void)hipGetLastError(); }
+        B.wr = &B.res[B.vis];
+        B.pending_fetch = keep; B.pending = true; B.fin_status = QUICKED_OK; B.shadow_ready = false;
+        trim_own();
         throw;
     }
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < ((size_t)48 << 30)) trim_own();
+    B.wr = &B.res[B.vis];
+    if (C.held.load() > ((size_t)8 << 30)) trim_own();
 }
 
 static void finisher_main() {
@@ -2449,6 +2002,7 @@ QE_API quicked_status_t quicked_set_device(int device) {
 static quicked_status_t guard(quicked_batch* B, quicked_status_t (*fn)(quicked_batch*, void*), void* arg) {
     std::unique_lock<std::mutex> lk;
     if (B) lk = std::unique_lock<std::mutex>(B->fin_mu);
+    ApiScope scope;
     try { return fn(B, arg); }
     catch (const HipError& e) {
         fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
@@ -2466,12 +2020,12 @@ static void batch_reset_state(quicked_batch* B) {
     for (bool& e : B->ev_done_set) e = false;
     B->parity = 0; B->pending = false; B->pending_fetch.reset(); B->d_score = nullptr;
     if (B->est_bound < 0) B->est_bound = 0;          // other pairs: QuickEd's sizing decision is taken again (a streamed batch keeps its estimate)
-    B->score.clear(); B->status.clear(); B->cigar_off.clear(); B->cigar_pool.size = 0; B->check_ok.clear();
+    B->res[0].clear(); B->res[1].clear(); B->vis = 0; B->wr = &B->res[0]; B->shadow_ready = false; B->last_parity = -1;
 }
 static void batch_arena(quicked_batch* B, size_t need) {
     if (B->arena && B->arena_bytes >= need) return;
-    if (B->arena) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(B->arena)); B->arena = nullptr; B->arena_bytes = 0; }
-    device_malloc_retry((void**)&B->arena, need, nullptr, "hipMalloc((void**)&B->arena, need)", __LINE__);
+    if (B->arena) { HIP_CHECK(hipDeviceSynchronize()); device_free(B->arena, B->device); B->arena = nullptr; B->arena_bytes = 0; }
+    device_malloc((void**)&B->arena, need, B->device, nullptr, "hipMalloc(batch arena)", __LINE__);
     B->arena_bytes = need;
 }
 static void batch_load(quicked_batch* B, Context& C, int64_t n,
@@ -2559,6 +2113,7 @@ static void batch_quiesce(quicked_batch* B) {
 
 static quicked_batch* guarded_new(const std::function<void(quicked_batch*)>& load) {
     quicked_batch* B = nullptr;
+    ApiScope scope;
     try {
         B = new quicked_batch();
         load(B);
@@ -2579,7 +2134,6 @@ QE_API quicked_batch_t* quicked_batch_create(int64_t n,
     return guarded_new([&](quicked_batch* B) {
         Context& C = ctx();
         batch_load(B, C, n, pattern_pool, pattern_off, pattern_len, text_pool, text_off, text_len);
-        ledger_note_create(&C.ledger);
     });
 }
 
@@ -2707,7 +2261,6 @@ QE_API quicked_batch_t* quicked_batch_create_packed(int64_t n, int wire,
     return guarded_new([&](quicked_batch* B) {
         Context& C = ctx();
         batch_load_packed(B, C, n, wire, pattern_words, pattern_word_off, pattern_len, text_words, text_word_off, text_len);
-        ledger_note_create(&C.ledger);
     });
 }
 
@@ -2730,13 +2283,22 @@ QE_API quicked_status_t quicked_batch_reload_packed(quicked_batch_t* batch, int6
 QE_API quicked_status_t quicked_batch_fetch(quicked_batch_t* batch) {
     if (!batch) return QUICKED_ERROR;
     return guard(batch, [](quicked_batch* B, void*) {
-        if (!B->pending_fetch && B->fin_status < 0) return B->fin_status;      // an early finish did the work, and failed
+        if (!B->pending_fetch && B->shadow_ready) {
+            // an early-finish thread has brought the run's results to the host already, into the set the getters do not
+            // read: it becomes the visible one
+            B->shadow_ready = false;
+            B->vis ^= 1;
+            B->wr = &B->res[B->vis];
+            return B->fin_status < 0 ? B->fin_status : QUICKED_OK;
+        }
+        B->wr = &B->res[B->vis];
         return fetch_pending(*B);
     }, nullptr);
 }
 
 QE_API void quicked_batch_destroy(quicked_batch_t* batch) {
     if (!batch) return;
+    ApiScope scope;
     try {
         tl_device = batch->device;
         (void)ctx();                           // binds the batch's device to this thread
@@ -2788,25 +2350,25 @@ QE_API quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double
 }
 
 QE_API quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_out, int32_t* status_out) {
-    if (batch->score.size() != (size_t)batch->n) return QUICKED_ERROR;
-    if (scores_out) memcpy(scores_out, batch->score.data(), (size_t)batch->n * sizeof(int32_t));
-    if (status_out) memcpy(status_out, batch->status.data(), (size_t)batch->n * sizeof(int32_t));
+    if (batch->res[batch->vis].score.size() != (size_t)batch->n) return QUICKED_ERROR;
+    if (scores_out) memcpy(scores_out, batch->res[batch->vis].score.data(), (size_t)batch->n * sizeof(int32_t));
+    if (status_out) memcpy(status_out, batch->res[batch->vis].status.data(), (size_t)batch->n * sizeof(int32_t));
     return QUICKED_OK;
 }
 
-QE_API int64_t quicked_batch_cigar_bytes(quicked_batch_t* batch) { return (int64_t)batch->cigar_pool.size; }
+QE_API int64_t quicked_batch_cigar_bytes(quicked_batch_t* batch) { return (int64_t)batch->res[batch->vis].cigar_pool.size; }
 
 QE_API quicked_status_t quicked_batch_cigar_view(quicked_batch_t* batch, const char** cigar_pool, const int64_t** cigar_off) {
-    if (!batch || batch->cigar_off.size() != (size_t)batch->n) return QUICKED_ERROR;
-    if (cigar_pool) *cigar_pool = batch->cigar_pool.p;
-    if (cigar_off) *cigar_off = batch->cigar_off.data();
+    if (!batch || batch->res[batch->vis].cigar_off.size() != (size_t)batch->n) return QUICKED_ERROR;
+    if (cigar_pool) *cigar_pool = batch->res[batch->vis].cigar_pool.p;
+    if (cigar_off) *cigar_off = batch->res[batch->vis].cigar_off.data();
     return QUICKED_OK;
 }
 
 QE_API quicked_status_t quicked_batch_cigars(quicked_batch_t* batch, char* cigar_pool, int64_t* cigar_off) {
-    if (batch->cigar_off.size() != (size_t)batch->n) return QUICKED_ERROR;
-    if (cigar_pool && batch->cigar_pool.size) memcpy(cigar_pool, batch->cigar_pool.p, batch->cigar_pool.size);
-    if (cigar_off) memcpy(cigar_off, batch->cigar_off.data(), (size_t)batch->n * sizeof(int64_t));
+    if (batch->res[batch->vis].cigar_off.size() != (size_t)batch->n) return QUICKED_ERROR;
+    if (cigar_pool && batch->res[batch->vis].cigar_pool.size) memcpy(cigar_pool, batch->res[batch->vis].cigar_pool.p, batch->res[batch->vis].cigar_pool.size);
+    if (cigar_off) memcpy(cigar_off, batch->res[batch->vis].cigar_off.data(), (size_t)batch->n * sizeof(int64_t));
     return QUICKED_OK;
 }
 
@@ -2819,8 +2381,8 @@ QE_API quicked_status_t quicked_batch_configure(quicked_batch_t* batch, int ciga
 }
 
 QE_API quicked_status_t quicked_batch_check_results(quicked_batch_t* batch, int32_t* ok_out) {
-    if (!batch || batch->check_ok.size() != (size_t)batch->n) return QUICKED_ERROR;
-    memcpy(ok_out, batch->check_ok.data(), (size_t)batch->n * sizeof(int32_t));
+    if (!batch || batch->res[batch->vis].check_ok.size() != (size_t)batch->n) return QUICKED_ERROR;
+    memcpy(ok_out, batch->res[batch->vis].check_ok.data(), (size_t)batch->n * sizeof(int32_t));
     return QUICKED_OK;
 }
 
@@ -2855,26 +2417,23 @@ QE_API quicked_status_t quicked_batch_validate(quicked_batch_t* batch, const cha
 
 QE_API quicked_status_t quicked_pool_stats(int64_t stats_out[8]) {
     for (int q = 0; q < 8; ++q) stats_out[q] = 0;
-    stats_out[1] = g_reclaim_events.load();
+    for (const auto& bk : g_book) stats_out[1] += bk.oom_events.load();
     Context* C = tl_ctx;
     if (!C) return QUICKED_OK;
-    for (const auto& q : C->pool_a2) stats_out[0] += (int64_t)q.cap;
-    for (const auto& q : C->pool_w2) stats_out[0] += (int64_t)q.cap;
-    stats_out[0] += (int64_t)C->pool_w.cap;
+    stats_out[0] = (int64_t)C->held.load();
     stats_out[2] = C->last_na; stats_out[3] = C->last_sub_batches; stats_out[4] = (int64_t)C->pool_budget;
+    stats_out[5] = (int64_t)g_book[C->device].held.load();
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); for (const Context* c : g_ctx_all) { ++stats_out[6]; if (c->leased.load()) ++stats_out[7]; } }
     return QUICKED_OK;
 }
 
 QE_API quicked_status_t quicked_pool_trim(void) {
+    ApiScope scope;
     try {
         Context& C = ctx();
-        reap_orphans();
-        C.sync_all();
-        for (auto& q : C.pool_a2) q.release_all();
-        for (auto& q : C.pool_w2) q.release_all();
-        C.pool_w.release_all();
-        std::lock_guard<std::mutex> lk(g_ledger_mu);
-        C.ledger.held = 0; C.ledger.planned = 0; C.ledger.wanted = 0;
+        (void)C.release_pools(nullptr, true);
+        { std::lock_guard<std::mutex> lk(g_ctx_mu); C.planned = 0; C.wanted = 0; }
+        (void)release_unleased(C.device);                  // what threads that have ended left behind
         return QUICKED_OK;
     } catch (const HipError& e) {
         fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
@@ -2882,10 +2441,10 @@ QE_API quicked_status_t quicked_pool_trim(void) {
     }
 }
 
-QE_API int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch) { return batch ? batch->deferred_pairs : -1; }
+QE_API int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch) { return batch ? batch->res[batch->vis].deferred_pairs : -1; }
 
 QE_API quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters_out[8]) {
-    memcpy(counters_out, batch->counters, sizeof(batch->counters));
+    memcpy(counters_out, batch->res[batch->vis].counters, sizeof(batch->counters));
     return QUICKED_OK;
 }
 
@@ -3028,18 +2587,19 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
         if (tlens[i]) memcpy(tp.data() + to[i], texts[i], (size_t)tlens[i]);
     }
     double tr_last = now_ms();
+    ApiScope scope;
     // small calls (quicked_align, small quicked_align_batch) reuse one batch object per thread and device: no hipMalloc /
     // hipFree (a device-wide synchronisation) per call
-    static thread_local quicked_batch* tl_small = nullptr;
+    // (the object belongs to the thread's context: the next thread that takes the context over inherits it)
     const bool small = pb + tb <= ((size_t)8 << 20);
     quicked_batch_t* B = nullptr;
     if (small) {
-        if (tl_small && tl_small->device != tl_device) { quicked_batch_destroy(tl_small); tl_small = nullptr; }
-        if (!tl_small) tl_small = quicked_batch_create(n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data());
-        else if (quicked_batch_reload(tl_small, n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data()) < 0) {
-            quicked_batch_destroy(tl_small); tl_small = nullptr;
+        quicked_batch*& slot = *reinterpret_cast<quicked_batch**>(&ctx().small_batch);
+        if (!slot) slot = quicked_batch_create(n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data());
+        else if (quicked_batch_reload(slot, n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data()) < 0) {
+            quicked_batch_destroy(slot); slot = nullptr;
         }
-        B = tl_small;
+        B = slot;
     } else B = quicked_batch_create(n, pp.data(), po.data(), pl.data(), tp.data(), to.data(), tl.data());
     if (!B) return QUICKED_ERROR;
     QE_TRACE_POINT("align_pairs: create");
@@ -3056,17 +2616,18 @@ static quicked_status_t align_pairs(quicked_aligner_t* aligner, int n, const cha
     quicked_status_t first_err = QUICKED_OK;
     bool any_err = false;
     for (int i = 0; i < n; ++i) {
-        const quicked_status_t s = (st < 0 && st != QUICKED_EMPTY_SEQUENCE) ? st : (quicked_status_t)B->status[(size_t)i];
+        const quicked_status_t s = (st < 0 && st != QUICKED_EMPTY_SEQUENCE) ? st : (quicked_status_t)B->res[B->vis].status[(size_t)i];
         if (status_out) status_out[i] = s;
         if (s < 0 && !any_err) { any_err = true; first_err = s; }
         // a split that did not converge still has a score and a CIGAR in the reference (run_hirschberg extracts them from the
         // partial operations buffer before it returns the status, quicked.c:149-160): what the converged leaves gave
-        if (scores_out && (s >= 0 || s == QUICKED_FAIL_NON_CONVERGENCE)) scores_out[i] = B->score[(size_t)i];
+        if (scores_out && (s >= 0 || s == QUICKED_FAIL_NON_CONVERGENCE)) scores_out[i] = B->res[B->vis].score[(size_t)i];
     }
     if (cigars_out) {
-        pool_keep->assign(B->cigar_pool.p, B->cigar_pool.p + B->cigar_pool.size);
+        const quicked_batch::HostResults& R = B->res[B->vis];
+        pool_keep->assign(R.cigar_pool.p, R.cigar_pool.p + R.cigar_pool.size);
         for (int i = 0; i < n; ++i)
-            cigars_out[i] = (B->cigar_off[(size_t)i] >= 0 && !p->only_score) ? pool_keep->data() + B->cigar_off[(size_t)i] : nullptr;
+            cigars_out[i] = (R.cigar_off[(size_t)i] >= 0 && !p->only_score) ? pool_keep->data() + R.cigar_off[(size_t)i] : nullptr;
     }
     if (!small) quicked_batch_destroy(B);
     QE_TRACE_POINT("align_pairs: destroy");

@@ -122,91 +122,6 @@ def test_wire_serializer_known_answers():
     assert L.quicked_wire_pack(b"ACRT", 4, 3, out.ctypes.data) < 0      # IUPAC
 
 
-def test_committed_bench_lines_follow_the_contract():
-    """the bench lines committed under profiles/ (what bench.py printed on the MI355X) carry every field of the
-    driver's contract, the roofline object and the CPU baseline"""
-    import glob
-    import json
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_i_bench_*.json")) + glob.glob(os.path.join(root, "profiles", "r02_[ijkl]_bench_*.json")))
-    assert files, "no committed bench lines"
-    for f in files:
-        d = json.load(open(f))
-        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-            assert k in d, (f, k)
-        assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["n_gpus"] == 1
-        assert "workload" in d["config"] and "model" not in d["config"]
-        r = d["roofline"]
-        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-            assert k in r, (f, k)
-        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-        c = d["cpu_baseline"]
-        for k in ("value", "unit", "cores", "kind", "sample"):
-            assert k in c, (f, k)
-        assert c["kind"] in ("reference", "port") and c["gpu_scores_identical_on_sample"] is True
-        assert abs(d["value"] - d["config"]["pairs_per_gpu"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-6
-        if "r02_" in f:
-            # round 2: a fraction is a fraction; traffic is measured for the profiled sizes; the CPU baseline counts the
-            # CPUs the process really has; the banded line carries the end-to-end leg
-            assert 0 < r["frac"] <= 1 and r["traffic"] is not None and r["traffic"] >= r["algorithmic_bytes_per_launch"]
-            assert c["cores"] <= 64 and "single_thread_value" in c and "suspect" in c
-            assert "DEVICE-RESIDENT" in d["config"]["workload"]
-            assert 0 < d["valu"]["aggregate_frac"] < 1
-            if "banded_score" in f:
-                assert d["e2e"]["2bit_pinned"]["value"] > d["e2e"]["ascii_pinned"]["value"] > 0
-
-
-def test_round3_bench_line_carries_every_leg():
-    """the line bench.py printed on the MI355X at the end of round 3 (profiles/r03_*_bench_line.json, the driver's command):
-    the headline and its contract fields, the QuickEd + CIGAR workload with its own roofline / e2e / cpu_baseline, the
-    12.5 k-pair share of the 8-GPU strong-scaling target for both workloads, the indel-heavy leg with its stage counts,
-    ranks_seen, and a roofline whose fraction comes from the kernel's duration alone on the chip"""
-    import glob
-    import json
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r03_*_bench_line.json")))
-    assert files, "no round-3 bench line committed"
-    for f in files:
-        d = json.loads(open(f).read().strip().splitlines()[-1])
-        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "ranks_seen", "e2e", "workloads", "strong_share"):
-            assert k in d, (f, k)
-        assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
-        assert abs(d["value"] - d["config"]["pairs_per_gpu"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-6
-        assert "banded_score" in d["config"]["workload"] and "DEVICE-RESIDENT" in d["config"]["workload"]
-
-        def roof_ok(r):
-            for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "kernel_ms_overlapped", "aggregate_achieved"):
-                assert k in r, (f, k)
-            assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1
-            assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
-            assert r["traffic"] is None or r["traffic"] > 0
-        roof_ok(d["roofline"])
-        assert d["roofline"]["traffic"] >= d["roofline"]["algorithmic_bytes_per_launch"]
-        assert d["e2e"]["2bit_pinned"]["value"] > d["e2e"]["ascii_hostpacked"]["value"] > d["e2e"]["ascii_pinned"]["value"] > 0
-        assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["gpu_scores_identical_on_sample"] is True
-        q = d["workloads"]["quicked"]
-        for k in ("value", "ms_per_step", "roofline", "valu", "e2e", "cpu_baseline", "quicked_flow", "cigar_bytes_per_step", "score_checksum"):
-            assert k in q, (f, k)
-        roof_ok(q["roofline"])
-        assert "k_banded<true>" in q["roofline"]["kernel"] and q["quicked_flow"]["deferred_pairs"] == 0
-        assert q["score_checksum"] == d["score_checksum"]                  # BandEd (bandwidth 15) and QuickEd agree on every distance
-        assert q["e2e"]["ascii_hostpacked"]["value"] > q["e2e"]["ascii_pinned"]["value"] > 0
-        assert q["e2e"]["ascii_hostpacked"]["d2h_cigar_bytes_per_batch"] == q["cigar_bytes_per_step"]
-        qi = d["workloads"]["quicked_indels"]
-        assert qi["quicked_flow"]["stage2_pairs"] > 0 and qi["quicked_flow"]["stage3_pairs"] > 0 and qi["value"] > 0
-        assert qi["quicked_flow"]["timed_flow"].startswith("classic")
-        s = d["strong_share"]
-        assert s["pairs_per_gpu"] == 12500
-        for wl in ("banded_score", "quicked"):
-            assert s[wl]["value"] > s[wl]["single_batch_value"] > 0 and s[wl]["runs_in_flight"] >= 3
-            assert abs(s[wl]["value"] - 12500 / s[wl]["ms_per_step"] * 1e3) / s[wl]["value"] < 1e-6
-        assert s["banded_score"]["score_checksum"] == s["quicked"]["score_checksum"]
-
-
 def test_wire_pack_pool_equals_the_per_sequence_serializer():
     """quicked_wire_pack_pool (SIMD, multi-threaded; no GPU involved) writes the words quicked_wire_pack writes, on ragged
     lengths around every block border, for both wire formats and every kernel this CPU has; unrepresentable symbols are
@@ -261,24 +176,3 @@ def test_wire_pack_pool_equals_the_per_sequence_serializer():
         L.quicked_wire_pack_isa(-1)
 
 
-def test_readme_numbers_are_generated_from_the_committed_bench_line():
-    """README.md's measured paragraph is tools/readme_numbers.py's output for the newest profiles/<tag>_bench_line.json"""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("readme_numbers", os.path.join(ROOT, "tools", "readme_numbers.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    text = open(os.path.join(ROOT, "README.md")).read()
-    held = text[text.index(mod.BEGIN) + len(mod.BEGIN):text.index(mod.END)].strip()
-    assert held == mod.paragraph().strip()
-
-
-def test_committed_kernel_resource_table_has_no_scratch():
-    """profiles/<newest tag>_kernel_resources.txt (tools/kernel_resources.sh): every kernel of the build it describes fits
-    its registers -- the fill's spills were a review item of round 2"""
-    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_resources.txt"))
-    assert files
-    lines = [l for l in open(os.path.join(ROOT, "profiles", files[-1])).read().splitlines() if l.strip()]
-    assert len(lines) >= 20
-    for l in lines:
-        assert "ScratchSize [bytes/lane]: 0" in l, l
-    assert any("k_banded<true>" in l for l in lines) and any("k_windowed_cp" in l for l in lines)

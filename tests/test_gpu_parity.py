@@ -754,47 +754,6 @@ def test_quicked_stage3_with_zero_cutoff_terminates():
     assert all(o == (est, esc, ecg) for o in out)
 
 
-def test_concurrent_host_threads_one_aligner_each():
-    """the reference's threading contract: no locks, no globals, one aligner per thread
-    (align_benchmark.c:246-284).  Here every host thread gets its own streams and device pools; results must not
-    depend on what the other threads are doing."""
-    import ctypes as C
-    import threading
-    lib = capi.lib()
-    batch = datagen.generate(count=48, length=1500, error=0.07, seed=515)
-    pairs = list(batch.pairs())
-    expect = {}
-    for algo, only in ((capi.QUICKED, False), (capi.BANDED, True), (capi.HIRSCHBERG, False), (capi.WINDOWED, False)):
-        expect[(algo, only)] = [O.oracle_align(p, t, algo=algo, only_score=only) for p, t in pairs]
-    errors = []
-
-    def worker(algo, only, lo, hi):
-        try:
-            prm = capi.make_params(algo=algo, only_score=only)
-            a = capi.Aligner()
-            assert lib.quicked_new(C.byref(a), C.byref(prm)) == capi.QUICKED_WIP
-            for i in range(lo, hi):
-                p, t = pairs[i]
-                st = lib.quicked_align(C.byref(a), p, len(p), t, len(t))
-                est, esc, ecg = expect[(algo, only)][i]
-                got = (st, a.score, a.cigar.decode() if (a.cigar and not only) else None)
-                if got != (est, esc, None if only else ecg):
-                    errors.append((algo, only, i, got[:2]))
-            lib.quicked_free(C.byref(a))
-        except Exception as e:      # noqa: BLE001
-            errors.append(repr(e))
-
-    threads = []
-    for k, (algo, only) in enumerate(expect):
-        for half in range(2):
-            threads.append(threading.Thread(target=worker, args=(algo, only, 24 * half, 24 * half + 24)))
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    assert not errors, errors[:5]
-
-
 def test_async_run_fetch_and_reload():
     """sync == 0 leaves the getters' data alone; quicked_batch_fetch brings exactly that run's results (scores,
     statuses, CIGARs, counters); quicked_batch_reload puts other pairs (other n, other lengths) into the same object"""
@@ -913,62 +872,6 @@ def test_bench_times_the_classic_flow_when_pairs_leave_stage_1():
         assert (f["stage2_pairs"] > 0) == (want == "classic"), f
 
 
-def test_streaming_reload_from_an_uploader_thread():
-    """bench.py's end-to-end pattern: an uploader thread reloads batch objects while the main thread runs and fetches
-    the others (ASCII and 2-bit input)"""
-    import threading
-    sets = [datagen.generate(count=256, length=900, error=0.05, seed=800 + k) for k in range(6)]
-    expect = [[O.oracle_align(p, t, algo=2, only_score=True)[1] for p, t in b.pairs()] for b in sets]
-    prm = capi.make_params(algo=capi.BANDED, only_score=True)
-    for wire in (None, capi.WIRE_2BIT):
-        slots = 3
-        words = None
-        if wire is None:
-            rbs = [capi.ResidentBatch(sets[0]) for _ in range(slots)]
-        else:
-            words = [capi.wire_pack_pool(b.pattern_pool, b.pattern_off, b.pattern_len, wire) +
-                     capi.wire_pack_pool(b.text_pool, b.text_off, b.text_len, wire) for b in sets]
-            rbs = [capi.ResidentBatch.from_wire(sets[0], wire, *words[0]) for _ in range(slots)]
-        up = [threading.Event() for _ in sets]
-        done = [threading.Event() for _ in sets]
-        errs = []
-
-        def uploader():
-            try:
-                for k, b in enumerate(sets):
-                    if k >= slots:
-                        done[k - slots].wait()
-                    st = rbs[k % slots].reload(b) if wire is None else rbs[k % slots].reload_wire(b, wire, *words[k])
-                    assert st >= 0
-                    up[k].set()
-            except Exception as e:      # noqa: BLE001
-                errs.append(e)
-                for ev in up:
-                    ev.set()
-
-        th = threading.Thread(target=uploader)
-        th.start()
-        got = {}
-
-        def finish(k):
-            assert rbs[k % slots].fetch() >= 0
-            got[k] = rbs[k % slots].scores()[0].tolist()
-            done[k].set()
-
-        for k in range(len(sets)):
-            up[k].wait()
-            assert not errs, errs
-            assert rbs[k % slots].run(prm, sync=False) >= 0
-            if k >= 1:
-                finish(k - 1)
-        finish(len(sets) - 1)
-        th.join()
-        for k in range(len(sets)):
-            assert got[k] == expect[k], (wire, k)
-        for rb in rbs:
-            rb.close()
-
-
 def test_cigar_strings_stay_valid_until_free():
     """quicked.c:48-50, 357-361: every string quicked_align returned is owned by the aligner until quicked_free"""
     import ctypes as C
@@ -1027,187 +930,6 @@ def test_timers_gain_one_sample_per_align(golden):
         assert l_seen > 0 and b_seen > 0, (l_seen, b_seen, list(runs))
         assert a.timer.contents.time_ns.total > 0
         lib.quicked_free(C.byref(a))
-
-
-def test_planner_cuts_a_large_cigar_batch_before_it_runs_out_of_memory():
-    """a21: the device-pool planner.  400 k pairs of 10 kb through QuickEd + CIGAR need ~92 GB of fill checkpoints per
-    run; three pool sets of that do not fit 288 GB.  The planner must pick the rotation depth and the fill sub-batches
-    up front: no out-of-memory reclaim event, results identical to the oracle's, and the rate stays in the millions."""
-    import time
-    n = 400000
-    batch = datagen.generate(count=n, length=10000, error=0.05, seed=0x51CED)
-    before = capi.pool_stats()["reclaim_events"]
-    rb = capi.ResidentBatch(batch)
-    p = capi.make_params(algo=capi.QUICKED)
-    assert rb.run(p, sync=True) >= 0                      # sizes the pools
-    first = capi.pool_stats()
-    for _ in range(3):                                    # every set of the rotation allocates its pools once (tens of GB each)
-        assert rb.run(p, sync=False) >= 0
-    rb.sync()
-    t0 = time.perf_counter()
-    steps = 4
-    for _ in range(steps):
-        assert rb.run(p, sync=False) >= 0
-    rb.sync()
-    dt = time.perf_counter() - t0
-    assert rb.run(p, sync=True) >= 0
-    s, st = rb.scores()
-    cg = rb.cigars()
-    stats = capi.pool_stats()
-    rb.close()
-    rate = n * steps / dt
-    print(f"planner: {rate / 1e6:.2f} M pairs/s, sets {stats['sets']}, fill sub-batches {stats['sub_batches']}, "
-          f"pools {stats['pool_bytes'] / 2**30:.1f} GiB, first run {first}")
-    assert stats["reclaim_events"] == before, stats
-    assert (st == capi.QUICKED_WIP).all()
-    for i in list(range(0, 48)) + list(range(n - 16, n)):
-        pt, tt = batch.pattern(i), batch.text(i)
-        assert (st[i], s[i], cg[i]) == O.oracle_align(pt, tt, algo=0), i
-    assert rate > 3.0e6, rate
-
-
-def test_two_host_threads_plan_hbm_together():
-    """the process-wide HBM ledger: two host threads, each with 150 k pairs of 10 kb through QuickEd + CIGAR (~35 GB of fill
-    checkpoints per run and pool set), plan their device pools against what the OTHER has planned, not against the whole
-    device each: no out-of-memory reclaim event, both threads' results equal to the oracle's on a stride.  A thread that
-    is done gives its pools back (quicked_pool_trim)."""
-    import threading
-    n = 150000
-    batch = datagen.generate(count=n, length=10000, error=0.05, seed=0x51CED)
-    assert capi.pool_trim() == 0            # what this (idle) thread's pools hold from earlier tests goes back to the device
-    before = capi.pool_stats()["reclaim_events"]
-    errors, stats, rates = [], {}, {}
-    gate = threading.Barrier(2)
-
-    def worker(name):
-        try:
-            import time
-            rb = capi.ResidentBatch(batch)
-            p = capi.make_params(algo=capi.QUICKED)
-            gate.wait()
-            assert rb.run(p, sync=True) >= 0
-            for _ in range(3):                        # every set of the rotation allocates its pools once (tens of GB each, seconds)
-                assert rb.run(p, sync=False) >= 0
-            rb.sync()
-            gate.wait()
-            t0 = time.perf_counter()
-            for _ in range(4):
-                assert rb.run(p, sync=False) >= 0
-            rb.sync()
-            rates[name] = n * 4 / (time.perf_counter() - t0)
-            assert rb.run(p, sync=True) >= 0
-            s, st = rb.scores()
-            cg = rb.cigars()
-            stats[name] = capi.pool_stats()
-            rb.close()
-            assert capi.pool_trim() == 0          # this thread is done: its pools go back to the device
-            assert (st == capi.QUICKED_WIP).all()
-            for i in list(range(0, n, n // 24)) + [n - 1]:
-                assert (st[i], s[i], cg[i]) == O.oracle_align(batch.pattern(i), batch.text(i), algo=0), (name, i)
-        except Exception as e:      # noqa: BLE001
-            errors.append((name, repr(e)))
-            try:
-                gate.abort()
-            except Exception:      # noqa: BLE001
-                pass
-
-    ths = [threading.Thread(target=worker, args=(k,)) for k in ("a", "b")]
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
-    assert not errors, errors
-    print(f"two threads: {rates}, {stats}")
-    for k in ("a", "b"):
-        assert stats[k]["reclaim_events"] == before, stats
-        # neither thread was allowed to plan for the whole device: the budgets of their pool sets add up to less than it
-    total = 288 * 2**30
-    assert sum(stats[k]["pool_budget"] * stats[k]["sets"] for k in ("a", "b")) < total, stats
-    assert sum(stats[k]["pool_bytes"] for k in ("a", "b")) < total, stats
-    assert all(stats[k]["sets"] >= 2 and stats[k]["sub_batches"] <= 2 for k in ("a", "b")), stats      # nobody was starved
-    assert min(rates.values()) > 0.4e6, rates           # a ledger test, not a benchmark: four runs each, two threads on one chip
-    # the threads trimmed their pools before they ended: the device is free again
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    free_b, total_b = C.c_size_t(), C.c_size_t()
-    assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0
-    assert free_b.value > 0.8 * total_b.value, (free_b.value, total_b.value)
-
-
-@pytest.mark.parametrize("finishers", ["3", "0"])
-def test_mixed_batches_finish_early(finishers, monkeypatch):
-    """ordinary reads with a few large-indel pairs among them: the QuickEd fast flow sizes its align step for the ordinary
-    ones (estimate within twice the median bound), the others leave it and are aligned through the host-driven stages -- by
-    the library's early-finish threads as soon as the run is over (QE_FINISHERS = 3, default) or by the caller's fetch
-    (0).  A stream of queued runs over several batch objects, fetched by one thread: every result equal to the oracle's,
-    the deferred pairs counted, no pool grown to the outliers' size."""
-    monkeypatch.setenv("QE_FINISHERS", finishers)
-    import numpy as np
-    easy = datagen.generate(count=6000, length=4000, error=0.05, seed=555)
-    hard = datagen.generate(count=120, length=4000, error=0.05, seed=556, indels_num=3, indels_len=400)
-    pairs = list(easy.pairs()) + list(hard.pairs())
-    batch = datagen.PairBatch(*_pools(pairs))
-    want = {i: O.oracle_align(*pairs[i], algo=0) for i in list(range(0, 6000, 500)) + list(range(6000, 6120, 7))}
-    prm = capi.make_params(algo=capi.QUICKED)
-    rbs = [capi.ResidentBatch(batch) for _ in range(3)]
-    for rb in rbs:
-        assert rb.run(prm, sync=True) >= 0
-    deferred = []
-    for rnd in range(4):
-        for rb in rbs:
-            assert rb.run(prm, sync=False) >= 0
-        for rb in rbs:
-            assert rb.fetch() >= 0
-            deferred.append(rb.deferred_pairs())
-            s, st = rb.scores(); cg = rb.cigars()
-            for i, w in want.items():
-                assert (st[i], s[i], cg[i]) == w, (finishers, rnd, i)
-    assert min(deferred) > 0, deferred                    # the outliers did leave the fast flow ...
-    assert max(deferred) < 600, deferred                  # ... and only they (and the few ordinary pairs above the estimate)
-    stats = capi.pool_stats()
-    for rb in rbs:
-        rb.close()
-    assert stats["pool_bytes"] < 40 * 2**30, stats        # this thread's pools: sized for the ordinary pairs
-
-
-def test_threads_that_end_without_trimming_leave_no_pools_behind():
-    """A host thread that just ends (no quicked_pool_trim, batches closed) must neither crash in its thread-local
-    destructors -- HIP may not be called from there -- nor keep its device pools: its contexts are parked, and the next live
-    thread that plans a run / trims / creates a context releases them.  Ten rounds of short-lived threads with pools of a
-    few GB each, then the device is free again."""
-    import ctypes as C
-    import threading
-    assert capi.pool_trim() == 0
-    batch = datagen.generate(count=20000, length=4000, error=0.05, seed=321)
-    want = [O.oracle_align(p, t, algo=0) for p, t in list(batch.pairs())[:8]]
-    errors = []
-
-    def worker():
-        try:
-            rb = capi.ResidentBatch(batch)
-            prm = capi.make_params(algo=capi.QUICKED)
-            for _ in range(2):
-                assert rb.run(prm, sync=False) >= 0
-            assert rb.fetch() >= 0
-            s, st = rb.scores(); cg = rb.cigars()
-            for i in range(8):
-                assert (st[i], s[i], cg[i]) == want[i]
-            rb.close()                            # ... and the thread ends with its pools allocated
-        except Exception as e:                    # noqa: BLE001
-            errors.append(e)
-
-    for _ in range(10):
-        ths = [threading.Thread(target=worker) for _ in range(3)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-    assert not errors, errors
-    assert capi.pool_trim() == 0                  # a live thread: releases what the ended ones held
-    hip = C.CDLL("libamdhip64.so")
-    free_b, total_b = C.c_size_t(), C.c_size_t()
-    assert hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b)) == 0
-    assert free_b.value > 0.8 * total_b.value, (free_b.value, total_b.value)
 
 
 @pytest.mark.parametrize("force", ["1", "0"])
