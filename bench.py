@@ -58,6 +58,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # over the loop at the guide's rates (2 / 4 cycles), the bound nothing can beat without removing instructions.
 SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9
 INSTR_PER_BLOCK_COLUMN = 26.1
+INSTR_PER_BLOCK_COLUMN_COOP = 33.4       # k_banded_coop_lds<false>, per LIVE block-column (profiles/r03_g_cfg4_sq_counters.txt)
 ISSUE_CYCLES_PER_BLOCK_COLUMN = 61.0     # (2 766 x 2 + 570 x 4) / 128 block-columns of the unrolled 4-slot loop
 # reference anchors of BASELINE.md section 2 (one core of the survey container's 2.1 GHz Xeon, AVX2 build)
 CPU_ANCHOR_PER_CORE = {"banded_score": 2463.0, "quicked": 1680.0}
@@ -151,6 +152,15 @@ def usable_cpus():
     return n, quota
 
 
+def strided_sample(batch, m):
+    """`m` pairs of the batch taken at equal strides (same pools, other offset arrays): a sample that keeps the mix of a
+    batch whose hard pairs are not at the front"""
+    from quicked_amd.datagen import PairBatch
+    idx = np.unique(np.linspace(0, len(batch) - 1, min(m, len(batch))).astype(np.int64))
+    return PairBatch(batch.pattern_pool, np.ascontiguousarray(batch.pattern_off[idx]), np.ascontiguousarray(batch.pattern_len[idx]),
+                     batch.text_pool, np.ascontiguousarray(batch.text_off[idx]), np.ascontiguousarray(batch.text_len[idx])), idx
+
+
 def cpu_baseline(batch, params_kw, workload, budget_s=10.0, anchored=True):
     """The compiled reference (oracle/_ref, kind "reference") or the oracle restatement (kind "port") on the host cores:
     oracle/cpu_bench.c, one aligner per OpenMP thread over disjoint pair ranges (the reference's own model,
@@ -179,8 +189,10 @@ def cpu_baseline(batch, params_kw, workload, budget_s=10.0, anchored=True):
         return wall, scores
 
     run(min(len(batch), cores), cores)                   # warm the library, the arenas and the page cache
-    n1 = min(len(batch), 64)
-    w1 = min(run(n1, 1)[0] for _ in range(3))            # single-thread calibration, best of three
+    # single-thread calibration, best of three, sized to ~0.3 s per try (64 pairs of 10 kb; 4 of 100 kb)
+    per0 = run(min(len(batch), 2), 1)[0] / min(len(batch), 2)
+    n1 = int(min(len(batch), max(2, min(64, 0.3 / max(per0, 1e-9)))))
+    w1 = min(run(n1, 1)[0] for _ in range(3))
     per = w1 / n1
     n = int(min(len(batch), max(cores * 8, budget_s / per * cores)))
     wall, scores = run(n, cores)
@@ -234,6 +246,7 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
         po, ptotal = capi.wire_offsets(batch.pattern_len, capi.WIRE_2BIT)
         to, ttotal = capi.wire_offsets(batch.text_len, capi.WIRE_2BIT)
         cores, _ = usable_cpus()
+        cores = max(1, cores // max(1, int(os.environ.get("WORLD_SIZE", "1"))))      # every rank of the node packs: the CPUs are shared
         pack_threads = max(1, cores // max(uploaders, 1))
         bufs = []
         for _ in range(slots):
@@ -380,11 +393,12 @@ def e2e_leg(capi, batch, params, fmt, nbatches, expect_checksum, slots=4, inflig
            "pool_sets": sets, "uploader_threads": uploaders, "d2h_cigar_bytes_per_batch": d2h_bytes[0] // max(nbatches, 1)}
     if pack_threads:
         out["host_pack_threads_per_uploader"] = pack_threads
+        out["host_cpus_per_rank"] = cores
         out["host_pack_kernel"] = {0: "scalar", 1: "avx2+bmi2", 2: "avx512bw+bmi2"}.get(L.quicked_wire_pack_isa(-1), "?")
     return out
 
 
-def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4):
+def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4, cpu_budget=0.0):
     """QuickEd + CIGAR on a MIXED batch: `pairs` ordinary pairs of which `share` carry 4 x 800-base indels (they leave the
     fast flow and go through the host-driven stages 2 / 3).  `slots` resident batch objects of the same data, runs queued
     with sync == 0 by this thread, every run fetched by ONE other thread -- the pattern of the end-to-end legs without the
@@ -401,7 +415,8 @@ def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4):
         for rb in rbs:
             if rb.run(p, sync=True) < 0:
                 raise RuntimeError("quicked_batch_run failed")
-            checks.append(int(rb.scores()[0].astype("int64").sum()))
+            gpu_scores = rb.scores()[0]
+            checks.append(int(gpu_scores.astype("int64").sum()))
         for rb in rbs:                                      # the fast flow, once, outside the clock (pools, estimates)
             rb.run(p, sync=False)
         for rb in rbs:
@@ -445,7 +460,7 @@ def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4):
             rb.close()
     if bad or len(set(checks)) != 1:
         return {"error": f"mixed leg failed: {sorted(set(bad))}"}
-    return {"value": pairs * steps / dt, "unit": "alignments/s", "ms_per_batch": dt / steps * 1e3, "pairs_per_gpu": pairs, "batches": steps,
+    out = {"value": pairs * steps / dt, "unit": "alignments/s", "ms_per_batch": dt / steps * 1e3, "pairs_per_gpu": pairs, "batches": steps,
             "hard_pairs": hard, "pairs_finished_outside_the_fast_flow_per_run": max(deferred) if deferred else 0,
             "batch_objects": slots, "fetching_threads": 1, "early_finish_threads": int(os.environ.get("QE_FINISHERS", "3")),
             "score_checksum": checks[0],
@@ -453,6 +468,20 @@ def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4):
             "note": "a stream of queued runs over resident batch objects, every run fetched (results on the host side of the "
                     "library, strings left in the batch's pinned pool); the pairs that leave the fast flow are aligned through "
                     "the host-driven stages by the library's early-finish threads"}
+    if cpu_budget > 0:
+        # the reference on the host cores over a sample that keeps the mix (every k-th pair: the hard ones are at the end)
+        cores, _ = usable_cpus()
+        sample, idx = strided_sample(batch, max(cores * 8, min(pairs, int(cpu_budget * cores * 400))))
+        try:
+            base, ref_scores = cpu_baseline(sample, dict(algo=capi.QUICKED, only_score=False, bandwidth=15), "quicked_mixed",
+                                            budget_s=cpu_budget, anchored=False)
+            k = len(ref_scores)
+            base["sample"] = f"every {max(1, pairs // len(idx))}-th pair of the batch ({len(idx)} pairs, {int((idx[:k] >= pairs - hard).sum())} of them hard); " + base["sample"]
+            base["gpu_scores_identical_on_sample"] = bool((gpu_scores[idx[:k]].astype(np.int64) == ref_scores).all())
+            out["cpu_baseline"] = base
+        except Exception as e:          # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
 
 
 class Bench:
@@ -483,7 +512,7 @@ class Bench:
         return shard.reduce_totals(self.dist, self.torch, self.device, pairs, cells, checksum, elapsed, extra_sum=extra)
 
     # -----------------------------------------------------------------------------------------------------------
-    def timed_resident(self, workload, first, count, steps, warmup, solo_steps=3):
+    def timed_resident(self, workload, first, count, steps, warmup, solo_steps=3, kind=None):
         """the contract's loop: `warmup` untimed steps, then exactly `steps` steps between two barrier + synchronize.
         -> dict(batch, scores, counters, elapsed, kernel ms overlapped / solo, cigar bytes, flow, latency)"""
         args, capi = self.args, self.capi
@@ -494,7 +523,13 @@ class Bench:
         batch = self._cache[1]
         rb = capi.ResidentBatch(batch)           # H2D happens here, outside the timed region
         quick = workload == "quicked"
+        if kind is None:
+            kind = 1 if quick else 0             # quicked_batch_kernel_times: 0 score-only passes, 1 fills, 2 Hirschberg half passes
         flow = {}
+
+        def kernel_time():
+            ms, n = rb.kernel_times()
+            return float(ms[kind]), int(n[kind])
         saved_fast = os.environ.get("QE_QUICKED_FAST")
 
         def run_checked(sync):
@@ -535,9 +570,9 @@ class Bench:
                 for _ in range(capi.pool_stats()["sets"]):
                     run_checked(False)
                 rb.sync()
-            rb.kernel_time()                         # drop the warm-up launches
+            kernel_time()                            # drop the warm-up launches
             elapsed = timed_loop()
-            kern_ms, kern_n = rb.kernel_time()
+            kern_ms, kern_n = kernel_time()
             sets = capi.pool_stats()["sets"]
             # one synchronous run to fetch results + work counters for the report ...
             tl0 = time.perf_counter()
@@ -549,22 +584,22 @@ class Bench:
                 flow["timed_flow"] = "classic (host-driven stages): the fast flow deferred pairs to the fetch on this data (re-timed)"
                 flow["deferred_pairs"] = rb.deferred_pairs()
                 run_checked(True)
-                rb.kernel_time()
+                kernel_time()
                 elapsed = timed_loop()
-                kern_ms, kern_n = rb.kernel_time()
+                kern_ms, kern_n = kernel_time()
                 run_checked(True)
             scores, status = rb.scores()
             assert (status >= 0).all(), "some pairs failed"
             counters = rb.counters()
             cig = capi.lib().quicked_batch_cigar_bytes(rb._h) if quick else None
             # ... then the dominant kernel ALONE on the chip (no other run in flight): what the roofline fraction divides by
-            rb.kernel_time()
+            kernel_time()
             lat = []
             for _ in range(solo_steps):
                 tl0 = time.perf_counter()
                 run_checked(True)
                 lat.append(time.perf_counter() - tl0)
-            solo_ms, solo_n = rb.kernel_time()
+            solo_ms, solo_n = kernel_time()
             latency = min([latency] + lat)
         finally:
             if saved_fast is None:
@@ -584,9 +619,20 @@ class Bench:
         solo_s = (r["solo_ms"] / 1e3 / r["solo_n"]) if r["solo_n"] else float("nan")
         over_s = (r["kern_ms"] / 1e3 / r["kern_n"]) if r["kern_n"] else float("nan")
         extra = {}
+        instr_per_bc = INSTR_PER_BLOCK_COLUMN
         if workload == "banded_score":
             # B_so = plen + tlen + 4 per pair (ASCII in, int32 score out)
             kernel, alg_bytes, work_blocks = "k_banded<false> (BandEd score-only)", per_launch_bytes, int(counters[0])
+        elif r.get("kind") == 2:
+            # Long reads: the dominant launches are the score-only half passes of Hirschberg's split levels
+            # (bpm_hirschberg.c:85-100), G lanes per alignment with the band state in LDS.  One level = a forward and a reverse
+            # launch that together read every pair's bit-planes once (3 bits per base) and leave one stopped band per node:
+            # per launch half of that.  counters[0] = block-columns of all half passes of the step.
+            launches_per_step = max(1, r["solo_n"] // max(1, r.get("solo_steps", 1)))
+            alg_bytes = 0.375 * float((batch.pattern_len.astype(np.int64) + batch.text_len.astype(np.int64)).sum()) / 2.0
+            kernel, work_blocks = "k_banded_coop_lds<false> (Hirschberg half passes, band state in LDS)", int(counters[0])
+            instr_per_bc = INSTR_PER_BLOCK_COLUMN_COOP
+            extra["launches_per_step"] = launches_per_step
         else:
             # The fill stores a 16-byte checkpoint per (slot, 16 columns) and the 16-byte carry words per (slot, chunk):
             # 1.25 B per block-column (round 2: a checkpoint every 8 columns, 2.25 B), and reads its inputs as bit-planes
@@ -607,8 +653,10 @@ class Bench:
         except Exception:      # noqa: BLE001
             traffic = None
         achieved = alg_bytes / solo_s / 1e9
+        # the VALU view compares a STEP's block-columns with a step's worth of the dominant launches (kind 2: several per step)
+        solo_step_s = solo_s * extra.get("launches_per_step", 1)
         # work_blocks counts block-columns per LANE (one alignment); a wave64 instruction serves 64 of them
-        wave_instr = work_blocks / 64.0 * INSTR_PER_BLOCK_COLUMN
+        wave_instr = work_blocks / 64.0 * instr_per_bc
         peak_instr = SIMDS * PEAK_CLOCK_HZ / 2.0
         roof = dict({"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -621,8 +669,8 @@ class Bench:
                              "runs overlap, so a launch inside the timed region lasts kernel_ms_overlapped)"}, **extra)
         valu = {"bound": "VALU issue, one wave64 instruction per SIMD per 2 cycles", "unit": "wave-instructions/s",
                 "peak": peak_instr, "aggregate_achieved": wave_instr / step_s, "aggregate_frac": wave_instr / step_s / peak_instr,
-                "solo_kernel_frac": wave_instr / solo_s / peak_instr,
-                "block_columns_per_launch": work_blocks, "instructions_per_block_column": INSTR_PER_BLOCK_COLUMN,
+                "solo_kernel_frac": wave_instr / solo_step_s / peak_instr,
+                "block_columns_per_launch": work_blocks, "instructions_per_block_column": instr_per_bc,
                 "issue_cycles_per_block_column": ISSUE_CYCLES_PER_BLOCK_COLUMN,
                 "instruction_mix_bound_block_columns_per_s": SIMDS * PEAK_CLOCK_HZ * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN,
                 "aggregate_block_columns_per_s": work_blocks / step_s,
@@ -661,11 +709,12 @@ class Bench:
         return out
 
     # -----------------------------------------------------------------------------------------------------------
-    def workload_object(self, workload, pairs, steps, warmup, with_e2e, with_cpu, scaling="weak"):
+    def workload_object(self, workload, pairs, steps, warmup, with_e2e, with_cpu, scaling="weak", kind=None, solo_steps=3):
         """one workload at `pairs` pairs per GPU (weak) or in total (strong): resident rate (+ roofline, e2e, cpu baseline)"""
         args = self.args
         first, count, _ = shard.plan(pairs, self.rank, self.world, scaling)
-        r = self.timed_resident(workload, first, count, steps, warmup)
+        r = self.timed_resident(workload, first, count, steps, warmup, solo_steps=solo_steps, kind=kind)
+        r["kind"], r["solo_steps"] = kind, solo_steps
         cells = r["batch"].cells()
         checksum = int(r["scores"].astype(np.int64).sum())
         tot_pairs, tot_cells, tot_checksum, max_elapsed, _ = self.reduce(count, cells, checksum, r["elapsed"])
@@ -722,6 +771,9 @@ def main():
     ap.add_argument("--indel-pairs", type=int, default=20000,
                     help="pairs of the indel-heavy QuickEd leg (4 x 800-base indels per 10 kb pair: stages 2 / 3 and band doubling, "
                          "SURVEY's own trigger set); 0: no such leg")
+    ap.add_argument("--cfg4-pairs", type=int, default=10000,
+                    help="pairs of the long-read leg (BASELINE.json configs[3]: 100 kb at 10 % error, QuickEd + Hirschberg CIGAR; "
+                         "workloads.cfg4, N = 1); 0: no such leg")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="profiling aid: no overlap between consecutive runs, so per-kernel durations are those of a kernel alone")
     ap.add_argument("--seed", type=int, default=0x51CED)
@@ -782,12 +834,34 @@ def main():
         saved = (args.indels_num, args.indels_len)
         args.indels_num, args.indels_len = 4, 800
         B._cache = None
-        o = B.workload_object("quicked", args.indel_pairs, min(args.steps, 10), 2, with_e2e=False, with_cpu=False)
+        budget = args.cpu_budget
+        args.cpu_budget = min(budget, 3.0)
+        o = B.workload_object("quicked", args.indel_pairs, min(args.steps, 10), 2, with_e2e=False, with_cpu=not args.no_cpu_baseline)
+        args.cpu_budget = budget
         args.indels_num, args.indels_len = saved
         B._cache = None
         others["quicked_indels"] = {k: o[k] for k in ("value", "unit", "ms_per_step", "pairs_per_gpu", "steps", "runs_in_flight",
-                                                       "single_batch_latency_ms", "quicked_flow", "score_checksum")}
+                                                       "single_batch_latency_ms", "quicked_flow", "score_checksum", "cpu_baseline") if k in o}
         others["quicked_indels"]["data"] = "4 x 800-base indels per pair on top of the 5 % edits (generate_dataset's -I 4 -L 800)"
+    if default_shape and args.cfg4_pairs > 0 and world == 1 and args.length == 10000:
+        # BASELINE.json configs[3]: QuickEd + Hirschberg CIGAR on long reads (100 kb at 10 % error).  Every pair splits
+        # (bpm_hirschberg.c:63-65); the dominant launches are the split levels' score-only half passes.  From empty pools:
+        # one pool set of this workload holds ~90 GB.
+        saved = (args.length, args.error, args.cpu_budget)
+        args.length, args.error, args.cpu_budget = 100000, 0.10, min(args.cpu_budget, 4.0)
+        B._cache = None
+        B.capi.pool_trim()
+        try:
+            o = B.workload_object("quicked", args.cfg4_pairs, 5, 2, with_e2e=False, with_cpu=not args.no_cpu_baseline, kind=2, solo_steps=1)
+            others["cfg4"] = {k: o[k] for k in ("value", "unit", "ms_per_step", "gcups", "band_gcups", "pairs_per_gpu", "steps", "runs_in_flight",
+                                                "single_batch_latency_ms", "quicked_flow", "score_checksum", "cigar_bytes_per_step",
+                                                "roofline", "valu", "cpu_baseline") if k in o}
+            others["cfg4"]["data"] = "BASELINE.json configs[3]: 100 kb ONT-like reads at 10 % error, QuickEd + Hirschberg CIGAR"
+        except Exception as e:          # noqa: BLE001  (a leg of its own: the line survives it)
+            others["cfg4"] = {"error": repr(e)}
+        args.length, args.error, args.cpu_budget = saved
+        B._cache = None
+        B.capi.pool_trim()
     # ---- strong scaling: `pairs` pairs in total (BASELINE.json's "100 k pairs at 8 GPUs"); at N = 1 the per-GPU share of it
     strong, strong_share = None, None
     if not args.no_strong:
@@ -820,7 +894,8 @@ def main():
         B._cache = None
         B.capi.pool_trim()
         try:
-            others["quicked_mixed"] = mixed_leg(B.capi, B.datagen, args.pairs, args.length, args.error, args.mixed_share)
+            others["quicked_mixed"] = mixed_leg(B.capi, B.datagen, args.pairs, args.length, args.error, args.mixed_share,
+                                                cpu_budget=0.0 if args.no_cpu_baseline else min(args.cpu_budget, 3.0))
         except Exception as e:          # noqa: BLE001  (a leg of its own: the line survives it)
             others["quicked_mixed"] = {"error": repr(e)}
         if "quicked_indels" in others:
@@ -859,7 +934,8 @@ def main():
         if others:
             line["workloads"] = {wl: dict(o, config={"workload": f"{wl}, DEVICE-RESIDENT inputs, " +
                                                                  (f"the same {args.pairs}" if wl == "quicked" else str(o.get("pairs_per_gpu"))) +
-                                                                 f" pairs/GPU x {args.length} bp @ {args.error:g} error; CIGAR strings left in HBM "
+                                                                 (" pairs/GPU x 100000 bp @ 0.1 error" if wl == "cfg4" else f" pairs/GPU x {args.length} bp @ {args.error:g} error") +
+                                                                 "; CIGAR strings left in HBM "
                                                                  "(end-to-end: e2e, strings on the host)"})
                                  for wl, o in others.items()}
         if strong is not None:

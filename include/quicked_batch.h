@@ -112,7 +112,8 @@ quicked_status_t quicked_batch_sync(quicked_batch_t* batch);
  * QUICKED: the pairs a queued run left for the host-driven stages (those past stage 1, those above the bound estimate)
  * are aligned by library threads as soon as the run is over ("early finish": up to QE_FINISHERS = 3 threads with streams
  * and pools of their own, started when first needed); the fetch then only waits for that.  Calls on one batch object are
- * serialised against such a thread by the library. */
+ * serialised against such a thread by the library, and such a thread writes into a second set of host-side result buffers
+ * that the fetch makes visible: the getters and the zero-copy views keep showing the previous results until the fetch. */
 quicked_status_t quicked_batch_fetch(quicked_batch_t* batch);
 
 /* results of the last sync != 0 run or of the last quicked_batch_fetch (host copies) */
@@ -155,19 +156,26 @@ quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters
 int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch);
 
 /* The device-pool planner's view of the calling thread (replaces mm_allocator, quicked_utils/src/mm_allocator.c:141-426):
- *   [0] bytes its pools hold   [1] out-of-memory reclaim events so far (process-wide; the planner is there to keep this 0)
- *   [2] pool sets in rotation in the last run   [3] fill sub-batches of the last run   [4] bytes one pool may hold */
+ *   [0] bytes its pools hold   [1] allocations that had to take memory from this thread's other pools or from other threads
+ *   (process-wide; the planner is there to keep this 0)   [2] pool sets in rotation in the last run   [3] fill sub-batches of
+ *   the last run   [4] bytes one pool may hold   [5] bytes all pools of the thread's device hold (every thread's)
+ *   [6] contexts {streams, pools} in existence   [7] contexts on lease to a live thread */
 quicked_status_t quicked_pool_stats(int64_t stats_out[8]);
 
-/* Gives the calling thread's device pools back to the device (waits for its runs first).  The pools belong to the thread and
- * stay allocated between runs -- that is what makes a steady stream of batches allocation-free -- so a thread that is done
- * with large batches while others go on should call this (at thread exit the library tries to, best effort). */
+/* Gives the calling thread's device pools back to the device (waits for its runs first), and those that ended threads left
+ * behind.  The pools belong to a per-thread context and stay allocated between runs -- that is what makes a steady stream of
+ * batches allocation-free -- so a thread that is done with large batches while others go on should call this.  A thread that
+ * simply ends leaves its context, pools and all, to the next thread that needs one; an allocation that finds the device
+ * full takes the pools of threads that have no call in progress (their next run allocates again). */
 quicked_status_t quicked_pool_trim(void);
 
 /* Sum of the HIP-event durations (ms) of the dominant kernel (BandEd score /
  * fill) over the runs of this thread since the previous call, and how many
  * launches that was; synchronises the batch's stream. */
 quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double* ms_sum, int64_t* launches);
+/* The same by kind of launch: [0] score-only BandEd passes (a BANDED run, QuickEd's stage 3), [1] fills, [2] the half passes of
+ * Hirschberg's split levels (bpm_hirschberg.c:85-100; the dominant launches of long reads), [3] unused. */
+quicked_status_t quicked_batch_kernel_times(quicked_batch_t* batch, double ms_sum[4], int64_t launches[4]);
 
 #ifdef __cplusplus
 }

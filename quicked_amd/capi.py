@@ -54,7 +54,7 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_align", "quicked_set_device", "quicked_align_batch", "quicked_batch_create",
            "quicked_batch_destroy", "quicked_batch_run", "quicked_batch_sync", "quicked_batch_scores",
            "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters",
-           "quicked_batch_kernel_time", "quicked_host_alloc", "quicked_host_free",
+           "quicked_batch_kernel_time", "quicked_batch_kernel_times", "quicked_host_alloc", "quicked_host_free",
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
            "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
            "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats", "quicked_batch_cigar_view",
@@ -104,6 +104,7 @@ def lib():
     L.quicked_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
     L.quicked_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.quicked_batch_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.quicked_batch_check_results.argtypes = [C.c_void_p, C.c_void_p]
     L.quicked_batch_validate.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -384,6 +385,12 @@ class ResidentBatch:
         ms, n = C.c_double(0), C.c_int64(0)
         self._lib.quicked_batch_kernel_time(self._h, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def kernel_times(self):
+        """-> (ms[4], launches[4]) by kind since the last call: 0 score-only passes, 1 fills, 2 Hirschberg half passes"""
+        ms, n = np.zeros(4, dtype=np.float64), np.zeros(4, dtype=np.int64)
+        self._lib.quicked_batch_kernel_times(self._h, ms.ctypes.data, n.ctypes.data)
+        return ms, n
 
     def close(self):
         if self._h:

@@ -435,7 +435,7 @@ static BandState band_state(const ScoreLaunch& S) {
     return b;
 }
 
-static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, bool timed) {
+static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int timed) {
     ScoreLaunch S;
     S.nt = L.pair.size();
     const BandLayout lay = band_layout(L, false, false);
@@ -449,7 +449,7 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
     a.o_maxrow = S.O.len;
     a.only_if = nullptr;
-    auto* ke = timed ? C.kernel_events() : nullptr;
+    auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;       // timed = kind + 1 (Context::kernel_events)
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     launch_groups(C, k_banded<false>, a, L.ngroups(), 8, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
@@ -490,7 +490,7 @@ static int coop_lanes(const TaskList& L, int in_flight = 1, bool fill = false) {
 }
 
 // k_banded_coop over the list, then k_banded<false> over the tasks it flagged
-static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int G, bool timed) {
+static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int G, int timed) {
     ScoreLaunch S;
     S.nt = L.pair.size();
     const int NA = 64 / G;
@@ -526,7 +526,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
     a.o_maxrow = S.O.len; a.o_abort = S.O.hew;
     HIP_CHECK(hipMemsetAsync(S.O.hew, 0, S.nt * sizeof(int32_t), C.stream));
-    auto* ke = timed ? C.kernel_events() : nullptr;
+    auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;       // timed = kind + 1 (Context::kernel_events)
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     // band state on chip where a wave's tasks fit its share of the LDS (k_banded_coop_lds); QE_COOP_LDS = 0: never
     CoopLdsArgs x;
@@ -628,7 +628,7 @@ static bool wave_form_wanted(const TaskList& L) {
     return live > 0 && (force == 1 || (live <= (size_t)max_env && n_max >= 4096));
 }
 
-static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskList& L, bool reversed, bool timed) {
+static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int timed) {
     ScoreLaunch S;
     S.nt = L.pair.size();
     S.T = upload_tasks(L, C);
@@ -638,7 +638,7 @@ static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskLi
     a.P = pair_view(B, reversed); a.T = S.T.v;
     a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
     a.o_maxrow = S.O.len;
-    auto* ke = timed ? C.kernel_events() : nullptr;
+    auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;       // timed = kind + 1 (Context::kernel_events)
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     launch_groups(C, k_banded_wave, a, S.nt, 4, 0);                     // one wave per task
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
@@ -652,8 +652,8 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
     const int G0 = coop_lanes(L, fetch ? 1 : C.in_flight);
     const bool wave = wave_form_wanted(L) && (G0 < 2 || env_int("QE_WAVE", -1) == 1);
     const int G = wave ? 1 : G0;
-    const ScoreLaunch S = wave ? launch_banded_wave(B, C, L, reversed, true)
-                               : ((G >= 2) ? launch_banded_coop(B, C, L, reversed, G, true) : launch_banded_score(B, C, L, reversed, true));
+    const ScoreLaunch S = wave ? launch_banded_wave(B, C, L, reversed, 1)
+                               : ((G >= 2) ? launch_banded_coop(B, C, L, reversed, G, 1) : launch_banded_score(B, C, L, reversed, 1));
     if (d_score_out) *d_score_out = S.O.score;
     if (pf && !fetch) {
         pf->kind = 1; pf->task_pair = L.pair; pf->d_score = S.O.score; pf->d_adv = S.O.adv; pf->counter_slot = 0;
@@ -887,9 +887,9 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         static const int side_env = env_int("QE_SIDE_STREAM", 1);
         hipStream_t main_s = C.stream, side = side_env ? C.side_stream() : main_s;
         if (side != main_s) { HIP_CHECK(hipEventRecord(C.ev_fork, main_s)); HIP_CHECK(hipStreamWaitEvent(side, C.ev_fork, 0)); }
-        const ScoreLaunch SF = (Gf >= 2) ? launch_banded_coop(B, C, F, false, Gf, false) : launch_banded_score(B, C, F, false, false);
+        const ScoreLaunch SF = (Gf >= 2) ? launch_banded_coop(B, C, F, false, Gf, 3) : launch_banded_score(B, C, F, false, 3);
         C.stream = side;
-        const ScoreLaunch SV = (Gf >= 2) ? launch_banded_coop(B, C, V, true, Gf, false) : launch_banded_score(B, C, V, true, false);
+        const ScoreLaunch SV = (Gf >= 2) ? launch_banded_coop(B, C, V, true, Gf, 3) : launch_banded_score(B, C, V, true, 3);
         C.stream = main_s;
         if (side != main_s) { HIP_CHECK(hipEventRecord(C.ev_join, side)); HIP_CHECK(hipStreamWaitEvent(main_s, C.ev_join, 0)); }
         const size_t ns = split.size();
@@ -1053,7 +1053,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         a.o_score = O.score + o; a.o_first = O.first + o; a.o_last = O.last + o; a.o_posv = O.posv + o; a.o_adv = O.adv + o;
         a.o_maxrow = O.len + o;
         a.only_if = nullptr;
-        auto* ke = C.kernel_events();
+        auto* ke = C.kernel_events(1);
         if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
         if (Gfill >= 2) {
             // few leaves: G lanes per leaf, band state on chip, the same checkpoints / carry words / band edges in the
@@ -2330,23 +2330,31 @@ QE_API quicked_status_t quicked_batch_sync(quicked_batch_t* batch) {
     }, nullptr);
 }
 
-QE_API quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double* ms_sum, int64_t* launches) {
+QE_API quicked_status_t quicked_batch_kernel_times(quicked_batch_t* batch, double ms_sum[4], int64_t launches[4]) {
     struct Arg { double* ms; int64_t* n; } arg{ms_sum, launches};
     return guard(batch, [](quicked_batch* B, void* a) {
         Arg* x = (Arg*)a;
         tl_device = B->device;
         Context& C = ctx();
         C.sync_all();
-        double total = 0;
+        for (int k = 0; k < 4; ++k) { x->ms[k] = 0; x->n[k] = 0; }
         for (size_t i = 0; i < C.kev_used; ++i) {
             float ms = 0;
             HIP_CHECK(hipEventElapsedTime(&ms, C.kev[i].first, C.kev[i].second));
-            total += ms;
+            const int k = C.kev_kind[i] & 3;
+            x->ms[k] += ms; ++x->n[k];
         }
-        *x->ms = total; *x->n = (int64_t)C.kev_used;
         C.kev_used = 0;
         return QUICKED_OK;
     }, &arg);
+}
+
+QE_API quicked_status_t quicked_batch_kernel_time(quicked_batch_t* batch, double* ms_sum, int64_t* launches) {
+    double ms[4]; int64_t n[4];
+    const quicked_status_t st = quicked_batch_kernel_times(batch, ms, n);
+    if (st < 0) return st;
+    *ms_sum = ms[0] + ms[1]; *launches = n[0] + n[1];
+    return QUICKED_OK;
 }
 
 QE_API quicked_status_t quicked_batch_scores(quicked_batch_t* batch, int32_t* scores_out, int32_t* status_out) {
@@ -2419,11 +2427,12 @@ QE_API quicked_status_t quicked_pool_stats(int64_t stats_out[8]) {
     for (int q = 0; q < 8; ++q) stats_out[q] = 0;
     for (const auto& bk : g_book) stats_out[1] += bk.oom_events.load();
     Context* C = tl_ctx;
+    const int dev = C ? C->device : tl_device;
+    if (dev >= 0 && dev < QE_MAX_DEVICES) stats_out[5] = (int64_t)g_book[dev].held.load();
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); for (const Context* c : g_ctx_all) { ++stats_out[6]; if (c->leased.load()) ++stats_out[7]; } }
     if (!C) return QUICKED_OK;
     stats_out[0] = (int64_t)C->held.load();
     stats_out[2] = C->last_na; stats_out[3] = C->last_sub_batches; stats_out[4] = (int64_t)C->pool_budget;
-    stats_out[5] = (int64_t)g_book[C->device].held.load();
-    { std::lock_guard<std::mutex> lk(g_ctx_mu); for (const Context* c : g_ctx_all) { ++stats_out[6]; if (c->leased.load()) ++stats_out[7]; } }
     return QUICKED_OK;
 }
 

@@ -314,16 +314,20 @@ struct Context {
     bool decided_set[NA] = {};               // the set's last run's k_stage1_decide (stream A) still reads its W pool: the set's next W phase waits for it
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_last = nullptr;            // end of the last run this context queued (the book: "runs on the device")
-    // HIP-event pairs around the dominant kernel of every run since the last collection (bench.py's roofline leg)
+    // HIP-event pairs around the BandEd launches of every run since the last collection (bench.py's roofline legs), by kind:
+    // 0 score-only pass of a BANDED run or of QuickEd's stage 3, 1 fill, 2 Hirschberg half pass
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+    std::vector<int> kev_kind;
     size_t kev_used = 0;
-    std::pair<hipEvent_t, hipEvent_t>* kernel_events() {
+    std::pair<hipEvent_t, hipEvent_t>* kernel_events(int kind) {
         if (kev_used >= 4096) return nullptr;
         if (kev_used == kev.size()) {
             hipEvent_t a, b;
             HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
             kev.emplace_back(a, b);
+            kev_kind.push_back(0);
         }
+        kev_kind[kev_used] = kind;
         return &kev[kev_used++];
     }
     void phase_w() { ensure_set(ai); stream = sw(); scratch_p = &pw(); }
