@@ -19,8 +19,12 @@
 extern "C" {
 #endif
 
-/* selects the HIP device used by subsequent calls of this thread (default 0) */
+/* selects the HIP device used by subsequent calls of this thread (default 0).  One process may drive every GPU of a node:
+ * a host thread per device, each with its own aligner / batch objects (tools/align_benchmark.cpp -t N: the reference's one
+ * aligner per thread, align_benchmark.c:246-249, mapped to devices); pairs are sharded, there is no data-path collective. */
 quicked_status_t quicked_set_device(int device);
+/* HIP devices this process sees (0 if there is no usable runtime) */
+int quicked_device_count(void);
 
 /* Convenience form: n pairs given as host pointers.  scores_out[n];
  * cigars_out may be NULL (scores only); otherwise cigars_out[i] is a

@@ -68,8 +68,8 @@ def build_harness(force=False):
     src = os.path.join(ROOT, "tools", "align_benchmark.cpp")
     os.makedirs(os.path.dirname(HARNESS), exist_ok=True)
     if force or _newer(HARNESS, [src, HIP_LIB, os.path.join(ROOT, "include", "quicked_batch.h")]):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-I", os.path.join(ROOT, "include"), "-L", HERE, "-lquicked_hip",
-              "-Wl,-rpath," + HERE, "-o", HARNESS])
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", src, "-I", os.path.join(ROOT, "include"), "-L", HERE, "-lquicked_hip",
+              "-ldl", "-Wl,-rpath," + HERE, "-o", HARNESS])
     return HARNESS
 
 

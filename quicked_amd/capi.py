@@ -51,7 +51,7 @@ class Aligner(C.Structure):
 
 
 EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params", "quicked_new", "quicked_free",
-           "quicked_align", "quicked_set_device", "quicked_align_batch", "quicked_batch_create",
+           "quicked_align", "quicked_set_device", "quicked_device_count", "quicked_align_batch", "quicked_batch_create",
            "quicked_batch_destroy", "quicked_batch_run", "quicked_batch_sync", "quicked_batch_scores",
            "quicked_batch_cigar_bytes", "quicked_batch_cigars", "quicked_batch_counters",
            "quicked_batch_kernel_time", "quicked_batch_kernel_times", "quicked_host_alloc", "quicked_host_free",

@@ -213,25 +213,21 @@ static PairView pair_view(const quicked_batch& B, bool reversed) {
 // workgroup is 4 waves -- the CU spreads them one per SIMD -- and claims a third-plus of the CU's LDS, so
 // at most two workgroups share a CU and no SIMD ever holds more than two of these waves, whichever
 // kernels and streams they come from.  A second kernel on another stream then fills exactly the SIMD
-// slots the first one left empty, at no cost to either.  QE_WG_WAVES / QE_PIN_LDS override the shape.
+// slots the first one left empty, at no cost to either.
 // ---------------------------------------------------------------------------
 template <typename Kernel, typename Args>
 static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ngroups, int max_waves, size_t lds_per_wave, bool chain = false) {
     if (ngroups == 0) return;
-    int wpb = 4;
-    static const int wpb_env = env_int("QE_WG_WAVES", 0);
-    if (wpb_env > 0) wpb = std::min(wpb_env, max_waves);
+    const int wpb = std::min(4, max_waves);
     const unsigned blocks = (unsigned)((ngroups + wpb - 1) / wpb);
     // 54 KB: 3 x 54 KB > 160 KB >= 2 x 54 KB, two workgroups per CU.  When the launches in flight have fewer workgroups than
     // the chip has CUs, 84 KB (one per CU): the dispatcher packs the workgroups of CONCURRENT small kernels two to a CU
     // while other CUs idle (three 49-workgroup launches in flight: 16.5 ms each at 54 KB, 11.7 ms at 84 KB, 11.4 ms alone)
-    static const int pin_env = env_int("QE_PIN_LDS", 0);
-    size_t pin = pin_env > 0 ? (size_t)pin_env : (((size_t)blocks * (size_t)std::max(1, C.in_flight) > 256) ? (size_t)54 * 1024 : (size_t)84 * 1024);
+    size_t pin = ((size_t)blocks * (size_t)std::max(1, C.in_flight) > 256) ? (size_t)54 * 1024 : (size_t)84 * 1024;
     // chain: a launch of few waves whose duration is one wave's serial chain (WindowEd on a few thousand long reads: 157
     // waves of 1563 windows each).  108 KB: no 54 KB workgroup fits beside it, so its waves have their SIMDs to themselves
     // instead of sharing them with the fill of the run before (config 4: the stage took 59 ms beside that fill, 36 alone)
-    static const int chain_env = env_int("QE_PIN_CHAIN", 108 * 1024);
-    if (chain && pin_env == 0 && (size_t)blocks * (size_t)std::max(1, C.in_flight) <= 128 && chain_env > 0) pin = (size_t)chain_env;
+    if (chain && (size_t)blocks * (size_t)std::max(1, C.in_flight) <= 128) pin = (size_t)108 * 1024;
     const size_t lds = std::max(pin, lds_per_wave * (size_t)wpb);
     static thread_local std::vector<std::pair<const void*, int>> configured;      // per host thread and device
     const void* fn = reinterpret_cast<const void*>(kernel);
@@ -482,9 +478,8 @@ static int coop_lanes(const TaskList& L, int in_flight = 1, bool fill = false) {
     // the band-height test first + 2 < last must stay decidable G - 2 chunks early: a band of >= 3 G + 4 slots always is;
     // with 2 G + 4 a task whose band comes within G slots of its minimum height is flagged and recomputed by the one-lane
     // kernel -- rare, and worth it where the launch is short of waves anyway (4 000 pairs of 10 kb: 4.2 -> 2.8 ms with G = 8)
-    static const int tall_env = env_int("QE_COOP_TALL", 3);
-    while (G > 1 && min_nsl < tall_env * G + 4) G /= 2;
-    if (!e && tall_env == 3)
+    while (G > 1 && min_nsl < 3 * G + 4) G /= 2;
+    if (!e)
         while (G < 64 && min_nsl >= 2 * (2 * G) + 4 && ((live * G) / 64) * (size_t)std::max(1, in_flight) < 512) G *= 2;
     return G < 2 ? 1 : G;
 }
@@ -614,7 +609,6 @@ struct PendingFetch {
 // passes (tfin == n: no stopped band to export) and a band that fits the wave.  QE_WAVE = 0 / 1 switches the form off /
 // forces it wherever it is eligible (tests).
 static bool wave_form_wanted(const TaskList& L) {
-    static const int max_env = env_int("QE_WAVE_MAX", 1024);
     const int force = env_int("QE_WAVE", -1);
     if (force == 0) return false;
     size_t live = 0;
@@ -625,7 +619,7 @@ static bool wave_form_wanted(const TaskList& L) {
         n_max = std::max(n_max, L.n[t]);
         if (L.tfin[t] != L.n[t] || host_geometry(L.m[t], L.n[t], L.cutoff[t]).ebb_local > 62) return false;
     }
-    return live > 0 && (force == 1 || (live <= (size_t)max_env && n_max >= 4096));
+    return live > 0 && (force == 1 || (live <= 1024 && n_max >= 4096));
 }
 
 static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int timed) {
@@ -884,8 +878,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         }
         const int Gf = coop_lanes(F);
         // forward half passes on the run's stream, reverse ones beside them on the side stream, joined before k_join
-        static const int side_env = env_int("QE_SIDE_STREAM", 1);
-        hipStream_t main_s = C.stream, side = side_env ? C.side_stream() : main_s;
+        hipStream_t main_s = C.stream, side = C.side_stream();
         if (side != main_s) { HIP_CHECK(hipEventRecord(C.ev_fork, main_s)); HIP_CHECK(hipStreamWaitEvent(side, C.ev_fork, 0)); }
         const ScoreLaunch SF = (Gf >= 2) ? launch_banded_coop(B, C, F, false, Gf, 3) : launch_banded_score(B, C, F, false, 3);
         C.stream = side;
@@ -1482,7 +1475,6 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     // Three sets: up to three runs of a thread are on the device at once (measured on 100 k x 10 kb: 6.69 -> 6.88 M/s
     // BandEd, 4.70 -> 5.31 M/s QuickEd + CIGAR against two; four are slower again).  Two when three fill matrices of the
     // size this batch needed last time would not fit (config 4: 94 GB each): sub-batching the fill costs more.
-    static const int na_env = env_int("QE_NA", 0);
     DeviceBook& book = g_book[C.device];
     // another thread ran out of memory after every reclaim: this one gives its pools back (its runs are waited for) and runs
     // with one set for a while
@@ -1549,7 +1541,6 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         if (deep && (double)min_set * k > 0.25 * (double)total0) continue;
         if ((double)min_set * k <= ((deep && k > sets_held) ? 0.6 : 1.0) * (double)avail) { na = k; break; }
     }
-    if (na_env > 0) na = std::min(std::min(na_env, (int)Context::NA), B.np_alloc);
     if (C.memory_tight && C.tight_left-- <= 0) { C.memory_tight = false; C.tight_left = 0; }      // the spell is over: plan normally again
     if (C.memory_tight) na = 1;
     // Sets outside the rotation keep their pools while this run's plan works without that memory -- the next batch may
@@ -1581,8 +1572,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         PinnedStage& st = C.stage[C.si];
         if (!st.done) HIP_CHECK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
         st.reset();                           // its last user is 2 na runs back: over unless the host is that far ahead
-        static const int staging_env = env_int("QE_STAGING", 1);
-        C.staging = staging_env != 0;
+        C.staging = true;
     }
     if (serial) {
         C.phase_a(); C.pa().reset();
@@ -1990,9 +1980,15 @@ QE_API void* quicked_host_alloc(size_t bytes) {
 }
 QE_API void quicked_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+QE_API int quicked_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return std::min(count, (int)QE_MAX_DEVICES);
+}
+
 QE_API quicked_status_t quicked_set_device(int device) {
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return QUICKED_ERROR;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count || device >= QE_MAX_DEVICES) return QUICKED_ERROR;
     tl_device = device;
     return QUICKED_OK;
 }

@@ -226,6 +226,44 @@ def test_align_benchmark_harness(tmp_path):
     assert [l for l in r.stderr.splitlines() if "Time.Align " in l][0].rstrip().endswith("(2 calls)")
 
 
+def test_align_benchmark_worker_threads_write_the_same_file(tmp_path):
+    """tools/align_benchmark -t N: the reference's parallel mode (N aligners over disjoint pairs of every block,
+    align_benchmark.c:246-284) as N host threads with an aligner each, worker g on device g % devices, reading / aligning /
+    writing overlapped.  On this one-GPU box both workers share device 0 (the totals are then summed on the host; with
+    several devices they go through ncclAllReduce): the output file must be byte-identical to -t 1's, whatever the job size,
+    and the totals the same."""
+    import re
+    import subprocess
+    from quicked_amd import build
+    exe = build.build_harness()
+    batch = datagen.generate(count=600, length=1200, error=0.06, seed=78)
+    hard = datagen.generate(count=40, length=1200, error=0.06, seed=79, indels_num=2, indels_len=150)
+    pairs = list(batch.pairs()) + list(hard.pairs()) + [(b"ACGT", b""), (b"ACGTACGT", b"ACGAACGT")]
+    seq = tmp_path / "in.seq"
+    with open(seq, "wb") as f:
+        for p, t in pairs:
+            f.write(b">" + p + b"\n<" + t + b"\n")
+    outs, sums = {}, {}
+    for tag, extra in (("t1", []), ("t2", ["-t", "2"]), ("t3", ["-t", "3", "--batch-size", "100"]), ("t4", ["-t", "4", "--devices", "1"])):
+        out = tmp_path / f"{tag}.out"
+        r = subprocess.run([exe, "-a", "quicked", "-i", str(seq), "-o", str(out), "-c", "correct", "--batch-size", "128"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = out.read_bytes()
+        sums[tag] = re.search(r"Score\.sum (-?\d+)", r.stderr).group(1)
+        assert f"Total.reads              {len(pairs)}" in r.stderr, r.stderr
+        assert f"Alignments.Correct     {len(pairs) - 1}/{len(pairs) - 1}" in r.stderr, r.stderr      # the empty-text pair has no alignment
+    lines = outs["t1"].decode().splitlines()
+    assert len(lines) == len(pairs)
+    for i in list(range(0, len(pairs), 37)) + [len(pairs) - 1]:
+        st, sc, cg = O.oracle_align(*pairs[i], algo=0)
+        assert lines[i] == f"{sc}\t{cg}", i
+    assert lines[len(pairs) - 2] == "-\t-"
+    for tag in ("t2", "t3", "t4"):
+        assert outs[tag] == outs["t1"], tag
+        assert sums[tag] == sums["t1"], (tag, sums)
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_randomised_shapes_and_params(seed, monkeypatch):
     """fuzz: ragged lengths 1..4000, mixed error rates, random algorithm parameters -- every score, status
