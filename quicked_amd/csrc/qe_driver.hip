@@ -445,6 +445,7 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
     a.o_maxrow = S.O.len;
     a.only_if = nullptr;
+    a.lane_rel = env_int("QE_LANE_REL", 1);
     auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;       // timed = kind + 1 (Context::kernel_events)
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     launch_groups(C, k_banded<false>, a, L.ngroups(), 8, 0);
@@ -549,6 +550,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     b.mat = nullptr; b.g_mat_off = S.D.mat_off;
     b.o_score = S.O.score; b.o_first = S.O.first; b.o_last = S.O.last; b.o_posv = S.O.posv; b.o_adv = S.O.adv;
     b.o_maxrow = S.O.len; b.only_if = S.O.hew;
+    b.lane_rel = env_int("QE_LANE_REL", 1);
     launch_groups(C, k_banded<false>, b, L.ngroups(), 8, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
@@ -1072,6 +1074,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             }
         }
         a.fill_multi = env_int("QE_FILL_MULTI", 1);
+        a.lane_rel = env_int("QE_LANE_REL", 1);
         launch_groups(C, k_banded<true>, a, (size_t)(g1 - g0), 8, 0);     // everything, or what the cooperative fill flagged
         if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
         TraceArgs tr;
@@ -1384,7 +1387,17 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     {
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const size_t mine = ledger_plan(&C, free_b, matrix_budget + ((size_t)1 << 30));
+        // what these pairs will need: their bounds are not known yet (stages 2 / 3 come first), so twice what the bandwidth
+        // cutoff would take -- pairs end up here because their bounds are large
+        size_t want = (size_t)256 << 20;
+        for (size_t t = 0; t < Ls.pair.size(); ++t) {
+            if (Ls.pair[t] < 0) continue;
+            const int m = Ls.m[t], n = Ls.n[t];
+            const HGeom G = host_geometry(m, n, 2 * max_cutoff(p.bandwidth, m, n));
+            want += (size_t)std::min<uint64_t>((uint64_t)(QE_CPC + 1) * (uint64_t)(n / 64 + 3) * (uint64_t)G.ebb * 16, (uint64_t)18 << 20);
+            want += (size_t)std::min<int64_t>((int64_t)m + n + 2, (int64_t)2 * G.cutoff + 8) * 15 + 512;
+        }
+        const size_t mine = ledger_plan(&C, free_b, want);
         const size_t other_pools = C.held.load() - std::min(C.held.load(), C.pa().cap + C.pw().cap);
         matrix_budget = std::min(matrix_budget, std::max(mine > other_pools ? mine - other_pools : (size_t)0, (size_t)256 << 20));
     }
@@ -1528,17 +1541,18 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     }
     // what the A pools of this thread may hold together: the device's free memory plus what its pools hold already, less
     // what the process's other contexts hold or have planned (the book, qe_pool.h), less this context's other pools
-    const size_t mine = ledger_plan(&C, free0, wanted);
+    size_t owed = 0;
+    const size_t mine = ledger_plan(&C, free0, wanted, &owed);
     const size_t not_a = C.held.load() - std::min(C.held.load(), pools_held);
     const size_t avail = mine > not_a ? mine - not_a : 0;
     int na = 1;
     // beyond three sets only with room to spare -- the plan does not see the batches' result arenas or what the caller
-    // allocates next -- and within a quarter of the device: depth is for small batches, whose sets are small
+    // allocates next -- and within 40 % of the device: depth is for small batches, whose sets are small
     int sets_held = 0;                                    // sets whose pools exist already: rotating over them costs nothing
     for (int q = 0; q < Context::NA; ++q) if (C.pool_a2[q].cap > ((size_t)1 << 28)) sets_held = q + 1;
     for (int k = std::min(depth_wanted, B.np_alloc); k >= 1; --k) {
         const bool deep = k > 3;
-        if (deep && (double)min_set * k > 0.25 * (double)total0) continue;
+        if (deep && (double)min_set * k > 0.4 * (double)total0) continue;
         if ((double)min_set * k <= ((deep && k > sets_held) ? 0.6 : 1.0) * (double)avail) { na = k; break; }
     }
     if (C.memory_tight && C.tight_left-- <= 0) { C.memory_tight = false; C.tight_left = 0; }      // the spell is over: plan normally again
@@ -1554,7 +1568,7 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
     C.last_na = na;
     C.in_flight = fetch ? 1 : na;
     B.np_used = na;
-    for (int q = 0; q < na; ++q)                        // a set that outgrew this thread's share (another thread has joined) too
+    for (int q = 0; q < na && owed > 0; ++q)            // a set that outgrew this thread's share while another thread waits for the room
         if (C.pool_a2[q].cap > ((size_t)1 << 30) && (double)C.pool_a2[q].cap > 1.25 * (double)C.pool_budget) {
             if (C.stream_a2[q]) HIP_CHECK(hipStreamSynchronize(C.stream_a2[q]));
             C.pool_a2[q].release_all();
@@ -1716,11 +1730,11 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         C.phase_a();
         // the batch has ONE result arena: the previous queued run of this batch (another stream of the rotation, possibly a
         // longer chain of kernels) must have put its results there before this run's overwrite them
-        if (B.last_parity >= 0 && B.last_parity != par && B.ev_done_set[B.last_parity]) HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_done[B.last_parity], 0));
+        if (B.last_parity >= 0 && B.last_parity != par && B.ev_done_set[B.last_parity] && !env_int("QE_DBG_NOSTASHWAIT", 0)) HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_done[B.last_parity], 0));
         stash_results(B, C, *pf);
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
-    HIP_CHECK(hipEventRecord(C.ev_last, C.sa()));
+    if (!env_int("QE_DBG_NOEVLAST", 0)) HIP_CHECK(hipEventRecord(C.ev_last, C.sa()));
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
     B.last_parity = par;
     if (C.staging) { HIP_CHECK(hipEventRecord(C.stage[C.si].done, C.sa())); C.stage[C.si].pending = true; C.staging = false; }

@@ -924,8 +924,17 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
         u64 T0 = 0, T1 = 0, TN = 0;
         if (on) load_planes(tp, t0 + 64 * k, T0, T1, TN);
         const int rhi = min(last, nw - 1 - pos_v);                 // rows >= nw are never computed (A.7(2))
-        const int i0 = wave_min(on ? first : 0x7fffffff);
-        const int i1 = wave_max(on ? rhi : -0x7fffffff);
+        // The slots a wave walks in this chunk.  Uniform batches: every lane's band sits at the same slots, the wave walks
+        // first .. last of all of them (i = x).  Pairs whose paths drift apart (large indels: the bands of a wave's 64
+        // lanes, a few slots tall each, lie scattered over 40-60 slots) would make every lane wait through the UNION of the
+        // bands; lane-relative, step x of a chunk is slot first + x of each lane's own band, and the walk is as long as the
+        // tallest band.  The rows a lane touches are then its own (state, checkpoints and carry words are [slot][lane]
+        // rows: a wave's access is one row only while its lanes agree on the slot), which costs less than the idle steps.
+        const int fmin = wave_min(on ? first : 0x7fffffff), fmax = wave_max(on ? first : -0x7fffffff);
+        const bool rel = A.lane_rel != 0 && fmin < fmax;
+        const int ib = rel ? (on ? first : 0) : 0;
+        const int i0 = rel ? 0 : fmin;
+        const int i1 = rel ? wave_max(on ? rhi - first : -0x7fffffff) : wave_max(on ? rhi : -0x7fffffff);
         u64 hinP = QE_ONES, hinM = 0;
         // fill: the state and pattern planes of the NEXT single-slot pass are loaded before the current one computes
         // (unconditionally, indices clamped; issued ahead of the pass's checkpoint stores they return under its compute --
@@ -942,8 +951,9 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
             if (unaligned) { qa1 = w[3]; qb1 = w[4]; }            // Hirschberg children start anywhere in their pair's pattern
             qi = j;
         };
-        if (FILL) prefetch(i0);
-        for (int i = i0; i <= i1; ++i) {
+        if (FILL) prefetch(i0 + ib);
+        for (int x = i0; x <= i1; ++x) {
+            const int i = x + ib;
             const bool act = on && i >= first && i <= rhi;
             const int r = i + pos_v;
             if (!FILL) {
@@ -956,10 +966,10 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
                     return !__any(bad);
                 };
                 if (i == first) { hinP = QE_ONES; hinM = 0; }
-                if (i + 3 <= i1 && uniform(4)) { slots_pass<4>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); i += 3; continue; }
-                if (i + 1 <= i1 && uniform(2)) { slots_pass<2>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); i += 1; continue; }
+                if (x + 3 <= i1 && uniform(4)) { slots_pass<4>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); x += 3; continue; }
+                if (x + 1 <= i1 && uniform(2)) { slots_pass<2>(act, i, r, Pv, Mv, S, S, 64, pp, p0, T0, T1, hinP, hinM, adv); x += 1; continue; }
             }
-            if (FILL && QE_FILL_K > 1 && A.fill_multi && i + QE_FILL_K - 1 <= i1) {
+            if (FILL && QE_FILL_K > 1 && A.fill_multi && x + QE_FILL_K - 1 <= i1) {
                 // K slots in one skewed pass, every lane with the slots inside its own band, unless a lane needs the
                 // general form for one of them (partial chunk, N, the pattern's last block row)
                 constexpr int K = QE_FILL_K;
@@ -1000,7 +1010,7 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
                         }
                     }
                     hinP = oP[K - 1]; hinM = oM[K - 1];
-                    i += K - 1;
+                    x += K - 1;
                     continue;
                 }
             }

@@ -483,23 +483,29 @@ static Context& ctx() {
 // its pools hold.  Contexts re-plan before every run, so a thread that had the device to itself is down to its share one
 // run after a second one shows up.
 // ---------------------------------------------------------------------------
-static size_t ledger_plan(Context* me, size_t free_now, size_t wanted) {
+static size_t ledger_plan(Context* me, size_t free_now, size_t wanted, size_t* owed = nullptr) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     me->wanted = wanted;
     std::vector<Context*> active;
     for (Context* c : g_ctx_all)
         if (c != me && c->device == me->device && c->planned > c->held.load() && (c->in_call.load() || c->runs_on_device())) active.push_back(c);
     const double space = 0.92 * (double)(free_now + g_book[me->device].held.load());          // what all pools of this device may hold together
-    double others = 0;
+    double others = 0, growth = 0;
     for (Context* c : g_ctx_all) {
         if (c == me || c->device != me->device) continue;
-        double claim = (double)c->held.load();
+        const double h = (double)c->held.load();
+        double claim = h;
         if (std::find(active.begin(), active.end(), c) != active.end())
             claim = std::max(claim, std::min((double)c->planned, space / (double)(active.size() + 1)));
         others += claim;
+        growth += claim - h;
     }
     const size_t mine = (size_t)std::max(space - others, 0.0);
     me->planned = std::min(mine, wanted);
+    // what the others have planned to grow by and will not find free: only then does this context have to hand memory back
+    // (a pool above its budget is left alone while nobody needs the room: giving back and re-allocating tens of GB because
+    // another thread's plan came and went costs more than anything it could save)
+    if (owed) *owed = (size_t)std::max(growth - 0.92 * (double)free_now, 0.0);
     return mine;
 }
 

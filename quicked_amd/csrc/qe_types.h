@@ -82,6 +82,7 @@ struct BandedArgs {
     int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;  int32_t* o_maxrow;
     const int32_t* only_if;  // run only tasks whose flag is non-zero (fallback pass after k_banded_coop); may be null
     int32_t fill_multi = 1;  // fill: K-slot skewed passes where no lane needs the general form (0: single-slot passes only; tests)
+    int32_t lane_rel = 1;    // every lane walks ITS band (slot first + j at step j of a chunk) instead of the wave walking the union of its lanes' bands (0: tests)
 };
 
 // BandEd score-only, G lanes per alignment (cooperative form of k_banded<false>)

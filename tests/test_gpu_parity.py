@@ -368,6 +368,38 @@ def test_fill_multi_slot_passes_forced(multi, monkeypatch):
                 assert out[i] == want, (multi, kw, i, len(p), len(t))
 
 
+@pytest.mark.parametrize("rel", ["1", "0"])
+def test_lane_relative_band_walk_forced(rel, monkeypatch):
+    """k_banded walks, in every chunk, either the union of its 64 lanes' bands (QE_LANE_REL = 0) or every lane's own band
+    from its own top slot (1, default; what pairs whose paths drift apart need: large indels scatter the tight QuickEd
+    bands of a wave over dozens of slots).  Same cells either way: scores, CIGARs AND the block-advance counters equal the
+    oracle's, for the fill (QuickEd, BandEd, Hirschberg leaves) and for the score-only kernel, on a batch that mixes
+    ordinary pairs with large-indel ones of several lengths."""
+    monkeypatch.setenv("QE_LANE_REL", rel)
+    rng = np.random.default_rng(17)
+    pairs = []
+    for i in range(160):
+        L = int(rng.choice([900, 2000, 4000, 7000]))
+        ind = int(rng.integers(0, 4)) if L >= 2000 else 0
+        p, t = next(datagen.generate(1, L, 0.05, seed=9300 + i, indels_num=ind, indels_len=int(rng.choice([100, 300, 600]))).pairs())
+        pairs.append((p, t))
+    batch = datagen.PairBatch(*_pools(pairs))
+    for kw, slot, key in ((dict(algo=0), 1, "fill_block_advances"), (dict(algo=2, bandwidth=40), 1, "fill_block_advances"),
+                          (dict(algo=3, bandwidth=40), 1, "fill_block_advances"), (dict(algo=2, bandwidth=40, only_score=True), 0, "score_block_advances")):
+        s, st, cg, cnt = gpu_batch(batch, **kw)
+        work = 0
+        for i, (p, t) in enumerate(pairs):
+            est, esc, ecg, tr = O.oracle_align(p, t, trace=True, **kw)
+            work += tr[key]
+            in_domain = kw["algo"] == 0 or O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+            if in_domain:
+                assert (st[i], s[i]) == (est, esc), (rel, kw, i)
+                if cg is not None:
+                    assert cg[i] == ecg, (rel, kw, i)
+        if kw["algo"] != 3:                    # Hirschberg's half passes count into the score-only slot
+            assert cnt[slot] == work, (rel, kw, int(cnt[slot]), work)
+
+
 @pytest.mark.parametrize("lds", ["1", "0"])
 def test_cooperative_kernel_forced(lds, monkeypatch):
     """QE_COOP_G forces the G-lanes-per-alignment kernel (and its fallback pass) on shapes the host would not pick it for:
