@@ -38,9 +38,11 @@ import threading
 import time
 
 # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one
-# serialise; the library asks for 24 when it is loaded, but under a launcher torch initialises HIP first -- so ask here too,
-# before anything imports torch.  A value the user has set is left alone.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# serialise; a thread's runs rotate over up to 12 stream sets.  The runtime reads the variable when it initialises, so it is
+# set here, before anything imports torch (a value the user has set is left alone).  20, not more: once a process has
+# created 24 hardware queues -- they stay for its lifetime, whatever happens to the streams -- an 11-deep stream of
+# 12.5 k-pair batches runs at 4.3 instead of 6.4 M alignments/s (tools/probe_leftover2.py: 14, 16 and 20 are immune).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -417,10 +419,11 @@ def mixed_leg(capi, datagen, pairs, length, error, share, steps=24, slots=4, cpu
                 raise RuntimeError("quicked_batch_run failed")
             gpu_scores = rb.scores()[0]
             checks.append(int(gpu_scores.astype("int64").sum()))
-        for rb in rbs:                                      # the fast flow, once, outside the clock (pools, estimates)
-            rb.run(p, sync=False)
-        for rb in rbs:
-            rb.fetch()
+        for _ in range(2):                                  # the fast flow, twice, outside the clock: pools, estimates, and both host-side
+            for rb in rbs:                                  # result sets of every batch object (its first early finish allocates the second:
+                rb.run(p, sync=False)                       # ~0.1 s of pinned memory for 100 k pairs' strings)
+            for rb in rbs:
+                rb.fetch()
         todo, free, deferred, bad = queue.Queue(), queue.Queue(), [], []
         for rb in rbs:
             free.put(rb)
@@ -886,6 +889,22 @@ def main():
                 strong_share[wl] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "runs_in_flight", "single_batch_latency_ms",
                                                        "single_batch_value", "score_checksum")}
                 strong_share[wl]["aggregate_block_columns_per_s"] = o["valu"]["aggregate_block_columns_per_s"]
+            if "quicked" in wls and args.mixed_share > 0 and args.indels_num == 0:
+                # the same share with realistic data: 1 % of every 12.5 k-pair batch leaves the fast flow.  A flow for a hundred
+                # pairs lasts as long as one for thousands (launch latency), so the early-finish threads serve the pairs of
+                # every run that is over with ONE flow (quicked_early_finish_stats: merged flows)
+                B._cache = None
+                B.capi.pool_trim()
+                try:
+                    before = B.capi.early_finish_stats()
+                    o = mixed_leg(B.capi, B.datagen, STRONG_SHARE_PAIRS, args.length, args.error, args.mixed_share, steps=96, slots=14)
+                    after = B.capi.early_finish_stats()
+                    strong_share["quicked_mixed"] = {k: o[k] for k in ("value", "unit", "ms_per_batch", "batches", "batch_objects", "hard_pairs",
+                                                                         "pairs_finished_outside_the_fast_flow_per_run", "early_finish_threads",
+                                                                         "score_checksum") if k in o} or o
+                    strong_share["quicked_mixed"]["early_finish_flows"] = {k: after[k] - before[k] for k in after}
+                except Exception as e:      # noqa: BLE001
+                    strong_share["quicked_mixed"] = {"error": repr(e)}
 
     if default_shape and args.mixed_share > 0 and args.indels_num == 0 and world == 1:
         # ordinary pairs with a few large-indel ones among them: what the fast flow's overflow path and the early-finish

@@ -159,6 +159,12 @@ quicked_status_t quicked_batch_counters(quicked_batch_t* batch, int64_t counters
  * fetches should check this, bench.py does) */
 int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch);
 
+/* Early-finish threads, process-wide since load: [0] host-driven flows they ran, [1] batch objects those finished, [2] flows
+ * that served the pairs of SEVERAL batch objects at once (the runs that were over when the thread got to work: the flow's
+ * duration is launch latency, not pairs), [3] batch objects in such flows.  QE_FINISH_MERGE (default 4) caps the batch
+ * objects per flow; 1 = never merge. */
+quicked_status_t quicked_early_finish_stats(int64_t stats_out[4]);
+
 /* The device-pool planner's view of the calling thread (replaces mm_allocator, quicked_utils/src/mm_allocator.c:141-426):
  *   [0] bytes its pools hold   [1] allocations that had to take memory from this thread's other pools or from other threads
  *   (process-wide; the planner is there to keep this 0)   [2] pool sets in rotation in the last run   [3] fill sub-batches of

@@ -58,7 +58,7 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
            "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
            "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats", "quicked_batch_cigar_view",
-           "quicked_batch_deferred_pairs", "quicked_wire_pack_pool", "quicked_wire_offsets", "quicked_wire_pack_isa", "quicked_pool_trim"]
+           "quicked_batch_deferred_pairs", "quicked_wire_pack_pool", "quicked_wire_offsets", "quicked_wire_pack_isa", "quicked_pool_trim", "quicked_early_finish_stats"]
 
 _LIB = None
 
@@ -77,7 +77,8 @@ def lib():
     # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that
     # share one serialise; a thread's runs rotate over up to 12 stream sets.  The runtime reads the variable when it
     # initialises, so the embedding application sets it before its first HIP call; this binding is one.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    # 20: with 24 queues in existence the hardware oversubscribes and small-batch streams lose a third of their rate.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
     L = C.CDLL(path)
     L.quicked_check_error.restype = C.c_bool
     L.quicked_check_error.argtypes = [C.c_int]
@@ -104,7 +105,8 @@ def lib():
     L.quicked_batch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_counters.argtypes = [C.c_void_p, C.c_void_p]
     L.quicked_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    L.quicked_batch_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(L, "quicked_batch_kernel_times"):      # (an older build loaded through QUICKED_HIP_LIB for an A/B run lacks the newer symbols)
+        L.quicked_batch_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.quicked_batch_check_results.argtypes = [C.c_void_p, C.c_void_p]
     L.quicked_batch_validate.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -117,6 +119,8 @@ def lib():
     L.quicked_batch_reload_packed.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.quicked_batch_fetch.argtypes = [C.c_void_p]
     L.quicked_pool_stats.argtypes = [C.c_void_p]
+    if hasattr(L, "quicked_early_finish_stats"):
+        L.quicked_early_finish_stats.argtypes = [C.c_void_p]
     L.quicked_batch_cigar_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.quicked_batch_deferred_pairs.restype = C.c_int64
     L.quicked_batch_deferred_pairs.argtypes = [C.c_void_p]
@@ -145,6 +149,13 @@ def pool_stats():
     lib().quicked_pool_stats(v.ctypes.data)
     return dict(pool_bytes=int(v[0]), reclaim_events=int(v[1]), sets=int(v[2]), sub_batches=int(v[3]), pool_budget=int(v[4]),
                 device_pool_bytes=int(v[5]), contexts=int(v[6]), contexts_leased=int(v[7]))
+
+
+def early_finish_stats():
+    """quicked_early_finish_stats: dict(flows, batches, merged_flows, merged_batches)"""
+    v = np.zeros(4, dtype=np.int64)
+    lib().quicked_early_finish_stats(v.ctypes.data)
+    return dict(flows=int(v[0]), batches=int(v[1]), merged_flows=int(v[2]), merged_batches=int(v[3]))
 
 
 def make_params(**kw):

@@ -158,6 +158,10 @@ struct quicked_batch {
     int cigar_style = 0;                          // SegFormatArgs::style of the runs to come (quicked_batch_configure)
     bool check = false;                           // validate every CIGAR on the device (k_check_segs)
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // of the run being queued / fetched (copied to wr->counters at its end)
+    // per-pair share of the counters [n][8], kept only by the object that stands in for the pairs of SEVERAL batch objects
+    // in a merged early finish (qe::merged_finish): every batch gets exactly the counts of its own pairs back
+    std::vector<int64_t> credit;
+    void note_pair(int pair, int slot, int64_t amount) { if (!credit.empty() && pair >= 0) credit[(size_t)pair * 8 + (size_t)slot] += amount; }
     // results of the last run, device side, indexed by task (what a timed run leaves in HBM)
     int32_t* d_score = nullptr;
     bool pending = false;
@@ -737,6 +741,7 @@ static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, co
         B.wr->status[pr] = root_status ? (*root_status)[i] : ok_status;
         if (edits[i] < 0) { B.wr->score[pr] = -1; B.wr->status[pr] = QUICKED_ERROR; }      // run-buffer overflow: cutoff below the distance
         B.counters[4] += nops[i];
+        B.note_pair(pr, 4, nops[i]);
         if (A.ok) B.wr->check_ok[pr] = okv[i];
         if (want_strings && len[i] > 0) B.wr->cigar_off[pr] = (int64_t)base + off[i];      // NUL-terminated in the pool
     }
@@ -820,7 +825,7 @@ static uint64_t split_threshold() {
     return e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 24);
 }
 static bool trace_on() { static int v = -1; if (v < 0) v = getenv("QE_TRACE") ? 1 : 0; return v == 1; }
-#define QE_TRACE_POINT(name) do { if (trace_on()) { double t__ = now_ms(); fprintf(stderr, "[qe] %-22s +%.3f ms\n", name, t__ - tr_last); tr_last = t__; } } while (0)
+#define QE_TRACE_POINT(name) do { if (trace_on()) { double t__ = now_ms(); fprintf(stderr, "[qe t%03d @%.1f] %-22s +%.3f ms\n", (int)(syscall(SYS_gettid) % 1000), t__, name, t__ - tr_last); tr_last = t__; } } while (0)
 
 static void reset_host_results(quicked_batch& B) {
     B.wr->score.assign((size_t)B.n, -1);
@@ -906,6 +911,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         QE_TRACE_POINT("  level: half passes+join");
         C.scratch_p->release(mark);
         if (stats) { stats->score_adv += sum_u32(advf) + sum_u32(advv); stats->splits += ns; }
+        for (size_t k = 0; k < ns; ++k) B.note_pair(nodes[split[k]].pair, 0, (int64_t)advf[k] + (int64_t)advv[k]);
         frontier.clear();
         for (size_t k = 0; k < ns; ++k) {
             const int32_t id = split[k];
@@ -1103,7 +1109,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             std::vector<u32> adv, steps;
             d2h(adv, O.adv, nt, C.stream); d2h(steps, O.steps, nt, C.stream);
             HIP_CHECK(hipStreamSynchronize(C.stream));
-            for (size_t t = 0; t < nt; ++t) if (LL.pair[t] >= 0) { stats->fill_adv += adv[t]; stats->tb_steps += steps[t]; }
+            for (size_t t = 0; t < nt; ++t) if (LL.pair[t] >= 0) { stats->fill_adv += adv[t]; stats->tb_steps += steps[t]; B.note_pair(LL.pair[t], 1, adv[t]); B.note_pair(LL.pair[t], 3, steps[t]); }
         }
         fetch_alignments(B, C, SL, AO, want_cigar, ok_status, &root_status);
     }
@@ -1196,6 +1202,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
         }
         if (whole_batch && B.est_bound >= 0) B.est_bound = quicked_estimate(stage1_bounds);      // what the fast path sizes the next run's align step for
         B.counters[6] = (int64_t)idx2.size();
+        for (size_t t : idx2) B.note_pair(L.pair[t], 6, 1);
         if (!idx2.empty()) {
             L2.pad();
             if (!B.have_rev[B.parity]) { launch_pack(B, C, true); B.have_rev[B.parity] = true; }
@@ -1220,6 +1227,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
             }
             qe_timer_stop(tl_timers.windowed_l);
             B.counters[2] += (int64_t)sum_u32(F.steps) + (int64_t)sum_u32(V.steps);
+            for (size_t k = 0; k < idx2.size(); ++k) B.note_pair(L2.pair[k], 2, (int64_t)F.steps[k] + (int64_t)V.steps[k]);
             TaskList L3; std::vector<size_t> idx3;
             for (size_t k = 0; k < idx2.size(); ++k) {
                 const size_t t = idx2[k];
@@ -1236,6 +1244,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
                 }
             }
             B.counters[7] = (int64_t)idx3.size();
+            for (size_t t : idx3) B.note_pair(L.pair[t], 7, 1);
             // band doubling (quicked.c:248-278): relaunch on the subset that has not converged
             int rounds = 0;
             while (!idx3.empty()) {
@@ -1251,6 +1260,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
                 run_banded_score(B, C, L3, false, &S3, true, nullptr);
                 qe_timer_stop(tl_timers.banded);
                 B.counters[0] += (int64_t)sum_u32(S3.adv);
+                for (size_t k = 0; k < idx3.size(); ++k) B.note_pair(L3.pair[k], 0, (int64_t)S3.adv[k]);
                 TaskList Ln; std::vector<size_t> idxn;
                 for (size_t k = 0; k < idx3.size(); ++k) {
                     const size_t t = idx3[k];
@@ -1346,40 +1356,57 @@ static bool quicked_fast_wanted(const quicked_batch& B, const Context& C, const 
     return true;
 }
 
-// after a fast run has completed: which pairs still need the classic flow; the next run's estimate
-static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_params_t& p, const TaskList& L, const int32_t* d_cut,
-                                const int32_t* d_skip, const u32* d_steps, size_t matrix_budget, int parity) {
+// after a fast run has completed: which pairs still need the classic flow (they keep their stage-1 results: the bound and
+// whether stage 2 follows); the next run's estimate
+struct FastLeft { TaskList Ls; KnownStage1 K1; };
+static bool fast_finish_collect(quicked_batch& B, Context& C, const TaskList& L, const int32_t* d_cut, const int32_t* d_skip,
+                                const u32* d_steps, FastLeft& W) {
     const size_t nt = L.pair.size();
     std::vector<int32_t> cut, skip; std::vector<u32> steps;
     d2h(cut, d_cut, nt, C.stream); d2h(skip, d_skip, nt, C.stream); d2h(steps, d_steps, nt, C.stream);
     HIP_CHECK(hipStreamSynchronize(C.stream));
-    TaskList Ls;
-    KnownStage1 K1;                                // the pairs left keep their stage-1 results: bound and whether stage 2 follows
     std::vector<int32_t> stage1_bounds;
     for (size_t t = 0; t < nt; ++t) {
         if (L.pair[t] < 0) continue;
         if (!(skip[t] & 1)) stage1_bounds.push_back(cut[t]);
-        if (skip[t]) { Ls.push(L.pair[t], 0, L.m[t], 0, L.n[t], L.cutoff[t], L.n[t]); K1.score.push_back(cut[t]); K1.stage2.push_back((uint8_t)(skip[t] & 1)); }
+        if (skip[t]) { W.Ls.push(L.pair[t], 0, L.m[t], 0, L.n[t], L.cutoff[t], L.n[t]); W.K1.score.push_back(cut[t]); W.K1.stage2.push_back((uint8_t)(skip[t] & 1)); }
         B.counters[2] += steps[t];
     }
     B.est_bound = quicked_estimate(stage1_bounds);
-    B.wr->deferred_pairs = (int64_t)Ls.pair.size();
-    if (Ls.pair.empty()) return;
-    Ls.pad();
-    K1.score.resize(Ls.pair.size(), 0); K1.stage2.resize(Ls.pair.size(), 0);
-    // the classic flow for the pairs left, on idle streams, above whatever the pools hold (a later run of this thread
-    // may have its buffers there)
+    B.wr->deferred_pairs = (int64_t)W.Ls.pair.size();
+    return !W.Ls.pair.empty();
+}
+
+// what the pairs of a list will need from the pools before their bounds are known (stages 2 / 3 come first): twice what the
+// bandwidth cutoff would take -- pairs end up in the host-driven flow because their bounds are large
+static size_t classic_need_estimate(const quicked_params_t& p, const TaskList& Ls) {
+    size_t want = (size_t)256 << 20;
+    for (size_t t = 0; t < Ls.pair.size(); ++t) {
+        if (Ls.pair[t] < 0) continue;
+        const int m = Ls.m[t], n = Ls.n[t];
+        const HGeom G = host_geometry(m, n, 2 * max_cutoff(p.bandwidth, m, n));
+        want += (size_t)std::min<uint64_t>((uint64_t)(QE_CPC + 1) * (uint64_t)(n / 64 + 3) * (uint64_t)G.ebb * 16, (uint64_t)18 << 20);
+        want += (size_t)std::min<int64_t>((int64_t)m + n + 2, (int64_t)2 * G.cutoff + 8) * 15 + 512;
+    }
+    return want;
+}
+
+// The classic flow for the pairs a fast run left (W), on idle streams.  X is the batch object the pairs belong to, or the
+// stand-in for the pairs of several (merged_finish).
+static void fast_finish_classic(quicked_batch& X, Context& C, const quicked_params_t& p, FastLeft& W, size_t matrix_budget, int parity) {
+    W.Ls.pad();
+    W.K1.score.resize(W.Ls.pair.size(), 0); W.K1.stage2.resize(W.Ls.pair.size(), 0);
     C.sync_all();
     struct Restore {            // also when a HIP error unwinds through here
         quicked_batch& B; Context& C; int parity; bool staging; int32_t* score; DevicePool::Mark mw, ma;
         ~Restore() { C.pw().release(mw); C.pa().release(ma); C.phase_u(); B.parity = parity; C.staging = staging; B.d_score = score; }
-    } restore{B, C, B.parity, C.staging, B.d_score, C.pw().mark(), C.pa().mark()};
-    B.parity = parity;
+    } restore{X, C, X.parity, C.staging, X.d_score, C.pw().mark(), C.pa().mark()};
+    X.parity = parity;
     C.staging = false;
     // Everything this thread's pools hold is dead by now: its streams are idle (sync_all above), the run being fetched has
-    // its results on the host or in the batch's result arena, and the three small arrays read above were the last thing
-    // needed from the pools.  The classic flow for the pairs left starts the pools over instead of stacking its buffers
-    // on the fast flow's (76 k of 100 k indel-heavy pairs: 100 GB on top of 170 GB did not fit)
+    // its results on the host or in the batch's result arena, and the three small arrays read by the collect step were the
+    // last thing needed from the pools.  The classic flow for the pairs left starts the pools over instead of stacking its
+    // buffers on the fast flow's (76 k of 100 k indel-heavy pairs: 100 GB on top of 170 GB did not fit)
     C.pw().release(DevicePool::Mark{0, 0});
     C.pa().release(DevicePool::Mark{0, 0});
     // the budget is planned again, in THIS context (the caller's fetch, or an early-finish thread's): what the queueing
@@ -1387,24 +1414,20 @@ static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_para
     {
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        // what these pairs will need: their bounds are not known yet (stages 2 / 3 come first), so twice what the bandwidth
-        // cutoff would take -- pairs end up here because their bounds are large
-        size_t want = (size_t)256 << 20;
-        for (size_t t = 0; t < Ls.pair.size(); ++t) {
-            if (Ls.pair[t] < 0) continue;
-            const int m = Ls.m[t], n = Ls.n[t];
-            const HGeom G = host_geometry(m, n, 2 * max_cutoff(p.bandwidth, m, n));
-            want += (size_t)std::min<uint64_t>((uint64_t)(QE_CPC + 1) * (uint64_t)(n / 64 + 3) * (uint64_t)G.ebb * 16, (uint64_t)18 << 20);
-            want += (size_t)std::min<int64_t>((int64_t)m + n + 2, (int64_t)2 * G.cutoff + 8) * 15 + 512;
-        }
-        const size_t mine = ledger_plan(&C, free_b, want);
+        const size_t mine = ledger_plan(&C, free_b, classic_need_estimate(p, W.Ls));
         const size_t other_pools = C.held.load() - std::min(C.held.load(), C.pa().cap + C.pw().cap);
         matrix_budget = std::min(matrix_budget, std::max(mine > other_pools ? mine - other_pools : (size_t)0, (size_t)256 << 20));
     }
     C.phase_w();
     auto enter_a = [&]() { C.phase_a(); };
-    quicked_classic(B, C, p, Ls, true, matrix_budget, nullptr, enter_a, false, &K1);
+    quicked_classic(X, C, p, W.Ls, true, matrix_budget, nullptr, enter_a, false, &W.K1);
     C.sync_all();
+}
+
+static void quicked_fast_finish(quicked_batch& B, Context& C, const quicked_params_t& p, const TaskList& L, const int32_t* d_cut,
+                                const int32_t* d_skip, const u32* d_steps, size_t matrix_budget, int parity) {
+    FastLeft W;
+    if (fast_finish_collect(B, C, L, d_cut, d_skip, d_steps, W)) fast_finish_classic(B, C, p, W, matrix_budget, parity);
 }
 
 // The results of a run queued with sync == 0 move from the run's pool set into the batch's result arena at the end of the
@@ -1730,11 +1753,11 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
         C.phase_a();
         // the batch has ONE result arena: the previous queued run of this batch (another stream of the rotation, possibly a
         // longer chain of kernels) must have put its results there before this run's overwrite them
-        if (B.last_parity >= 0 && B.last_parity != par && B.ev_done_set[B.last_parity] && !env_int("QE_DBG_NOSTASHWAIT", 0)) HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_done[B.last_parity], 0));
+        if (B.last_parity >= 0 && B.last_parity != par && B.ev_done_set[B.last_parity]) HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_done[B.last_parity], 0));
         stash_results(B, C, *pf);
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
-    if (!env_int("QE_DBG_NOEVLAST", 0)) HIP_CHECK(hipEventRecord(C.ev_last, C.sa()));
+    HIP_CHECK(hipEventRecord(C.ev_last, C.sa()));
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
     B.last_parity = par;
     if (C.staging) { HIP_CHECK(hipEventRecord(C.stage[C.si].done, C.sa())); C.stage[C.si].pending = true; C.staging = false; }
@@ -1770,7 +1793,14 @@ static quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, b
 
 // quicked_batch_fetch: waits for the batch's last sync == 0 run and copies its results to the host-side arrays the
 // getters read -- what a sync != 0 run does at its end, only later (so that further runs can be queued meanwhile)
-static quicked_status_t fetch_pending(quicked_batch& B) {
+// left != nullptr: the pairs a fast QuickEd run left for the host-driven flow are only LISTED (merged early finish: one flow
+// for the pairs of several batch objects); the caller then runs it and calls fetch_finalize
+static void fetch_finalize(quicked_batch& B, bool quicked) {
+    if (quicked) for (auto& st : B.wr->status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+    memcpy(B.wr->counters, B.counters, sizeof(B.counters));
+    B.pending = false;
+}
+static quicked_status_t fetch_pending(quicked_batch& B, FastLeft* left = nullptr) {
     tl_device = B.device;
     Context& C = ctx();
     if (!B.pending_fetch) return B.pending ? QUICKED_ERROR : QUICKED_OK;      // nothing queued asynchronously
@@ -1809,11 +1839,11 @@ static quicked_status_t fetch_pending(quicked_batch& B) {
             B.counters[2] += (int64_t)sum_u32(steps);
         }
         fetch_alignments(B, C, F.SL, F.AO, F.want_strings, F.ok_status, F.root_status.empty() ? nullptr : &F.root_status);
-        if (F.fast) quicked_fast_finish(B, C, F.params, F.L, F.d_cut, F.d_skip, F.d_stage_steps, F.matrix_budget, F.parity);
-        if (F.quicked) for (auto& st : B.wr->status) if (st == QUICKED_FAIL_NON_CONVERGENCE) st = QUICKED_WIP;
+        if (F.fast && left) {
+            if (fast_finish_collect(B, C, F.L, F.d_cut, F.d_skip, F.d_stage_steps, *left)) return QUICKED_OK;      // the caller goes on
+        } else if (F.fast) quicked_fast_finish(B, C, F.params, F.L, F.d_cut, F.d_skip, F.d_stage_steps, F.matrix_budget, F.parity);
     }
-    memcpy(B.wr->counters, B.counters, sizeof(B.counters));
-    B.pending = false;
+    fetch_finalize(B, F.kind != 1 && F.quicked);
     return QUICKED_OK;
 }
 
@@ -1836,80 +1866,275 @@ static int g_fin_threads = 0, g_fin_idle = 0;
 static std::atomic<int> g_fin_busy{0};               // jobs being worked on
 static std::atomic<bool> g_fin_stop{false};          // the process is exiting: no new work
 
-static void finisher_work(const FinishJob& job) {
-    quicked_batch& B = *job.B;
-    PendingFetch& F = *static_cast<PendingFetch*>(job.pf.get());
+// One host-driven flow for the pairs that SEVERAL queued runs (of different batch objects) left: the flow's duration is a
+// chain of launch latencies -- 70-90 ms for 800 pairs or 4 000 alike -- so the pairs of every run that is over when an
+// early-finish thread gets to work are aligned together.  A stand-in batch object V holds those pairs: their lengths, the
+// addresses of their raw bytes in the batches' arenas (the validator and non-canonical input compare bytes), and a COPY of
+// their forward bit-planes, gathered into one buffer (a few MB); reversed planes come from those (k_reverse_planes, as for
+// packed input).  Results and the per-pair share of every work counter go back to the batch each pair came from.
+struct MergeItem {
+    quicked_batch* B; std::shared_ptr<void> pf; FastLeft W;
+    std::unique_lock<std::mutex> lk;                  // the batch's fin_mu, held from the collect step to the end
+    std::shared_ptr<void> keep;                       // what a failure puts back as the batch's pending fetch
+};
+// (the first `ni` entries of items)
+static void merged_finish(std::vector<MergeItem>& items, size_t ni, Context& C) {
+    const PendingFetch& F0 = *static_cast<const PendingFetch*>(items[0].pf.get());
+    const quicked_params_t p = F0.params;
+    C.phase_u();
+    quicked_batch*& V = *reinterpret_cast<quicked_batch**>(&C.merge_batch);
+    if (!V) V = new quicked_batch();
+    // ---- the pairs, renumbered 0 .. n-1 in item order
+    size_t n = 0;
+    for (size_t x = 0; x < ni; ++x) n += items[x].W.Ls.pair.size();
+    std::vector<int32_t> src_item(n), src_pair(n);
+    FastLeft WV;
+    V->n = (int64_t)n; V->device = C.device;
+    V->p_len.resize(n); V->t_len.resize(n); V->p_off.resize(n); V->t_off.resize(n); V->plp_off.resize(n); V->plt_off.resize(n);
+    V->order.resize(n);
+    std::iota(V->order.begin(), V->order.end(), 0);
+    std::vector<int64_t> g_src(2 * n), g_dst(2 * n);
+    std::vector<int32_t> g_nw(2 * n);
+    std::vector<u32> flags(n, 0);
+    const uint8_t* asc_base_p = items[0].B->d_asc_p; const uint8_t* asc_base_t = items[0].B->d_asc_t;
+    size_t wp = 0, wt = 0, j = 0;
+    size_t budget = 0;
+    for (size_t x = 0; x < ni; ++x) {
+        quicked_batch& B = *items[x].B;
+        const PendingFetch& F = *static_cast<const PendingFetch*>(items[x].pf.get());
+        budget = std::max(budget, F.matrix_budget);
+        std::vector<u32> bf;                              // the batch's pack flags (N / non-canonical symbols) of the run's plane set
+        d2h(bf, (const u32*)B.d_flags[F.parity], (size_t)B.n, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        const FastLeft& W = items[x].W;
+        for (size_t t = 0; t < W.Ls.pair.size(); ++t, ++j) {
+            const int pr = W.Ls.pair[t];
+            src_item[j] = (int32_t)x; src_pair[j] = pr;
+            V->p_len[j] = B.p_len[(size_t)pr]; V->t_len[j] = B.t_len[(size_t)pr];
+            V->p_off[j] = (B.d_asc_p + B.p_off[(size_t)pr]) - asc_base_p;         // byte offsets from the first batch's pools: any sign
+            V->t_off[j] = (B.d_asc_t + B.t_off[(size_t)pr]) - asc_base_t;
+            const int32_t nwp = 3 * ((V->p_len[j] + 63) / 64 + 2), nwt = 3 * ((V->t_len[j] + 63) / 64 + 2);
+            V->plp_off[j] = (int64_t)wp; V->plt_off[j] = (int64_t)wt;
+            g_src[2 * j] = (int64_t)(uintptr_t)(B.d_pl_p[F.parity] + B.plp_off[(size_t)pr]); g_nw[2 * j] = nwp;
+            g_src[2 * j + 1] = (int64_t)(uintptr_t)(B.d_pl_t[F.parity] + B.plt_off[(size_t)pr]); g_nw[2 * j + 1] = nwt;
+            wp += (size_t)nwp; wt += (size_t)nwt;
+            flags[j] = bf[(size_t)pr];
+            WV.Ls.push((int32_t)j, 0, W.Ls.m[t], 0, W.Ls.n[t], W.Ls.cutoff[t], W.Ls.n[t]);
+            WV.K1.score.push_back(W.K1.score[t]); WV.K1.stage2.push_back(W.K1.stage2[t]);
+        }
+    }
+    for (size_t q = 0; q < n; ++q) { g_dst[2 * q] = V->plp_off[q]; g_dst[2 * q + 1] = (int64_t)wp + V->plt_off[q]; }
+    // ---- V's device side: carved from this thread's utility pool for the length of the flow
+    struct PoolMark { Context& C; DevicePool::Mark m; ~PoolMark() { C.pool_w.release(m); C.util_pinned = false; } } pm{C, C.pool_w.mark()};
+    C.util_pinned = true;
+    DevicePool& U = C.pool_w;
+    V->d_asc_p = const_cast<uint8_t*>(asc_base_p); V->d_asc_t = const_cast<uint8_t*>(asc_base_t);
+    V->d_p_off = U.take<int64_t>(n); V->d_t_off = U.take<int64_t>(n); V->d_plp_off = U.take<int64_t>(n); V->d_plt_off = U.take<int64_t>(n);
+    V->d_p_len = U.take<int32_t>(n); V->d_t_len = U.take<int32_t>(n);
+    u64* planes = U.take<u64>(wp + wt + 8); u64* planes_r = U.take<u64>(wp + wt + 8);
+    u32* d_fl = U.take<u32>(n);
+    int64_t* d_gsrc = U.take<int64_t>(2 * n); int64_t* d_gdst = U.take<int64_t>(2 * n); int32_t* d_gnw = U.take<int32_t>(2 * n);
+    V->pl_p_words = wp; V->pl_t_words = wt;
+    for (int q = 0; q < quicked_batch::NP; ++q) {          // every plane set is the same gathered copy
+        V->d_pl_p[q] = planes; V->d_pl_t[q] = planes + wp; V->d_pl_pr[q] = planes_r; V->d_pl_tr[q] = planes_r + wp;
+        V->d_flags[q] = d_fl; V->have_rev[q] = false; V->ev_done_set[q] = false;
+    }
+    V->np_alloc = quicked_batch::NP; V->np_used = 1; V->parity = 0; V->last_parity = -1;
+    V->packed = true;                                      // forward planes are the input: no pack stage, reversed planes from them
+    V->unpack_pending = false; V->unpack_event_set = false;
+    V->cigar_style = items[0].B->cigar_style; V->check = false;
+    V->est_bound = 0; V->pending = false; V->pending_fetch.reset();
+    h2d(V->d_p_off, V->p_off, C.stream); h2d(V->d_t_off, V->t_off, C.stream);
+    h2d(V->d_plp_off, V->plp_off, C.stream); h2d(V->d_plt_off, V->plt_off, C.stream);
+    h2d(V->d_p_len, V->p_len, C.stream); h2d(V->d_t_len, V->t_len, C.stream);
+    h2d(d_fl, flags, C.stream); h2d(d_gsrc, g_src, C.stream); h2d(d_gdst, g_dst, C.stream); h2d(d_gnw, g_nw, C.stream);
+    hipLaunchKernelGGL(k_gather_words, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, C.stream, (int)(2 * n), d_gsrc, d_gdst, d_gnw, planes);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+    // ---- the flow, once
+    V->wr = &V->res[0]; V->vis = 0; V->shadow_ready = false;
+    reset_host_results(*V);
+    for (auto& c : V->counters) c = 0;
+    V->credit.assign(n * 8, 0);
+    fast_finish_classic(*V, C, p, WV, budget, 0);
+    // ---- results and counters back to where the pairs came from
+    const quicked_batch::HostResults& R = V->res[0];
+    std::vector<size_t> extra(ni, 0);
+    for (size_t q = 0; q < n; ++q) if (R.cigar_off[q] >= 0) extra[(size_t)src_item[q]] += strlen(R.cigar_pool.p + R.cigar_off[q]) + 1;
+    for (size_t x = 0; x < ni; ++x) items[x].B->wr->cigar_pool.reserve(items[x].B->wr->cigar_pool.size + extra[x]);
+    for (size_t q = 0; q < n; ++q) {
+        quicked_batch& B = *items[(size_t)src_item[q]].B;
+        const size_t pr = (size_t)src_pair[q];
+        B.wr->score[pr] = R.score[q]; B.wr->status[pr] = R.status[q];
+        if (R.cigar_off[q] >= 0) {
+            const char* str = R.cigar_pool.p + R.cigar_off[q];
+            const size_t len = strlen(str) + 1;
+            memcpy(B.wr->cigar_pool.p + B.wr->cigar_pool.size, str, len);
+            B.wr->cigar_off[pr] = (int64_t)B.wr->cigar_pool.size;
+            B.wr->cigar_pool.size += len;
+        } else B.wr->cigar_off[pr] = -1;
+        for (int slot : {0, 1, 2, 3, 4}) B.counters[slot] += V->credit[q * 8 + (size_t)slot];
+    }
+    for (size_t x = 0; x < ni; ++x) { items[x].B->counters[6] = 0; items[x].B->counters[7] = 0; }     // quicked_classic ASSIGNS these two
+    for (size_t q = 0; q < n; ++q) {
+        quicked_batch& B = *items[(size_t)src_item[q]].B;
+        B.counters[6] += V->credit[q * 8 + 6]; B.counters[7] += V->credit[q * 8 + 7];
+    }
+    V->credit.clear();
+}
+
+static bool same_flow(const PendingFetch& a, const PendingFetch& b) {
+    const quicked_params_t &x = a.params, &y = b.params;
+    return x.algo == y.algo && x.bandwidth == y.bandwidth && x.window_size == y.window_size && x.overlap_size == y.overlap_size &&
+           x.hew_threshold[0] == y.hew_threshold[0] && x.hew_threshold[1] == y.hew_threshold[1] &&
+           x.hew_percentage[0] == y.hew_percentage[0] && x.hew_percentage[1] == y.hew_percentage[1] &&
+           x.only_score == y.only_score && x.force_scalar == y.force_scalar;
+}
+
+// -> every job this call has dealt with (the one handed in and those it took from the queue): the caller retires them
+static std::atomic<int64_t> g_fin_stats[4];        // flows run, batches they finished, merged flows (>= 2 batches), batches in merged flows
+static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
+    quicked_batch& B0 = *job.B;
+    PendingFetch& F0 = *static_cast<PendingFetch*>(job.pf.get());
     // the run is over (the batch is alive: destroy waits for fin_jobs).  Polled with short sleeps: hipEventSynchronize spins,
     // and these threads wait for every queued QuickEd run of the process.  No context is held meanwhile.
-    HIP_CHECK(hipSetDevice(B.device));
-    tl_bound_device = B.device;
+    HIP_CHECK(hipSetDevice(B0.device));
+    tl_bound_device = B0.device;
     for (;;) {
-        const hipError_t e = hipEventQuery(B.ev_done[F.parity]);
+        const hipError_t e = hipEventQuery(B0.ev_done[F0.parity]);
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) throw HipError{e, "hipEventQuery(B.ev_done[F.parity])", __LINE__};
         if (g_fin_stop.load()) return;                               // the process is exiting
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
-    std::unique_lock<std::mutex> lk(B.fin_mu);
-    if (B.pending_fetch.get() != job.pf.get()) { if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p already fetched / superseded\n", (void*)&B); return; }
+    // other queued jobs whose runs are over too: the same flow serves their pairs (merged_finish)
+    static const int merge_max = std::max(1, env_int("QE_FINISH_MERGE", 4));
+    std::vector<FinishJob> group{job};
+    {
+        std::lock_guard<std::mutex> lk(g_fin_mu);
+        for (auto it = g_fin_q.begin(); it != g_fin_q.end() && (int)group.size() < merge_max;) {
+            const PendingFetch& F = *static_cast<const PendingFetch*>(it->pf.get());
+            const bool fits = it->B->device == B0.device && it->B != &B0 && same_flow(F0, F) && it->B->cigar_style == B0.cigar_style &&
+                              !it->B->check && !B0.check && hipEventQuery(it->B->ev_done[F.parity]) == hipSuccess;
+            if (fits) { group.push_back(*it); taken.push_back(*it); it = g_fin_q.erase(it); }
+            else ++it;
+        }
+    }
+    (void)hipGetLastError();
     ApiScope scope;
-    tl_device = B.device;
+    tl_device = B0.device;
     Context& C = ctx();
-    std::vector<int32_t> skip;
-    d2h(skip, F.d_skip, F.L.pair.size(), C.stream);
-    HIP_CHECK(hipStreamSynchronize(C.stream));
-    bool any = false;
-    for (size_t t = 0; t < skip.size() && !any; ++t) any = skip[t] != 0 && F.L.pair[t] >= 0;
-    if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p deferred pairs %s\n", (void*)&B, any ? "yes" : "none");
-    if (!any) return;                                                // nothing to finish: the caller's fetch is a copy
-    // The results go to the batch's shadow set (quicked_batch::res): the caller may be reading the visible one.  This
-    // thread's context is in the book like any other (its pools are planned in quicked_fast_finish); what it keeps between
-    // jobs is capped.
+    // ---- per batch: its fin_mu (the first is waited for, the others only taken when free: a caller that is fetching one
+    // right now does that one's work itself), still the run this job was made for, pairs left at all
+    std::vector<MergeItem> items;
+    for (size_t x = 0; x < group.size(); ++x) {
+        quicked_batch& B = *group[x].B;
+        PendingFetch& F = *static_cast<PendingFetch*>(group[x].pf.get());
+        std::unique_lock<std::mutex> lk(B.fin_mu, std::defer_lock);
+        if (x == 0) lk.lock(); else if (!lk.try_lock()) continue;
+        if (B.pending_fetch.get() != group[x].pf.get()) { if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p already fetched / superseded\n", (void*)&B); continue; }
+        std::vector<int32_t> skip;
+        d2h(skip, F.d_skip, F.L.pair.size(), C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        bool any = false;
+        for (size_t t = 0; t < skip.size() && !any; ++t) any = skip[t] != 0 && F.L.pair[t] >= 0;
+        if (!any) continue;                                              // nothing to finish: the caller's fetch is a copy
+        MergeItem it;
+        it.B = &B; it.pf = group[x].pf; it.lk = std::move(lk); it.keep = B.pending_fetch;
+        items.push_back(std::move(it));
+    }
+    if (trace_on()) fprintf(stderr, "[qe t%03d @%.1f] early finish: %zu job(s), %zu with pairs left\n", (int)(syscall(SYS_gettid) % 1000), now_ms(), group.size(), items.size());
+    if (items.empty()) return;
+    // The results go to the batches' shadow sets (quicked_batch::res): a caller may be reading the visible ones.  This
+    // thread's context is in the book like any other (fast_finish_classic plans its pools there).
     auto trim_own = [&]() { (void)C.release_pools(nullptr, true); };
-    const std::shared_ptr<void> keep = B.pending_fetch;
-    B.wr = &B.res[1 - B.vis];
+    const double t_job = now_ms();
+    for (MergeItem& it : items) it.B->wr = &it.B->res[1 - it.B->vis];
     try {
-        B.fin_status = fetch_pending(B);
-        B.shadow_ready = true;
+        if (items.size() == 1) {
+            quicked_batch& B = *items[0].B;
+            B.fin_status = fetch_pending(B);
+            B.shadow_ready = true;
+        } else {
+            std::vector<MergeItem> left;                  // batches whose runs did leave pairs (the skip flags said so; the collect step agrees)
+            for (MergeItem& it : items) {
+                it.B->fin_status = fetch_pending(*it.B, &it.W);
+                if (!it.W.Ls.pair.empty()) left.push_back(std::move(it)); else { it.B->shadow_ready = true; it.B->wr = &it.B->res[it.B->vis]; it.lk.unlock(); }
+            }
+            items.swap(left);
+            // one flow for the batches that left FEW pairs -- there the flow's duration is launch latency, whatever the
+            // number of pairs (12.5 k-pair batches with 1 % hard pairs: 0.54 -> 1.08 M alignments/s) -- a flow of its own
+            // for a batch that left thousands (20 k indel-heavy pairs each: merged, three of them ran 5 x slower than apart)
+            std::sort(items.begin(), items.end(), [](const MergeItem& a, const MergeItem& b) { return a.W.Ls.pair.size() < b.W.Ls.pair.size(); });
+            static const size_t merge_pairs = (size_t)std::max(0, env_int("QE_FINISH_MERGE_PAIRS", 8192));
+            size_t nm = 0, pairs = 0;
+            while (nm < items.size() && pairs + items[nm].W.Ls.pair.size() <= merge_pairs) pairs += items[nm++].W.Ls.pair.size();
+            if (nm < 2) nm = 0;
+            if (nm >= 2) { merged_finish(items, nm, C); ++g_fin_stats[2]; g_fin_stats[3] += (int64_t)nm; }
+            for (size_t x = nm; x < items.size(); ++x) {
+                PendingFetch& F = *static_cast<PendingFetch*>(items[x].pf.get());
+                fast_finish_classic(*items[x].B, C, F.params, items[x].W, F.matrix_budget, F.parity);
+            }
+            for (MergeItem& it : items) {
+                fetch_finalize(*it.B, static_cast<PendingFetch*>(it.pf.get())->quicked);
+                it.B->shadow_ready = true;
+            }
+        }
     }
     catch (const HipError&) {
-        // e.g. out of memory next to the other threads' pools: nothing is lost -- the run's results are still in the batch's
-        // result arena, and the caller's fetch does the same work in its own context
+        // e.g. out of memory next to the other threads' pools: nothing is lost -- the runs' results are still in the batches'
+        // result arenas, and the callers' fetches do the same work in their own contexts
         (void)hipGetLastError();
-        B.wr = &B.res[B.vis];
-        B.pending_fetch = keep; B.pending = true; B.fin_status = QUICKED_OK; B.shadow_ready = false;
+        for (MergeItem& it : items) {
+            if (!it.B || !it.lk.owns_lock() || it.B->shadow_ready) continue;
+            quicked_batch& B = *it.B;
+            B.wr = &B.res[B.vis];
+            B.pending_fetch = it.keep; B.pending = true; B.fin_status = QUICKED_OK; B.shadow_ready = false;
+        }
         trim_own();
         throw;
     }
-    B.wr = &B.res[B.vis];
-    if (C.held.load() > ((size_t)8 << 30)) trim_own();
+    for (MergeItem& it : items) it.B->wr = &it.B->res[it.B->vis];
+    if (!items.empty()) { ++g_fin_stats[0]; g_fin_stats[1] += (int64_t)items.size(); }
+    if (trace_on()) fprintf(stderr, "[qe t%03d @%.1f] early finish: %zu batch(es) done in %.1f ms (context %p holds %.2f GB)\n", (int)(syscall(SYS_gettid) % 1000), now_ms(), items.size(), now_ms() - t_job, (void*)&C, C.held.load() / 1e9);
+    // what this thread keeps between jobs is in the book like anybody's pools (and an allocation that finds the device full
+    // takes it, qe_pool.h); it goes back on its own only where the device is short
+    if (C.held.load() > ((size_t)8 << 30)) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 5) trim_own();
+    }
 }
 
-static void finisher_main() {
+static int g_fin_limit = 3;                          // threads that may take work now (QE_FINISHERS at the last submit; under g_fin_mu)
+static void finisher_main(int index) {
     for (;;) {
         FinishJob job;
         {
             std::unique_lock<std::mutex> lk(g_fin_mu);
             ++g_fin_idle;
-            g_fin_cv.wait(lk, [] { return !g_fin_q.empty(); });
+            g_fin_cv.wait(lk, [index] { return !g_fin_q.empty() && index < g_fin_limit; });
             --g_fin_idle;
             job = std::move(g_fin_q.front());
             g_fin_q.pop_front();
             ++g_fin_busy;
         }
-        try { if (!g_fin_stop.load()) finisher_work(job); }
+        std::vector<FinishJob> taken;                     // jobs the work took from the queue besides this one
+        try { if (!g_fin_stop.load()) finisher_work(job, taken); }
         catch (const HipError& e) {
             fprintf(stderr, "[quicked_hip] early finish: HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
             (void)hipGetLastError();
         }
         catch (const std::exception& e) { fprintf(stderr, "[quicked_hip] early finish: %s\n", e.what()); }
         --g_fin_busy;
-        if (g_fin_stop.load()) continue;             // exiting: the batch object may be gone
-        {
-            std::lock_guard<std::mutex> lk(job.B->fin_mu);
-            --job.B->fin_jobs;
+        if (g_fin_stop.load()) continue;             // exiting: the batch objects may be gone
+        taken.push_back(job);
+        for (const FinishJob& j : taken) {
+            {
+                std::lock_guard<std::mutex> lk(j.B->fin_mu);
+                --j.B->fin_jobs;
+            }
+            j.B->fin_cv.notify_all();
         }
-        job.B->fin_cv.notify_all();
     }
 }
 // at process exit (this library's destructors run before the HIP runtime's, which it depends on): no new early-finish work,
@@ -1926,9 +2151,10 @@ static void finisher_submit(quicked_batch& B, const std::shared_ptr<void>& pf) {
     if (max_threads <= 0) return;
     ++B.fin_jobs;
     std::lock_guard<std::mutex> lk(g_fin_mu);
+    g_fin_limit = max_threads;
     g_fin_q.push_back(FinishJob{&B, pf});
-    if (g_fin_idle == 0 && g_fin_threads < max_threads) { ++g_fin_threads; std::thread(finisher_main).detach(); }
-    g_fin_cv.notify_one();
+    if (g_fin_idle == 0 && g_fin_threads < max_threads) { std::thread(finisher_main, g_fin_threads).detach(); ++g_fin_threads; }
+    g_fin_cv.notify_all();
 }
 
 }  // namespace qe
@@ -2452,12 +2678,18 @@ QE_API quicked_status_t quicked_pool_trim(void) {
         Context& C = ctx();
         (void)C.release_pools(nullptr, true);
         { std::lock_guard<std::mutex> lk(g_ctx_mu); C.planned = 0; C.wanted = 0; }
-        (void)release_unleased(C.device);                  // what threads that have ended left behind
+        (void)release_unleased(C.device);                  // what threads that have ended left behind: pools ...
+        retire_idle_streams(C.device);                      // ... and streams nobody is using
         return QUICKED_OK;
     } catch (const HipError& e) {
         fprintf(stderr, "[quicked_hip] HIP error %d (%s) at %s, qe_driver.hip:%d\n", (int)e.e, hipGetErrorString(e.e), e.what, e.line);
         return QUICKED_ERROR;
     }
+}
+
+QE_API quicked_status_t quicked_early_finish_stats(int64_t stats_out[4]) {
+    for (int q = 0; q < 4; ++q) stats_out[q] = qe::g_fin_stats[q].load();
+    return QUICKED_OK;
 }
 
 QE_API int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch) { return batch ? batch->res[batch->vis].deferred_pairs : -1; }

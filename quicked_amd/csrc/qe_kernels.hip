@@ -3060,6 +3060,19 @@ __global__ __launch_bounds__(256) void k_copy_multi(CopyTable T) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.n_u4[e]; i += (int64_t)gridDim.x * blockDim.x) d[i] = q[i];
 }
 
+// gathers word spans from anywhere on the device into one buffer: span e = nwords[e] 64-bit words at address src_addr[e] ->
+// dst + dst_off[e] (the bit-planes of pairs that live in several batch objects' arenas, qe_driver.hip merged early finish);
+// one wave per span
+__global__ __launch_bounds__(256) void k_gather_words(int nspans, const int64_t* __restrict__ src_addr, const int64_t* __restrict__ dst_off,
+                                                      const int32_t* __restrict__ nwords, u64* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= nspans) return;
+    const u64* __restrict__ q = reinterpret_cast<const u64*>(src_addr[e]);
+    u64* __restrict__ d = dst + dst_off[e];
+    for (int i = lane; i < nwords[e]; i += 64) d[i] = q[i];
+}
+
 // copies the first *total bytes (a count only the device knows: the string pool of a run) from src to dst, 16 bytes per lane
 __global__ __launch_bounds__(256) void k_copy_total(uint4* __restrict__ dst, const uint4* __restrict__ src, const int64_t* __restrict__ total, int64_t cap_u4) {
     const int64_t n = min((*total + 15) >> 4, cap_u4);

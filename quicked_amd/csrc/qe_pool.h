@@ -266,6 +266,8 @@ struct Context {
     std::atomic<bool> in_call{false};
     uint64_t pressure_seen = 0;
     void* small_batch = nullptr;             // the batch object single quicked_align calls reuse (qe_driver.hip: align_pairs)
+    void* merge_batch = nullptr;             // the stand-in object of merged early finishes (qe_driver.hip: merged_finish)
+    bool util_pinned = false;                // the utility pool holds live data of the call in progress (merged_finish): not to be reclaimed
 
     // Two phases of a run use two pools so that consecutive runs pipeline:
     //   W: pack + bound stages (WindowEd, band doubling)      A: the BandEd kernels (score / fill / traceback / format)
@@ -284,8 +286,8 @@ struct Context {
     hipStream_t side_stream() {
         if (!stream_x) {
             HIP_CHECK(hipStreamCreateWithFlags(&stream_x, hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+            if (!ev_fork) HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            if (!ev_join) HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         }
         return stream_x;
     }
@@ -343,11 +345,7 @@ struct Context {
     // all streams of the process onto GPU_MAX_HW_QUEUES hardware queues, and streams that share one serialise.
     // A run's W phase and A phase depend on each other (pack -> bound stages -> align step): one stream serves both;
     // consecutive runs are on different sets, that is where the overlap comes from.
-    void ensure_set(int q) {
-        if (stream_a2[q]) return;
-        HIP_CHECK(hipStreamCreateWithFlags(&stream_a2[q], hipStreamNonBlocking));
-        stream_w2[q] = stream_a2[q];
-    }
+    void ensure_set(int q);
     explicit Context(int dev) : device(dev) {
         pool_w.device = dev; pool_w.owner_held = &held;
         for (auto& q : pool_w2) { q.device = dev; q.owner_held = &held; }
@@ -357,13 +355,15 @@ struct Context {
         if (stream_w) { if (!stream) phase_u(); return; }
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&stream_w, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&ev_last, hipEventDisableTiming));
-        for (auto& e : ev_decided) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (!ev_pack) {            // the events are made once; the utility stream again after retire_streams(true)
+            HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&ev_last, hipEventDisableTiming));
+            for (auto& e : ev_decided) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreate(&ev0));
+            HIP_CHECK(hipEventCreate(&ev1));
+        }
         phase_u();
-        HIP_CHECK(hipEventCreate(&ev0));
-        HIP_CHECK(hipEventCreate(&ev1));
     }
     // has work on the device (queried by other threads: hipEventQuery on an event the owner may be re-recording is safe,
     // the runtime serialises event operations)
@@ -377,12 +377,12 @@ struct Context {
     // every stream drained, every pool but `keep` back to the device.  The caller holds `busy` (the owner inside a call, or a
     // reclaiming thread that got it with try_lock) and is bound to this context's device.
     bool release_pools(DevicePool* keep, bool also_current_w) {
-        if (!stream_w || held.load() == 0) return false;
+        if (held.load() == 0) return false;
         bool freed = false;
         bool drained = false;
         auto drain = [&]() {
             if (drained) return true;
-            if (hipStreamSynchronize(stream_w) != hipSuccess) return false;
+            if (stream_w && hipStreamSynchronize(stream_w) != hipSuccess) return false;      // (no streams at all: retired, drained then)
             if (stream_x && hipStreamSynchronize(stream_x) != hipSuccess) return false;
             for (auto q : stream_a2) if (q && hipStreamSynchronize(q) != hipSuccess) return false;
             drained = true;
@@ -392,8 +392,27 @@ struct Context {
             if (&pool_a2[q] != keep && pool_a2[q].cap != 0) { if (!drain()) return freed; pool_a2[q].release_all(); freed = true; }
             if (&pool_w2[q] != keep && pool_w2[q].cap != 0 && (also_current_w || q != ai)) { if (!drain()) return freed; pool_w2[q].release_all(); freed = true; }
         }
-        if (&pool_w != keep && pool_w.cap != 0 && (also_current_w || scratch_p != &pool_w)) { if (!drain()) return freed; pool_w.release_all(); freed = true; }
+        if (&pool_w != keep && pool_w.cap != 0 && !util_pinned && (also_current_w || scratch_p != &pool_w)) { if (!drain()) return freed; pool_w.release_all(); freed = true; }
         return freed;
+    }
+    // The set streams and the side stream go back to the runtime (the utility stream and the events stay).  The HIP runtime
+    // maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues and streams that share a queue serialise: the streams
+    // of contexts whose threads have ended must not keep queues that a live thread's rotation needs (a bench line whose
+    // uploader / fetcher threads had left 20 streams behind ran its 11-deep stream of small batches at 3.5 instead of
+    // 6.3 M alignments/s).  The caller holds `busy`, has drained the streams (release_pools) and is bound to the device.
+    void retire_streams(bool utility_too = false) {
+        if (!stream_w) return;
+        for (int q = 0; q < NA; ++q) {
+            if (stream_a2[q]) { (void)hipStreamSynchronize(stream_a2[q]); (void)hipStreamDestroy(stream_a2[q]); }
+            stream_a2[q] = nullptr; stream_w2[q] = nullptr; decided_set[q] = false;
+        }
+        if (stream_x) { (void)hipStreamSynchronize(stream_x); (void)hipStreamDestroy(stream_x); stream_x = nullptr; }
+        for (auto& st : stage) { if (st.pending && st.done) (void)hipEventSynchronize(st.done); st.pending = false; }
+        phase_u();
+        if (utility_too) {         // a context without a lease keeps no stream at all: init() makes the utility stream again
+            (void)hipStreamSynchronize(stream_w); (void)hipStreamDestroy(stream_w);
+            stream_w = nullptr; stream = nullptr;
+        }
     }
     void go_tight() {
         memory_tight = true;
@@ -540,8 +559,34 @@ static bool reclaim(int device, int level, DevicePool* keep) {
         if (level == 1 && c->leased.load()) continue;          // taken over meanwhile: its new thread waits for `busy`, and keeps the pools
         if (pool_trace()) fprintf(stderr, "[qe-pool] reclaim level %d: context %p (%s) gives %.2f GB back\n", level, (void*)c, c->leased.load() ? "idle thread" : "no lease", c->held.load() / 1e9);
         freed |= c->release_pools(nullptr, true);
+        if (!c->leased.load()) c->retire_streams(true);
     }
     return freed;
+}
+
+// The set / side streams of every context that is doing nothing -- no lease, or a lease whose thread has no call in progress
+// and no run on the device (an early-finish thread between jobs, a thread that has finished its batches) -- go back to the
+// runtime (Context::retire_streams; pools stay; the owner creates them again when it next needs them): a stream that the
+// calling thread is about to create then finds a hardware queue of its own
+static void retire_idle_streams(int device) {
+    std::vector<Context*> list;
+    { std::lock_guard<std::mutex> lk(g_ctx_mu); list = g_ctx_all; }
+    for (Context* c : list) {
+        if (c == tl_ctx || c->device != device || !c->stream_w) continue;
+        bool any = c->stream_x != nullptr || !c->leased.load();
+        for (auto q : c->stream_a2) any |= q != nullptr;
+        if (!any || c->in_call.load()) continue;
+        std::unique_lock<std::mutex> lk(c->busy, std::try_to_lock);
+        if (!lk.owns_lock() || c->runs_on_device()) continue;
+        c->retire_streams(!c->leased.load());
+    }
+}
+
+inline void Context::ensure_set(int q) {
+    if (stream_a2[q]) return;
+    retire_idle_streams(device);               // a new stream: first those that nobody is using
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_a2[q], hipStreamNonBlocking));
+    stream_w2[q] = stream_a2[q];
 }
 
 static void oom_report(int device, size_t bytes, const DevicePool* pool) {

@@ -451,3 +451,62 @@ def test_getters_are_stable_while_a_queued_run_finishes_early(monkeypatch):
         pv, ov = rb.cigar_view()
         snap_pool, snap_off = pv.copy(), ov.copy()
     rb.close()
+
+
+def test_merged_early_finish_gives_every_batch_its_own(monkeypatch):
+    """The pairs that the queued QuickEd runs of SEVERAL batch objects left for the host-driven stages are aligned by one flow
+    when those runs are over by the time an early-finish thread gets to work (qe_driver.hip merged_finish: a stand-in batch
+    object with gathered bit-planes).  Every batch must get exactly what its own fetch would have produced: scores,
+    statuses, CIGARs, the count of deferred pairs and every work counter -- compared here with QE_FINISHERS = 0, where the
+    caller's fetch runs the flow per batch.  Batches of different sizes and lengths, one of them from packed wire words."""
+    import time
+    rng = np.random.default_rng(31)
+    batches = []
+    for k, (n_easy, n_hard, length) in enumerate(((3000, 90, 4000), (1500, 200, 2500), (2500, 40, 6000))):
+        easy = datagen.generate(count=n_easy, length=length, error=0.05, seed=700 + k)
+        hard = datagen.generate(count=n_hard, length=length, error=0.05, seed=800 + k, indels_num=3, indels_len=300)
+        pairs = list(easy.pairs()) + list(hard.pairs())
+        order = rng.permutation(len(pairs))
+        batches.append(datagen.PairBatch(*_pools([pairs[i] for i in order])))
+    prm = capi.make_params(algo=capi.QUICKED)
+
+    def collect(finishers, wire):
+        monkeypatch.setenv("QE_FINISHERS", finishers)
+        rbs = [capi.ResidentBatch(b, wire=(wire if k == 2 else None)) for k, b in enumerate(batches)]
+        for rb in rbs:
+            assert rb.run(prm, sync=True) >= 0
+        out = []
+        for rnd in range(3):
+            for rb in rbs:
+                assert rb.run(prm, sync=False) >= 0
+            for rb in rbs:
+                rb.sync()
+            if finishers != "0":
+                time.sleep(0.6)                     # the early-finish thread takes the first job alone, the other two together
+            got = []
+            for rb in rbs:
+                assert rb.fetch() >= 0
+                s, st = rb.scores()
+                got.append((s.copy(), st.copy(), rb.cigars(), rb.counters()[[0, 1, 2, 3, 4, 6, 7]].copy(), rb.deferred_pairs()))
+            out.append(got)
+        for rb in rbs:
+            rb.close()
+        return out
+
+    before = capi.early_finish_stats()
+    own = collect("0", capi.WIRE_2BIT)
+    assert capi.early_finish_stats() == before
+    merged = collect("1", capi.WIRE_2BIT)
+    after = capi.early_finish_stats()
+    assert after["merged_flows"] > before["merged_flows"] and after["merged_batches"] >= before["merged_batches"] + 2, (before, after)
+    for rnd in range(3):
+        for k in range(3):
+            a, b = own[rnd][k], merged[rnd][k]
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), (rnd, k)
+            assert a[2] == b[2], (rnd, k)
+            assert (a[3] == b[3]).all(), (rnd, k, a[3], b[3])
+            assert a[4] == b[4] and a[4] > 0, (rnd, k, a[4], b[4])
+    # ... and the oracle agrees on a stride
+    for k, bt in enumerate(batches):
+        for i in range(0, len(bt), 211):
+            assert (merged[2][k][1][i], merged[2][k][0][i], merged[2][k][2][i]) == O.oracle_align(bt.pattern(i), bt.text(i), algo=0), (k, i)

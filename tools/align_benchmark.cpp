@@ -162,7 +162,7 @@ struct Job {
 int main(int argc, char** argv) {
     // the HIP runtime reads this when it initialises (the library's first HIP call): a thread's runs rotate over up to 12
     // stream sets, and streams that share a hardware queue serialise
-    setenv("GPU_MAX_HW_QUEUES", "24", 0);
+    setenv("GPU_MAX_HW_QUEUES", "20", 0);
     std::string algo_name, input, output, output_full, check;
     quicked_params_t params = quicked_default_params();
     bool bandwidth_set = false, verbose = false;

@@ -28,4 +28,14 @@ for rel in (0, 1):
         print("cfg4", rel, repr(e))
 PY
 cat $out/overlap_rel0.txt $out/overlap_rel1.txt $out/mixed_rates.txt >> $out/summary.txt
+for tag in full nocfg4; do
+  extra=""; [ $tag = nocfg4 ] && extra="--cfg4-pairs 0"
+  ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-e2e $extra > $out/line_$tag.json 2> $out/line_$tag.err ) 2> $out/line_${tag}_time.txt
+  python - $out/line_$tag.json $tag <<'PY' >> gpurun_out/r4d/summary.txt
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); w = d["workloads"]; s = d["strong_share"]
+print(sys.argv[2], "share", round(s["banded_score"]["value"]/1e6,2), round(s["quicked"]["value"]/1e6,2), "mixed", round(w["quicked_mixed"].get("value",0)/1e6,2),
+      "indel", round(w["quicked_indels"]["value"]/1e6,3), "stream", round(w["quicked_indels"].get("fetched_stream",{}).get("value",0)/1e6,3), "cfg4", round(w.get("cfg4",{}).get("value",0)/1e3,1))
+PY
+done
 cat $out/summary.txt
