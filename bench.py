@@ -647,11 +647,16 @@ class Bench:
             extra["survey_equivalent_bytes"] = per_launch_bytes + 16.0 * counters[1] + 16.0 * counters[3] + float(counters[4])
             kernel, work_blocks = "k_banded<true> (BandEd fill, checkpointed)", int(counters[1])
         traffic, traffic_src = None, None
-        try:      # HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profiles.sh)
+        try:      # HBM bytes per launch from the committed PMC passes of this same command (tools/collect_profiles.sh) ...
+            import hashlib
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
                 pm = json.load(f)
-            ent = pm.get(f"{workload}:{pairs}x{args.length}")
-            if ent:
+            with open(os.path.join(ROOT, "quicked_amd", "csrc", "qe_kernels.hip"), "rb") as f:
+                now = hashlib.sha256(f.read()).hexdigest()
+            ent = pm.get(f"{'cfg4' if r.get('kind') == 2 else workload}:{pairs}x{args.length}")
+            if pm.get("kernels_sha256") != now:      # ... of THESE kernels: a figure measured with another qe_kernels.hip is not printed
+                traffic_src = "stale: profiles/pmc_traffic_latest.json was collected with another qe_kernels.hip (re-run tools/collect_profiles.sh)"
+            elif ent:
                 traffic, traffic_src = ent["hbm_bytes"], ent.get("source")
         except Exception:      # noqa: BLE001
             traffic = None

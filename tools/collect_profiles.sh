@@ -41,6 +41,16 @@ if [[ " $wls " == *" quicked "* ]]; then
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_qsq1 -- python3 bench.py --workload quicked $one --steps 1 --warmup 0 --sync-each-step > $out/pmc_qsq1.log 2>&1
   cp $out/pmc_qsq1/*/*counter_collection.csv $out/${tag}_quicked_pmc_sq1.csv
   rm -rf $out/pmc_qsq1
+  # what the QuickEd kernels' waves wait for (k_traceback): memory instructions by kind, the time spent
+  # with a memory instruction outstanding, L2 hits / misses -- separate passes
+  q="--workload quicked $one --steps 1 --warmup 0 --sync-each-step"
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM --output-format csv -d $out/pmc_qsq2 -- python3 bench.py $q > $out/pmc_qsq2.log 2>&1
+  cp $out/pmc_qsq2/*/*counter_collection.csv $out/${tag}_quicked_pmc_sq2.csv
+  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_qtcc -- python3 bench.py $q > $out/pmc_qtcc.log 2>&1
+  cp $out/pmc_qtcc/*/*counter_collection.csv $out/${tag}_quicked_pmc_tcc.csv
+  timeout 300 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $out/pmc_qtcp -- python3 bench.py $q > $out/pmc_qtcp.log 2>&1
+  cp $out/pmc_qtcp/*/*counter_collection.csv $out/${tag}_quicked_pmc_tcp.csv
+  rm -rf $out/pmc_qsq2 $out/pmc_qtcc $out/pmc_qtcp
 fi
 ./tools/bin/valu_rate ABC > $out/${tag}_valu_rates.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do

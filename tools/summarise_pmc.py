@@ -66,23 +66,34 @@ for part in ("sq1", "sq2", "grbm"):
 if sq:
     res["banded_score_sq"] = sq
 qsq = collections.defaultdict(dict)
-for r in rows(f"{out}/{tag}_quicked_pmc_sq1.csv"):
-    if "qe::" in r["Kernel_Name"]:
-        k = short(r["Kernel_Name"])
-        qsq[k][r["Counter_Name"]] = qsq[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+for part in ("sq1", "sq2", "tcc", "tcp"):
+    for r in rows(f"{out}/{tag}_quicked_pmc_{part}.csv"):
+        if "qe::" in r["Kernel_Name"]:
+            k = short(r["Kernel_Name"])
+            qsq[k][r["Counter_Name"]] = qsq[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 for k, v in qsq.items():
     if v.get("SQ_WAVE_CYCLES"):
         v["wait_any_share"] = v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]
         v["active_valu_share"] = v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_WAVE_CYCLES"]
+        if "SQ_INST_LEVEL_VMEM" in v:      # vector-memory instructions in flight, summed over wave-cycles (another pass than SQ_WAVE_CYCLES)
+            v["vmem_in_flight_per_wave_cycle"] = v["SQ_INST_LEVEL_VMEM"] / v["SQ_WAVE_CYCLES"]
+    if v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and v["TCC_HIT_sum"] + v["TCC_MISS_sum"] > 0:
+        v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
 if qsq:
     res["quicked_sq"] = qsq
 with open(f"{out}/{tag}_pmc_summary.json", "w") as f:
     json.dump(res, f, indent=1)
 # what bench.py prints as roofline.traffic: the dominant kernel's HBM bytes per launch, keyed by workload and size
-shape = {"banded_score": ("banded_score:100000x10000", "k_banded<false>"), "quicked": ("quicked:100000x10000", "k_banded<true>"),
-         "cfg4": ("quicked:10000x100000", "k_banded<true>"), "share": ("banded_score:12500x10000", "k_banded<false>")}
-latest = {}
-for wl, (key, kern) in shape.items():
+shape = {"banded_score": [("banded_score:100000x10000", "k_banded<false>")], "quicked": [("quicked:100000x10000", "k_banded<true>")],
+         "cfg4": [("quicked:10000x100000", "k_banded<true>"), ("cfg4:10000x100000", "k_banded_coop_lds<false>")],
+         "share": [("banded_score:12500x10000", "k_banded<false>")]}
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(root, "quicked_amd", "csrc", "qe_kernels.hip"), "rb") as f:
+    kernels_sha = hashlib.sha256(f.read()).hexdigest()
+# bench.py prints these figures only while qe_kernels.hip is the file they were measured with
+latest = {"kernels_sha256": kernels_sha}
+for wl, (key, kern) in [(w, kk) for w, lst in shape.items() for kk in lst]:
     ent = res.get(wl, {}).get(kern)
     if ent:
         latest[key] = dict(kernel=kern, hbm_bytes=ent["hbm_bytes"], FETCH_SIZE_KiB=ent["FETCH_SIZE_KiB"], WRITE_SIZE_KiB=ent["WRITE_SIZE_KiB"],
