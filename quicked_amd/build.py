@@ -45,16 +45,21 @@ def hip_sources():
 def build_hip(force=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    # one device translation unit (qe_driver.hip includes qe_kernels.hip) plus the host-only SIMD packer, which g++
-    # compiles (x86 intrinsics with per-function targets; never seen by the device pass)
+    # Three translation units: the device side (qe_driver.hip, which includes the kernels of qe_kernels.hip: hipcc), the
+    # C-ABI (qe_capi.cpp: host code over the HIP runtime API, g++) and the host-only SIMD packer (qe_hostpack.cpp: x86
+    # intrinsics with per-function targets, g++; never seen by the device pass).  qe_pool.h / qe_batch.h are what they share.
     if force or _newer(HIP_LIB, hip_sources()):
+        rocm_inc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")
+        host = ["g++", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra", "-pthread", "-c",
+                "-I", os.path.join(ROOT, "include"), "-I", CSRC]
         hostpack_o = os.path.join(HERE, "qe_hostpack.o")
-        _run(["g++", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra", "-pthread", "-c",
-              "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "qe_hostpack.cpp"), "-o", hostpack_o])
+        _run(host + [os.path.join(CSRC, "qe_hostpack.cpp"), "-o", hostpack_o])
+        capi_o = os.path.join(HERE, "qe_capi.o")
+        _run(host + ["-Wno-unused-parameter", "-D__HIP_PLATFORM_AMD__", "-I", rocm_inc, os.path.join(CSRC, "qe_capi.cpp"), "-o", capi_o])
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
                "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-               os.path.join(CSRC, "qe_driver.hip"), "-Wl," + hostpack_o, "-lpthread", "-o", HIP_LIB]      # -Wl,: hipcc would compile a bare .o as HIP source
+               os.path.join(CSRC, "qe_driver.hip"), "-Wl," + hostpack_o, "-Wl," + capi_o, "-lpthread", "-o", HIP_LIB]      # -Wl,: hipcc would compile a bare .o as HIP source
         cmd += os.environ.get("QE_HIPCC_FLAGS", "").split()      # experiments: -D switches of qe_kernels.hip
         _run(cmd)
     return HIP_LIB

@@ -1,4 +1,6 @@
 // qe_pool.h -- device memory of libquicked_hip.so: bump pools, per-thread contexts on lease, the process-wide book.
+// Header-only (inline functions and variables): included by the device translation unit (qe_driver.hip) and by the C-ABI
+// translation unit (qe_capi.cpp), one instance of every variable in the library.
 //
 // Replaces mm_allocator (quicked_utils/src/mm_allocator.c:141-426) on this path.  The reference runs one aligner per host
 // thread (tools/align_benchmark/align_benchmark.c:246-249), each with an arena that grows on demand and "cannot fail"
@@ -48,30 +50,30 @@ struct HipError { hipError_t e; const char* what; int line; };
         if (e__ != hipSuccess) throw qe::HipError{e__, #expr, __LINE__};            \
     } while (0)
 
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static bool pool_trace() { static int v = -1; if (v < 0) v = getenv("QE_TRACE_POOL") ? 1 : 0; return v == 1; }
-static double mono_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline bool pool_trace() { static int v = -1; if (v < 0) v = getenv("QE_TRACE_POOL") ? 1 : 0; return v == 1; }
+inline double mono_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 // ---------------------------------------------------------------------------
 // the book, per device
 // ---------------------------------------------------------------------------
-static constexpr int QE_MAX_DEVICES = 16;
+inline constexpr int QE_MAX_DEVICES = 16;
 struct DeviceBook {
     std::atomic<size_t> held{0};            // bytes in pool chunks of all contexts of this device
     std::atomic<uint64_t> epoch{0};         // bumped whenever the library allocates or frees device memory: a cached hipMemGetInfo reading is good for one epoch
     std::atomic<uint64_t> pressure{0};      // bumped by a thread that is out of memory after every reclaim
     std::atomic<int64_t> oom_events{0};     // allocations that needed level >= 2 (quicked_pool_stats()[1]: the planner is there to keep this 0)
 };
-static DeviceBook g_book[QE_MAX_DEVICES];
+inline DeviceBook g_book[QE_MAX_DEVICES];
 
 struct DevicePool;
 struct Context;
 // -> true if device memory went back.  level: see the header comment.  `keep`: a pool of the caller that must survive
-static bool reclaim(int device, int level, DevicePool* keep);
-static void oom_report(int device, size_t bytes, const DevicePool* pool);
+inline bool reclaim(int device, int level, DevicePool* keep);
+inline void oom_report(int device, size_t bytes, const DevicePool* pool);
 
 // hipMalloc with the out-of-memory path.  `keep`: the pool that is being grown (its memory is in use by the current run)
-static void device_malloc(void** p, size_t bytes, int device, DevicePool* keep, const char* what, int line) {
+inline void device_malloc(void** p, size_t bytes, int device, DevicePool* keep, const char* what, int line) {
     DeviceBook& bk = g_book[device];
     hipError_t e = hipMalloc(p, bytes);
     for (int level = 0; e == hipErrorOutOfMemory && level <= 3; ++level) {
@@ -100,7 +102,7 @@ static void device_malloc(void** p, size_t bytes, int device, DevicePool* keep, 
     }
     ++bk.epoch;
 }
-static void device_free(void* p, int device) {
+inline void device_free(void* p, int device) {
     if (!p) return;
     (void)hipFree(p);
     ++g_book[device].epoch;
@@ -424,13 +426,13 @@ struct Context {
 // ---------------------------------------------------------------------------
 // registry + leases
 // ---------------------------------------------------------------------------
-static std::mutex g_ctx_mu;                         // the registry, every context's leased / planned / wanted
-static std::vector<Context*>& g_ctx_all = *new std::vector<Context*>;     // never destroyed: detached library threads outlive static destruction
-static thread_local Context* tl_ctx = nullptr;
-static thread_local int tl_device = 0;
-static thread_local int tl_bound_device = -1;
-static thread_local int tl_api_depth = 0;
-static thread_local std::vector<Context*> tl_locked;      // contexts whose `busy` this thread holds (released by the outermost ApiScope)
+inline std::mutex g_ctx_mu;                         // the registry, every context's leased / planned / wanted
+inline std::vector<Context*>& g_ctx_all = *new std::vector<Context*>;     // never destroyed: detached library threads outlive static destruction
+inline thread_local Context* tl_ctx = nullptr;
+inline thread_local int tl_device = 0;
+inline thread_local int tl_bound_device = -1;
+inline thread_local int tl_api_depth = 0;
+inline thread_local std::vector<Context*> tl_locked;      // contexts whose `busy` this thread holds (released by the outermost ApiScope)
 
 // the contexts this thread has on lease, one per device it has used.  Its destructor runs when the thread ends and must
 // not call into HIP (the runtime's own per-thread state may be gone already): it ends the leases, nothing else.
@@ -441,7 +443,7 @@ struct LeaseList {
         for (Context* c : v) { c->planned = 0; c->wanted = 0; c->lessee_tid = 0; c->leased = false; }
     }
 };
-static thread_local LeaseList tl_leases;
+inline thread_local LeaseList tl_leases;
 
 // every exported function that touches a context opens one; the outermost one closes the thread's call
 struct ApiScope {
@@ -456,7 +458,7 @@ struct ApiScope {
     ApiScope& operator=(const ApiScope&) = delete;
 };
 
-static Context* lease_context(int device) {
+inline Context* lease_context(int device) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     Context* best = nullptr;
     for (Context* c : g_ctx_all)
@@ -469,7 +471,7 @@ static Context* lease_context(int device) {
 }
 
 // the calling thread's context on tl_device, `busy` held until the outermost ApiScope closes
-static Context& ctx() {
+inline Context& ctx() {
     if (tl_api_depth <= 0) { fprintf(stderr, "[quicked_hip] internal error: ctx() outside an API scope\n"); abort(); }
     if (!tl_ctx || tl_ctx->device != tl_device) {
         tl_ctx = nullptr;
@@ -502,7 +504,7 @@ static Context& ctx() {
 // its pools hold.  Contexts re-plan before every run, so a thread that had the device to itself is down to its share one
 // run after a second one shows up.
 // ---------------------------------------------------------------------------
-static size_t ledger_plan(Context* me, size_t free_now, size_t wanted, size_t* owed = nullptr) {
+inline size_t ledger_plan(Context* me, size_t free_now, size_t wanted, size_t* owed = nullptr) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     me->wanted = wanted;
     std::vector<Context*> active;
@@ -529,15 +531,15 @@ static size_t ledger_plan(Context* me, size_t free_now, size_t wanted, size_t* o
 }
 
 // pools of contexts nobody holds a lease on (their threads have ended): released when a plan could use the room
-static bool release_unleased(int device) { return reclaim(device, 1, nullptr); }
-static size_t unleased_held(int device) {
+inline bool release_unleased(int device) { return reclaim(device, 1, nullptr); }
+inline size_t unleased_held(int device) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     size_t s = 0;
     for (Context* c : g_ctx_all) if (c->device == device && !c->leased) s += c->held.load();
     return s;
 }
 
-static bool reclaim(int device, int level, DevicePool* keep) {
+inline bool reclaim(int device, int level, DevicePool* keep) {
     Context* me = (tl_ctx && tl_ctx->device == device) ? tl_ctx : nullptr;
     if (level == 0) return keep ? keep->drop_unused_chunks() : false;
     if (level == 2) {
@@ -568,7 +570,7 @@ static bool reclaim(int device, int level, DevicePool* keep) {
 // and no run on the device (an early-finish thread between jobs, a thread that has finished its batches) -- go back to the
 // runtime (Context::retire_streams; pools stay; the owner creates them again when it next needs them): a stream that the
 // calling thread is about to create then finds a hardware queue of its own
-static void retire_idle_streams(int device) {
+inline void retire_idle_streams(int device) {
     std::vector<Context*> list;
     { std::lock_guard<std::mutex> lk(g_ctx_mu); list = g_ctx_all; }
     for (Context* c : list) {
@@ -589,7 +591,7 @@ inline void Context::ensure_set(int q) {
     stream_w2[q] = stream_a2[q];
 }
 
-static void oom_report(int device, size_t bytes, const DevicePool* pool) {
+inline void oom_report(int device, size_t bytes, const DevicePool* pool) {
     size_t f = 0, t = 0;
     (void)hipMemGetInfo(&f, &t);
     fprintf(stderr, "[quicked_hip] out of device memory: want %.2f GB, device %d has %.2f of %.2f GB free; pools hold %.2f GB",
