@@ -1969,6 +1969,9 @@ __global__ __launch_bounds__(256) void k_banded_wave(BandedArgs A) {
 // ---------------------------------------------------------------------------
 // RLE emitter shared by the tracebacks: ops arrive back to front
 // ---------------------------------------------------------------------------
+#ifndef QE_TB_ELIDE
+#define QE_TB_ELIDE 0      // tools/pmc_tb_elide.sh: k_traceback with one kind of memory access left out (results garbage, time is the datum)
+#endif
 struct RunSink {
     u32* runs; int cap; int nruns; int cur_op; int cur_len; int nops; int edits; int stride;
     // stride: elements between consecutive runs of this lane's task: 64 in the [idx][lane] layout (one coalesced row per store
@@ -1999,7 +2002,7 @@ struct RunSink {
     __device__ __forceinline__ void emit(int op, int count, bool pred) {
         const bool brk = pred && op != cur_op;
         const bool st = brk && cur_len > 0;
-        if (st && nruns < cap) runs[(int64_t)nruns * stride] = ((u32)cur_len << 2) | (u32)cur_op;
+        if (!(QE_TB_ELIDE & 1)) if (st && nruns < cap) runs[(int64_t)nruns * stride] = ((u32)cur_len << 2) | (u32)cur_op;
         nruns += st ? 1 : 0;
         cur_len = brk ? count : cur_len + (pred ? count : 0);
         cur_op = brk ? op : cur_op;
@@ -2132,11 +2135,14 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
         if (act) {
             if (k != ck) {
                 ck = k; cs = -1;
+                if (QE_TB_ELIDE & 8) { cf_a = 0; cf_b = 0; cl_b = gns - 1; T0 = 0x9E3779B97F4A7C15ull * (u64)(k + lane + 1); T1 = T0 >> 7; TN = 0; }
+                else {
                 cf_a = cf[(int64_t)(k + 1) * 64]; cf_b = cf[(int64_t)k * 64]; cl_b = cl[(int64_t)k * 64];
                 load_planes(tp, t0 + 64 * k, T0, T1, TN);
+                }
             }
             const int s = Rb - (k - G.prolog);
-            if (Rb != cR) { cR = Rb; load_planes(pp, p0 + 64 * Rb, pa, pb, pn); }
+            if (Rb != cR) { cR = Rb; if (QE_TB_ELIDE & 8) { pa = 0xD1B54A32D192ED03ull * (u64)(Rb + lane + 1); pb = pa >> 5; pn = 0; } else load_planes(pp, p0 + 64 * Rb, pa, pb, pn); }
             // a step at column h reads Pv of stored column h + 1: inside the band of THAT column's chunk or 0
             // (oracle header).  All but the last column of the tile share this chunk; the last may be the chunk's last.
             inb_same = (u32)((s >= 0) & (s >= cf_b) & (s <= cl_b));
@@ -2149,10 +2155,11 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
             const int pos_v = k - G.prolog, s = Rb - pos_v;
             computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
             if (computed) {
-                const uint4 c0 = cp[(int64_t)(q * (TW / QE_CP_COLS)) * cps + (int64_t)s * 64];
+                const int se = (QE_TB_ELIDE & 14) ? min(max(s, 0), gns - 1) : s;        // (with made-up band edges any slot may come up)
+                const uint4 c0 = (QE_TB_ELIDE & 2) ? make_uint4((u32)q * 2654435761u, (u32)lane, 0u, 0u) : cp[(int64_t)(q * (TW / QE_CP_COLS)) * cps + (int64_t)se * 64];
                 if (s != cs) {
                     cs = s;
-                    const uint4 w0 = hw[((int64_t)k * gns + s) * 64];
+                    const uint4 w0 = (QE_TB_ELIDE & 4) ? make_uint4(~0u, ~0u, 0u, 0u) : hw[((int64_t)k * gns + se) * 64];
                     hinP = mk64(w0.x, w0.y); hinM = mk64(w0.z, w0.w);
                 }
                 P = mk64(c0.x, c0.y); M = mk64(c0.z, c0.w);
