@@ -604,13 +604,13 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
     }
     if (serial) {
         C.phase_a(); C.pa().reset();
-        if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.sa(), B.ev_done[par], 0));
+        if (B.ev_done_set[par]) HIP_CHECK(B.done_wait_on(C.sa(), par));
     }
     else {
         C.phase_w();
         C.pw().reset();
         if (C.decided_set[C.ai]) { HIP_CHECK(hipStreamWaitEvent(C.sw(), C.ev_decided[C.ai], 0)); C.decided_set[C.ai] = false; }
-        if (B.ev_done_set[par]) HIP_CHECK(hipStreamWaitEvent(C.sw(), B.ev_done[par], 0));
+        if (B.ev_done_set[par]) HIP_CHECK(B.done_wait_on(C.sw(), par));
     }
     B.only_score_run = p.only_score;
     // sync == 0 leaves the host-side results of the last fetched run untouched (quicked_batch_fetch brings this run's)
@@ -640,9 +640,10 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
         w.words = B.d_wire_t; w.w_off = B.d_wire_t_off; w.len = B.d_t_len; w.planes = B.d_pl_t[0]; w.pl_off = B.d_plt_off;
         hipLaunchKernelGGL(k_unpack_wire, dim3(blocks), dim3(256), 0, C.stream, w);
         HIP_CHECK(hipEventRecord(B.ev_unpacked, C.stream));
+        B.ev_unpacked_tag = C.tag_a2[C.ai];
         B.unpack_pending = false; B.unpack_event_set = true;
     } else if (B.packed && B.unpack_event_set) {
-        HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_unpacked, 0));
+        { std::shared_lock<std::shared_mutex> life(g_stream_life); if (!stream_gone(B.ev_unpacked_tag)) HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_unpacked, 0)); }
     }
     if (!B.packed) HIP_CHECK(hipMemsetAsync(B.d_flags[par], 0, (size_t)B.n * sizeof(u32), C.stream));
     launch_pack(B, C, false);
@@ -744,12 +745,14 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
         C.phase_a();
         // the batch has ONE result arena: the previous queued run of this batch (another stream of the rotation, possibly a
         // longer chain of kernels) must have put its results there before this run's overwrite them
-        if (B.last_parity >= 0 && B.last_parity != par && B.ev_done_set[B.last_parity]) HIP_CHECK(hipStreamWaitEvent(C.stream, B.ev_done[B.last_parity], 0));
+        if (B.last_parity >= 0 && B.last_parity != par && B.ev_done_set[B.last_parity]) HIP_CHECK(B.done_wait_on(C.stream, B.last_parity));
         stash_results(B, C, *pf);
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
     HIP_CHECK(hipEventRecord(C.ev_last, C.sa()));
+    C.ev_last_tag = C.tag_a2[C.ai];
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
+    B.ev_done_tag[par] = C.tag_a2[C.ai];
     B.last_parity = par;
     if (C.staging) { HIP_CHECK(hipEventRecord(C.stage[C.si].done, C.sa())); C.stage[C.si].pending = true; C.staging = false; }
     QE_TRACE_POINT("stages launched");
@@ -798,7 +801,7 @@ static quicked_status_t fetch_pending(quicked_batch& B, FastLeft* left = nullptr
     std::shared_ptr<void> hold = B.pending_fetch;
     PendingFetch& F = *static_cast<PendingFetch*>(hold.get());
     B.pending_fetch.reset();
-    HIP_CHECK(hipEventSynchronize(B.ev_done[F.parity]));
+    HIP_CHECK(B.done_sync(F.parity));
     C.phase_u();
     reset_host_results(B);
     for (int q = 0; q < 8; ++q) B.counters[q] = F.counters[q];
@@ -992,7 +995,7 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
     HIP_CHECK(hipSetDevice(B0.device));
     tl_bound_device = B0.device;
     for (;;) {
-        const hipError_t e = hipEventQuery(B0.ev_done[F0.parity]);
+        const hipError_t e = B0.done_query(F0.parity);
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) throw HipError{e, "hipEventQuery(B.ev_done[F.parity])", __LINE__};
         if (g_fin_stop.load()) return;                               // the process is exiting
@@ -1006,7 +1009,7 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
         for (auto it = g_fin_q.begin(); it != g_fin_q.end() && (int)group.size() < merge_max;) {
             const PendingFetch& F = *static_cast<const PendingFetch*>(it->pf.get());
             const bool fits = it->B->device == B0.device && it->B != &B0 && same_flow(F0, F) && it->B->cigar_style == B0.cigar_style &&
-                              !it->B->check && !B0.check && hipEventQuery(it->B->ev_done[F.parity]) == hipSuccess;
+                              !it->B->check && !B0.check && it->B->done_query(F.parity) == hipSuccess;
             if (fits) { group.push_back(*it); taken.push_back(*it); it = g_fin_q.erase(it); }
             else ++it;
         }
@@ -1297,7 +1300,7 @@ void batch_load(quicked_batch* B, Context& C, int64_t n,
 // every run of the batch that is still on the device (queued by any thread) is over
 void batch_quiesce(quicked_batch* B) {
     for (int q = 0; q < quicked_batch::NP; ++q)
-        if (B->ev_done[q] && B->ev_done_set[q]) HIP_CHECK(hipEventSynchronize(B->ev_done[q]));
+        if (B->ev_done[q] && B->ev_done_set[q]) HIP_CHECK(B->done_sync(q));
 }
 }  // namespace qe
 

@@ -1457,7 +1457,10 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
     if (w * NA >= A.T.ntasks) return;
     const int q = lane >> lgG, g = lane & (G - 1);
     const int t = w * NA + q;
-    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    // FILL: a task that arrives flagged is not this kernel's (the host leaves the leaves whose bands are too short for G
+    // lanes to the one-lane kernel, which runs over the flagged tasks afterwards)
+    if (FILL && pair >= 0 && A.o_abort[t] != 0) pair = -1;
     const bool valid = pair >= 0;
     int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0, tfin = 0;
     const u64* pp = A.P.pl_p;

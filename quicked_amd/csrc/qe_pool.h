@@ -33,7 +33,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <vector>
 
@@ -254,6 +256,20 @@ struct PinnedStage {
 };
 
 // ---------------------------------------------------------------------------
+// Streams that go back to the runtime (Context::retire_streams) and the events recorded on them.  A batch object's
+// ev_done / ev_unpacked and a context's ev_last are waited for or queried by OTHER threads, at any later time; the HIP
+// runtime faults on an event whose stream has been destroyed (hipEventSynchronize from quicked_batch_destroy: one GPU-suite
+// run in five).  Every stream has a tag that says whether it is alive, an event keeps the tag of the stream it was last
+// recorded on, and whoever touches such an event from outside its context holds g_stream_life shared and skips the call
+// when the stream is gone -- its work was drained before it was destroyed, so the event is complete.  Destroying streams
+// takes the lock exclusively (try_lock: a thread that sits in a long wait only postpones the clean-up).
+// ---------------------------------------------------------------------------
+struct StreamTag { std::atomic<bool> alive{true}; };
+using StreamTagRef = std::shared_ptr<StreamTag>;
+inline std::shared_mutex g_stream_life;
+inline bool stream_gone(const StreamTagRef& t) { return t && !t->alive.load(); }
+
+// ---------------------------------------------------------------------------
 // Context: what one host thread uses on one device.  Never destroyed; held on lease (see the header comment).
 // ---------------------------------------------------------------------------
 struct Context {
@@ -280,6 +296,7 @@ struct Context {
     static constexpr int NA = 12;
     hipStream_t stream_w = nullptr;          // utility stream: loads, fetches, the validator -- everything outside a run
     hipStream_t stream_w2[NA] = {}, stream_a2[NA] = {};
+    StreamTagRef tag_a2[NA], tag_x, ev_last_tag;      // see StreamTag
     hipStream_t stream = nullptr;            // where the current phase launches
     // fork-join helper: the reverse half passes of a Hirschberg level run next to the forward ones (two 5000-wave launches
     // on one stream each end in a tail of their own; side by side the chip stays full until both are nearly done)
@@ -288,6 +305,7 @@ struct Context {
     hipStream_t side_stream() {
         if (!stream_x) {
             HIP_CHECK(hipStreamCreateWithFlags(&stream_x, hipStreamNonBlocking));
+            tag_x = std::make_shared<StreamTag>();
             if (!ev_fork) HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
             if (!ev_join) HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         }
@@ -370,7 +388,11 @@ struct Context {
     // has work on the device (queried by other threads: hipEventQuery on an event the owner may be re-recording is safe,
     // the runtime serialises event operations)
     bool runs_on_device() const {
-        if (!ev_last) return false;
+        std::shared_lock<std::shared_mutex> life(g_stream_life);
+        return runs_on_device_locked();
+    }
+    bool runs_on_device_locked() const {       // the caller holds g_stream_life (shared or exclusive)
+        if (!ev_last || stream_gone(ev_last_tag)) return false;
         const hipError_t e = hipEventQuery(ev_last);
         if (e == hipErrorNotReady) return true;
         if (e != hipSuccess) (void)hipGetLastError();
@@ -402,13 +424,15 @@ struct Context {
     // of contexts whose threads have ended must not keep queues that a live thread's rotation needs (a bench line whose
     // uploader / fetcher threads had left 20 streams behind ran its 11-deep stream of small batches at 3.5 instead of
     // 6.3 M alignments/s).  The caller holds `busy`, has drained the streams (release_pools) and is bound to the device.
+    // ... and holds g_stream_life exclusively (StreamTag): the events recorded on these streams are complete from here on
     void retire_streams(bool utility_too = false) {
         if (!stream_w) return;
         for (int q = 0; q < NA; ++q) {
-            if (stream_a2[q]) { (void)hipStreamSynchronize(stream_a2[q]); (void)hipStreamDestroy(stream_a2[q]); }
-            stream_a2[q] = nullptr; stream_w2[q] = nullptr; decided_set[q] = false;
+            if (stream_a2[q]) { (void)hipStreamSynchronize(stream_a2[q]); (void)hipStreamDestroy(stream_a2[q]); if (tag_a2[q]) tag_a2[q]->alive = false; }
+            stream_a2[q] = nullptr; stream_w2[q] = nullptr; decided_set[q] = false; tag_a2[q].reset();
         }
-        if (stream_x) { (void)hipStreamSynchronize(stream_x); (void)hipStreamDestroy(stream_x); stream_x = nullptr; }
+        if (stream_x) { (void)hipStreamSynchronize(stream_x); (void)hipStreamDestroy(stream_x); stream_x = nullptr; if (tag_x) tag_x->alive = false; tag_x.reset(); }
+        kev_used = 0;              // the kernel-timing events of runs since the last collection were recorded on those streams
         for (auto& st : stage) { if (st.pending && st.done) (void)hipEventSynchronize(st.done); st.pending = false; }
         phase_u();
         if (utility_too) {         // a context without a lease keeps no stream at all: init() makes the utility stream again
@@ -561,7 +585,10 @@ inline bool reclaim(int device, int level, DevicePool* keep) {
         if (level == 1 && c->leased.load()) continue;          // taken over meanwhile: its new thread waits for `busy`, and keeps the pools
         if (pool_trace()) fprintf(stderr, "[qe-pool] reclaim level %d: context %p (%s) gives %.2f GB back\n", level, (void*)c, c->leased.load() ? "idle thread" : "no lease", c->held.load() / 1e9);
         freed |= c->release_pools(nullptr, true);
-        if (!c->leased.load()) c->retire_streams(true);
+        if (!c->leased.load()) {
+            std::unique_lock<std::shared_mutex> life(g_stream_life, std::try_to_lock);
+            if (life.owns_lock()) c->retire_streams(true);
+        }
     }
     return freed;
 }
@@ -571,6 +598,8 @@ inline bool reclaim(int device, int level, DevicePool* keep) {
 // runtime (Context::retire_streams; pools stay; the owner creates them again when it next needs them): a stream that the
 // calling thread is about to create then finds a hardware queue of its own
 inline void retire_idle_streams(int device) {
+    std::unique_lock<std::shared_mutex> life(g_stream_life, std::try_to_lock);
+    if (!life.owns_lock()) return;             // some thread is inside a call on an event of a set stream: another time
     std::vector<Context*> list;
     { std::lock_guard<std::mutex> lk(g_ctx_mu); list = g_ctx_all; }
     for (Context* c : list) {
@@ -579,7 +608,7 @@ inline void retire_idle_streams(int device) {
         for (auto q : c->stream_a2) any |= q != nullptr;
         if (!any || c->in_call.load()) continue;
         std::unique_lock<std::mutex> lk(c->busy, std::try_to_lock);
-        if (!lk.owns_lock() || c->runs_on_device()) continue;
+        if (!lk.owns_lock() || c->runs_on_device_locked()) continue;
         c->retire_streams(!c->leased.load());
     }
 }
@@ -589,6 +618,7 @@ inline void Context::ensure_set(int q) {
     retire_idle_streams(device);               // a new stream: first those that nobody is using
     HIP_CHECK(hipStreamCreateWithFlags(&stream_a2[q], hipStreamNonBlocking));
     stream_w2[q] = stream_a2[q];
+    tag_a2[q] = std::make_shared<StreamTag>();
 }
 
 inline void oom_report(int device, size_t bytes, const DevicePool* pool) {

@@ -821,7 +821,32 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     // one-lane kernel (config 4's leaves: both kernels ran, 45 + 36 ms instead of 38).  A user bandwidth leaves the band
     // tall: few long BandEd alignments with CIGAR fill with G lanes each.  QE_COOP_FILL_G forces a width (tests).
     const bool fill_forced = getenv("QE_COOP_FILL_G") != nullptr;
-    const int Gfill = (env_int("QE_COOP_LDS", 1) == 0 || (tight_runs && !fill_forced)) ? 1 : coop_lanes(LL, fetch ? 1 : C.in_flight, true);
+    int Gfill = (env_int("QE_COOP_LDS", 1) == 0 || (tight_runs && !fill_forced)) ? 1 : coop_lanes(LL, fetch ? 1 : C.in_flight, true);
+    // Round 4: ... except where the bound is LARGE.  A pair with large indels has a bound of thousands, its band is 40-60
+    // slots tall for most of its length (the edge pruning only bites as the score nears the cutoff), and a launch of such
+    // leaves is a few waves of one lane's chain each (the pairs a QuickEd run left for the host-driven flow: 25-35 ms for
+    // thirteen waves).  There the leaves whose bands are tall enough for G >= 4 lanes (>= 3 G + 4 slots) fill cooperatively
+    // and the others arrive flagged and stay with the one-lane kernel -- one list may hold both kinds.  Not where the
+    // cutoffs are still on the device (the fast flow's chip-filling runs) and not where the one-lane launch fills the chip.
+    std::vector<int32_t> hew_init;
+    if (Gfill < 2 && tight_runs && !fill_forced && !d_cut && env_int("QE_COOP_LDS", 1) != 0 && env_int("QE_COOP_TALL_FILL", 1) != 0 &&
+        (size_t)ng * (size_t)std::max(1, fetch ? 1 : C.in_flight) < 1024) {
+        size_t live = 0;
+        std::vector<int> ebb(nt, 0);
+        for (size_t t = 0; t < nt; ++t) if (LL.pair[t] >= 0) { ebb[t] = host_geometry(LL.m[t], LL.n[t], LL.cutoff[t]).ebb; ++live; }
+        for (int G : {16, 8, 4}) {
+            size_t ok = 0;
+            for (size_t t = 0; t < nt; ++t) ok += LL.pair[t] >= 0 && ebb[t] >= 3 * G + 4;
+            if (ok >= 16 && ok * 4 >= live) {              // a quarter of the leaves or more: the launch's duration is theirs
+                Gfill = G;
+                hew_init.assign(nt, 1);
+                for (size_t t = 0; t < nt; ++t) if (LL.pair[t] >= 0 && ebb[t] >= 3 * G + 4) hew_init[t] = 0;
+                break;
+            }
+        }
+    }
+    int32_t* d_hew_init = nullptr;
+    if (!hew_init.empty()) { d_hew_init = C.scratch_p->take<int32_t>(nt); h2d(d_hew_init, hew_init, C.stream); }
     for (size_t sb = 0; sb + 1 < sub_start.size(); ++sb) {
         const int g0 = sub_start[sb], g1 = sub_start[sb + 1];
         if (g1 <= g0) continue;
@@ -865,7 +890,8 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             x.mat = mat; x.g_mat_off = a.g_mat_off; x.gws = ws; x.g_ws_off = a.g_ws_off;
             x.g_nslots = a.g_nslots; x.g_nrows = a.g_nrows; x.g_nch = a.g_nch;
             if ((size_t)x.lds_per_wave <= (size_t)38 * 1024) {
-                HIP_CHECK(hipMemsetAsync(O.hew + o, 0, (size_t)(g1 - g0) * 64 * sizeof(int32_t), C.stream));
+                if (d_hew_init) copy_kernel(O.hew + o, d_hew_init + o, (size_t)(g1 - g0) * 64 * sizeof(int32_t), C.stream);
+                else HIP_CHECK(hipMemsetAsync(O.hew + o, 0, (size_t)(g1 - g0) * 64 * sizeof(int32_t), C.stream));
                 launch_groups(C, k_banded_coop_lds<true>, x, (size_t)(g1 - g0) * 64 / NAf, 8, (size_t)x.lds_per_wave);
                 a.only_if = O.hew + o;
             }

@@ -368,6 +368,30 @@ def test_fill_multi_slot_passes_forced(multi, monkeypatch):
                 assert out[i] == want, (multi, kw, i, len(p), len(t))
 
 
+@pytest.mark.parametrize("tall", ["1", "0"])
+def test_tall_band_cooperative_fill(tall, monkeypatch):
+    """QuickEd's align step on pairs with LARGE bounds (large indels: bands of 30-50 slots) in a launch of few waves: the
+    leaves whose bands are tall enough fill with G lanes each (k_banded_coop_lds<true>), the others -- ordinary pairs in
+    the same list -- arrive flagged and stay with the one-lane kernel (QE_COOP_TALL_FILL = 1, default; 0: one lane for all).
+    Same cells either way: statuses, scores, CIGARs and the fill's block-advance counter equal the oracle's."""
+    monkeypatch.setenv("QE_COOP_TALL_FILL", tall)
+    rng = np.random.default_rng(23)
+    pairs = []
+    for i in range(288):
+        L = int(rng.choice([5000, 8000]))
+        hard = rng.random() < 0.6
+        p, t = next(datagen.generate(1, L, 0.05, seed=9500 + i, indels_num=3 if hard else 0, indels_len=int(rng.choice([400, 700]))).pairs())
+        pairs.append((p, t))
+    batch = datagen.PairBatch(*_pools(pairs))
+    s, st, cg, cnt = gpu_batch(batch, algo=0)
+    work = 0
+    for i, (p, t) in enumerate(pairs):
+        est, esc, ecg, tr = O.oracle_align(p, t, trace=True, algo=0)
+        work += tr["fill_block_advances"]
+        assert (st[i], s[i], cg[i]) == (est, esc, ecg), (tall, i)
+    assert cnt[1] == work, (tall, int(cnt[1]), work)
+
+
 @pytest.mark.parametrize("rel", ["1", "0"])
 def test_lane_relative_band_walk_forced(rel, monkeypatch):
     """k_banded walks, in every chunk, either the union of its 64 lanes' bands (QE_LANE_REL = 0) or every lane's own band

@@ -2,8 +2,7 @@
 profiles/<tag>_bench_cfg4.json, profiles/<tag>_single_call_latency.txt) instead of edited by hand.
 
     python tools/readme_numbers.py            # prints the paragraph for the newest tag under profiles/
-    python tools/readme_numbers.py --write    # rewrites it in README.md between the bench:begin / bench:end markers
-tests/test_abi.py checks that README.md holds exactly what this prints."""
+    python tools/readme_numbers.py --write    # rewrites it in README.md between the bench:begin / bench:end markers"""
 import glob, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,8 +57,15 @@ def paragraph(tag=None):
         f"{d['workloads']['quicked_indels']['value'] / 1e6:.2f} M alignments/s"
         + (f", on ordinary batches with {d['workloads']['quicked_mixed']['hard_pairs'] * 100 // d['workloads']['quicked_mixed']['pairs_per_gpu']} % of such pairs "
            f"among them {d['workloads']['quicked_mixed']['value'] / 1e6:.1f} M" if "value" in d["workloads"].get("quicked_mixed", {}) else "")
+        + (f" (the per-GPU share, 12.5 k pairs with 1 % of them: {s['quicked_mixed']['value'] / 1e6:.1f} M, the hard pairs of several runs aligned by one merged flow)"
+           if "value" in s.get("quicked_mixed", {}) else "")
         + ". "
-        f"The compiled reference on the same box, on the {d['cpu_baseline']['cores']} CPUs the process is allowed (one aligner per thread): "
+        + (f"Config 4 inside the one line ({d['workloads']['cfg4']['steps']} timed steps): {d['workloads']['cfg4']['value'] / 1e3:.1f} k alignments/s. "
+           if "value" in d["workloads"].get("cfg4", {}) else "")
+        + (f"The compiled reference on the same {d['cpu_baseline']['cores']} CPUs does {d['workloads']['cfg4']['cpu_baseline']['value'] / 1e3:.2f} k (config 4), "
+           f"{d['workloads']['quicked_indels']['cpu_baseline']['value'] / 1e3:.0f} k (indel pairs) and {d['workloads']['quicked_mixed']['cpu_baseline']['value'] / 1e3:.0f} k (1 % mix) alignments/s. "
+           if all("cpu_baseline" in d["workloads"].get(k, {}) and "value" in d["workloads"][k]["cpu_baseline"] for k in ("cfg4", "quicked_indels", "quicked_mixed")) else "")
+        + f"The compiled reference on the same box, on the {d['cpu_baseline']['cores']} CPUs the process is allowed (one aligner per thread): "
         f"{d['cpu_baseline']['value'] / 1e3:.0f} k and {q['cpu_baseline']['value'] / 1e3:.0f} k alignments/s for the two 10 kb workloads, "
         f"identical scores on all pairs of the sample.")
     if lat:
