@@ -827,10 +827,12 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     // leaves is a few waves of one lane's chain each (the pairs a QuickEd run left for the host-driven flow: 25-35 ms for
     // thirteen waves).  There the leaves whose bands are tall enough for G >= 4 lanes (>= 3 G + 4 slots) fill cooperatively
     // and the others arrive flagged and stay with the one-lane kernel -- one list may hold both kinds.  Not where the
-    // cutoffs are still on the device (the fast flow's chip-filling runs) and not where the one-lane launch fills the chip.
+    // cutoffs are still on the device (the fast flow's chip-filling runs), and only for launches of at most 64 one-lane
+    // waves: 20 k such pairs (313 waves one-lane, 3 750 cooperative) fill faster one lane each (76 against 85 ms per run),
+    // the 813 pairs a 100 k-pair run leaves gain (50 -> 47 ms per batch of the mixed stream).
     std::vector<int32_t> hew_init;
     if (Gfill < 2 && tight_runs && !fill_forced && !d_cut && env_int("QE_COOP_LDS", 1) != 0 && env_int("QE_COOP_TALL_FILL", 1) != 0 &&
-        (size_t)ng * (size_t)std::max(1, fetch ? 1 : C.in_flight) < 1024) {
+        (size_t)ng * (size_t)std::max(1, fetch ? 1 : C.in_flight) <= 64) {
         size_t live = 0;
         std::vector<int> ebb(nt, 0);
         for (size_t t = 0; t < nt; ++t) if (LL.pair[t] >= 0) { ebb[t] = host_geometry(LL.m[t], LL.n[t], LL.cutoff[t]).ebb; ++live; }

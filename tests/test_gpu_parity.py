@@ -377,7 +377,7 @@ def test_tall_band_cooperative_fill(tall, monkeypatch):
     monkeypatch.setenv("QE_COOP_TALL_FILL", tall)
     rng = np.random.default_rng(23)
     pairs = []
-    for i in range(288):
+    for i in range(160):
         L = int(rng.choice([5000, 8000]))
         hard = rng.random() < 0.6
         p, t = next(datagen.generate(1, L, 0.05, seed=9500 + i, indels_num=3 if hard else 0, indels_len=int(rng.choice([400, 700]))).pairs())
