@@ -433,7 +433,9 @@ struct Context {
         }
         if (stream_x) { (void)hipStreamSynchronize(stream_x); (void)hipStreamDestroy(stream_x); stream_x = nullptr; if (tag_x) tag_x->alive = false; tag_x.reset(); }
         kev_used = 0;              // the kernel-timing events of runs since the last collection were recorded on those streams
-        for (auto& st : stage) { if (st.pending && st.done) (void)hipEventSynchronize(st.done); st.pending = false; }
+        // the pinned stages' events were recorded on those streams: complete (the streams were drained), and not to be
+        // touched again (an event of a destroyed stream: see StreamTag)
+        for (auto& st : stage) st.pending = false;
         phase_u();
         if (utility_too) {         // a context without a lease keeps no stream at all: init() makes the utility stream again
             (void)hipStreamSynchronize(stream_w); (void)hipStreamDestroy(stream_w);
