@@ -46,20 +46,22 @@ struct quicked_batch {
     int last_groups = 0;                          // 64-task groups of that stage
     int est_bound = 0;                            // QuickEd: the cutoff the next run's align buffers are sized for (0: none yet, < 0: classic flow only)
     hipEvent_t ev_done[NP] = {};    // end of the A phase of the last run that used this parity
-    qe::StreamTagRef ev_done_tag[NP], ev_unpacked_tag;      // the streams those events were last recorded on (qe_pool.h: StreamTag)
+    // the streams those events were last recorded on (qe_pool.h: StreamTag); read by early-finish threads that poll a run while
+    // the caller queues the next one: atomic_load / atomic_store
+    qe::StreamTagRef ev_done_tag[NP], ev_unpacked_tag;
     // waits for / queries ev_done[q] unless its stream has gone back to the runtime (the run is over then); hipErrorNotReady
     // only from the query form
     hipError_t done_sync(int q) const {
         std::shared_lock<std::shared_mutex> life(qe::g_stream_life);
-        return qe::stream_gone(ev_done_tag[q]) ? hipSuccess : hipEventSynchronize(ev_done[q]);
+        return qe::stream_gone(std::atomic_load(&ev_done_tag[q])) ? hipSuccess : hipEventSynchronize(ev_done[q]);
     }
     hipError_t done_query(int q) const {
         std::shared_lock<std::shared_mutex> life(qe::g_stream_life);
-        return qe::stream_gone(ev_done_tag[q]) ? hipSuccess : hipEventQuery(ev_done[q]);
+        return qe::stream_gone(std::atomic_load(&ev_done_tag[q])) ? hipSuccess : hipEventQuery(ev_done[q]);
     }
     hipError_t done_wait_on(hipStream_t s, int q) const {           // s waits for the run that used plane set q last
         std::shared_lock<std::shared_mutex> life(qe::g_stream_life);
-        return qe::stream_gone(ev_done_tag[q]) ? hipSuccess : hipStreamWaitEvent(s, ev_done[q], 0);
+        return qe::stream_gone(std::atomic_load(&ev_done_tag[q])) ? hipSuccess : hipStreamWaitEvent(s, ev_done[q], 0);
     }
     bool ev_done_set[NP] = {};
     size_t pl_p_words = 0, pl_t_words = 0;

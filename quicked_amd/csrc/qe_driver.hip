@@ -750,9 +750,9 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
     }
     HIP_CHECK(hipEventRecord(C.ev1, C.stream));
     HIP_CHECK(hipEventRecord(C.ev_last, C.sa()));
-    C.ev_last_tag = C.tag_a2[C.ai];
+    std::atomic_store(&C.ev_last_tag, C.tag_a2[C.ai]);
     HIP_CHECK(hipEventRecord(B.ev_done[par], C.sa()));
-    B.ev_done_tag[par] = C.tag_a2[C.ai];
+    std::atomic_store(&B.ev_done_tag[par], C.tag_a2[C.ai]);
     B.last_parity = par;
     if (C.staging) { HIP_CHECK(hipEventRecord(C.stage[C.si].done, C.sa())); C.stage[C.si].pending = true; C.staging = false; }
     QE_TRACE_POINT("stages launched");

@@ -392,7 +392,7 @@ struct Context {
         return runs_on_device_locked();
     }
     bool runs_on_device_locked() const {       // the caller holds g_stream_life (shared or exclusive)
-        if (!ev_last || stream_gone(ev_last_tag)) return false;
+        if (!ev_last || stream_gone(std::atomic_load(&ev_last_tag))) return false;
         const hipError_t e = hipEventQuery(ev_last);
         if (e == hipErrorNotReady) return true;
         if (e != hipSuccess) (void)hipGetLastError();

@@ -59,6 +59,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $out/calib_$c
 done
 python3 tools/summarise_pmc.py $out $tag $wls > /dev/null
+cp $out/pmc_traffic_latest.json profiles/pmc_traffic_latest.json      # (on the box's copy: the line below prints the traffic of THESE kernels)
 # the full line (what the driver runs) and config 4 on its own
 ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_line.json 2> $out/bench_line.err ) 2> $out/${tag}_bench_line_time.txt
 python3 bench.py --workload quicked --pairs 10000 --length 100000 --error 0.1 --steps 20 --warmup 3 --no-workloads --no-strong --indel-pairs 0 > $out/${tag}_bench_cfg4.json 2> $out/bench_cfg4.err
