@@ -21,6 +21,9 @@
 //                shrinks to one pool set at its next run, and the allocation is retried for QE_OOM_WAIT_MS (10 s).
 //                Every context has a `busy` mutex: its thread holds it for the length of an API call, a reclaiming thread
 //                only ever try_locks it.
+//   streams      are a budget too (the runtime's hardware queues): a context that is doing nothing gives its set / side
+//                streams back before another thread creates one (retire_idle_streams); events recorded on a stream that
+//                is gone are never touched again (StreamTag).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -600,10 +603,12 @@ inline bool reclaim(int device, int level, DevicePool* keep) {
 // runtime (Context::retire_streams; pools stay; the owner creates them again when it next needs them): a stream that the
 // calling thread is about to create then finds a hardware queue of its own
 inline void retire_idle_streams(int device) {
-    std::unique_lock<std::shared_mutex> life(g_stream_life, std::try_to_lock);
-    if (!life.owns_lock()) return;             // some thread is inside a call on an event of a set stream: another time
+    // lock order: g_ctx_mu is never taken while g_stream_life is held (ledger_plan holds g_ctx_mu and takes the life lock
+    // shared through runs_on_device: the other order deadlocked a bench run of the round's proof)
     std::vector<Context*> list;
     { std::lock_guard<std::mutex> lk(g_ctx_mu); list = g_ctx_all; }
+    std::unique_lock<std::shared_mutex> life(g_stream_life, std::try_to_lock);
+    if (!life.owns_lock()) return;             // some thread is inside a call on an event of a set stream: another time
     for (Context* c : list) {
         if (c == tl_ctx || c->device != device || !c->stream_w) continue;
         bool any = c->stream_x != nullptr || !c->leased.load();
