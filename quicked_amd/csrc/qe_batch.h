@@ -40,6 +40,7 @@ struct quicked_batch {
     qe::u32* d_flags[NP] = {};
     int parity = 0;
     int np_used = 2;                              // plane sets in rotation = stream / pool sets in rotation (run_batch)
+    int na_cap = 0;                               // the rotation depth this batch's first queued run was planned with: later runs do not go above it
     int last_parity = -1;                         // plane set of the last run queued (its end orders the next run's stash)
     size_t last_mat_bytes = 0;                    // fill matrices of this batch's last CIGAR run (all leaves at once)
     size_t last_fixed_bytes = 0;                  // everything else its align stage took from the pool (runs, strings, workspaces)

@@ -570,6 +570,11 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
         if ((double)min_set * k <= ((deep && k > sets_held) ? 0.6 : 1.0) * (double)avail) { na = k; break; }
     }
     if (C.memory_tight && C.tight_left-- <= 0) { C.memory_tight = false; C.tight_left = 0; }      // the spell is over: plan normally again
+    // The depth of a batch's rotation is decided by its first queued run and does not grow afterwards: what this thread may
+    // hold moves with what the other threads are doing at the instant of the plan, and a rotation that widened whenever a
+    // neighbour paused allocated another 25 GB pool set in the middle of a stream (two threads of 150 k pairs: the four
+    // timed runs took 1.9 instead of 0.18 s in three of eight processes, one thread ending up with five sets' pools)
+    if (!fetch && !C.memory_tight) { if (B.na_cap > 0) na = std::min(na, B.na_cap); else B.na_cap = na; }
     if (C.memory_tight) na = 1;
     // Sets outside the rotation keep their pools while this run's plan works without that memory -- the next batch may
     // widen the rotation again, and freeing / re-allocating tens of GB per run costs more than any of this saves (a stream
@@ -1211,7 +1216,7 @@ static void batch_reset_state(quicked_batch* B) {
     B->pl_p_words = 0; B->pl_t_words = 0;
     for (bool& h : B->have_rev) h = false;
     for (bool& e : B->ev_done_set) e = false;
-    B->parity = 0; B->pending = false; B->pending_fetch.reset(); B->d_score = nullptr;
+    B->parity = 0; B->pending = false; B->pending_fetch.reset(); B->d_score = nullptr; B->na_cap = 0;
     if (B->est_bound < 0) B->est_bound = 0;          // other pairs: QuickEd's sizing decision is taken again (a streamed batch keeps its estimate)
     B->res[0].clear(); B->res[1].clear(); B->vis = 0; B->wr = &B->res[0]; B->shadow_ready = false; B->last_parity = -1;
 }
