@@ -2,7 +2,8 @@
 // the API scope's lock discipline.  Compiled and run by tests/test_pool_cpu.py.
 #include "qe_pool.h"
 
-#include <cassert>
+#include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <thread>
 
@@ -30,9 +31,11 @@ int main() {
     // two threads alive at once need two contexts; a third, later, reuses one of them; another device gets its own
     Context *a = nullptr, *b = nullptr, *c = nullptr, *d1 = nullptr;
     {
-        std::thread ta([&] { a = lease_context(0); tl_leases.v.push_back(a); while (!b) std::this_thread::yield(); });
-        std::thread tb([&] { while (!a) std::this_thread::yield(); b = lease_context(0); tl_leases.v.push_back(b); });
+        std::atomic<Context*> ha{nullptr}, hb{nullptr};
+        std::thread ta([&] { Context* x = lease_context(0); tl_leases.v.push_back(x); ha = x; while (!hb.load()) std::this_thread::yield(); });
+        std::thread tb([&] { while (!ha.load()) std::this_thread::yield(); Context* x = lease_context(0); tl_leases.v.push_back(x); hb = x; });
         ta.join(); tb.join();
+        a = ha; b = hb;
     }
     CHECK(a != b && (a == first || b == first));
     std::thread([&] { c = lease_context(0); d1 = lease_context(1); tl_leases.v.push_back(c); tl_leases.v.push_back(d1); }).join();
