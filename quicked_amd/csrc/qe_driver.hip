@@ -1049,13 +1049,14 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
     auto trim_own = [&]() { (void)C.release_pools(nullptr, true); };
     const double t_job = now_ms();
     for (MergeItem& it : items) it.B->wr = &it.B->res[1 - it.B->vis];
+    std::vector<MergeItem> left;                          // declared out here: a failure below still finds every lock and batch
     try {
         if (items.size() == 1) {
             quicked_batch& B = *items[0].B;
             B.fin_status = fetch_pending(B);
             B.shadow_ready = true;
         } else {
-            std::vector<MergeItem> left;                  // batches whose runs did leave pairs (the skip flags said so; the collect step agrees)
+            // `left`: the batches whose runs did leave pairs (the skip flags said so; the collect step agrees)
             for (MergeItem& it : items) {
                 it.B->fin_status = fetch_pending(*it.B, &it.W);
                 if (!it.W.Ls.pair.empty()) left.push_back(std::move(it)); else { it.B->shadow_ready = true; it.B->wr = &it.B->res[it.B->vis]; it.lk.unlock(); }
@@ -1084,7 +1085,7 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
         // e.g. out of memory next to the other threads' pools: nothing is lost -- the runs' results are still in the batches'
         // result arenas, and the callers' fetches do the same work in their own contexts
         (void)hipGetLastError();
-        for (MergeItem& it : items) {
+        for (std::vector<MergeItem>* set : {&items, &left}) for (MergeItem& it : *set) {      // (an entry moved from one to the other owns no lock)
             if (!it.B || !it.lk.owns_lock() || it.B->shadow_ready) continue;
             quicked_batch& B = *it.B;
             B.wr = &B.res[B.vis];
