@@ -471,7 +471,7 @@ int qo_windowed(const char* pattern, int plen, const char* text, int tlen,
     }
     if (score_out) *score_out = w.score;
     if (hew_out) *hew_out = w.hew;
-    if (block_steps) *block_steps = w.block_steps;
+    if (block_steps) *block_steps += w.block_steps;           /* accumulates: QuickEd counts stage 1 and both stage-2 passes */
     free(w.Pv); free(w.Mv); free(w.peqw);
     pat_free(&pat);
     return QO_WIP;

@@ -2358,6 +2358,11 @@ __device__ __forceinline__ void windowed_body(const WindowArgs& A) {
     int pos_v = m - 1, pos_h = n - 1;
     int score = 0, hew = 0;
     u32 steps = 0;
+    if (A.state && valid) {                                         // the chain so far: k_windowed_quad's
+        const int64_t nt = A.T.ntasks;
+        pos_v = A.state[t]; pos_h = A.state[nt + t]; score = A.state[2 * nt + t]; hew = A.state[3 * nt + t];
+        steps = (u32)A.state[4 * nt + t];
+    }
 
     const bool w2 = W == 2 && O == 1 && !__any(valid && (hasN || E.raw));
     const bool cp_ok = CP && !sse && A.cp_path != 0 && !__any(valid && (hasN || E.raw));
@@ -2638,6 +2643,189 @@ __device__ __forceinline__ void windowed_body(const WindowArgs& A) {
 }
 __global__ __launch_bounds__(512) void k_windowed(WindowArgs A) { windowed_body<false>(A); }
 __global__ __launch_bounds__(512) void k_windowed_cp(WindowArgs A) { windowed_body<true>(A); }
+
+// ===========================================================================
+// WindowEd(2, 1) with FOUR LANES PER ALIGNMENT (k_windowed_quad): the cooperative form of the on-chip window above, for
+// launches of few waves whose duration is one lane's serial chain (a batch of a few thousand pairs, QuickEd's stage 1 of
+// config 4, a single pair).  Lane j of a quad owns rows 32 j .. 32 j + 31 of the 128 x 128 window as ONE 32-bit block:
+// the Myers step is exact for any partition of a column into blocks (bpm_commons.h:82-101 evaluates the recurrence cell
+// by cell; the carries between 32-bit blocks are what the 64-bit add carries inside a block), so every Pv / Mv bit equals
+// the reference's.  The four blocks form a systolic array skewed by one column per lane: at step s lane j works on
+// column s - j, its carry-in is lane j - 1's carry-out of the step before (one v_mov_dpp quad_perm:[3,0,1,2] per carry
+// bit; lane 0 takes the window's top boundary instead) -- 132 steps of one 32-bit block step instead of 256 64-bit
+// ones, and every step's text bit is a literal position of the lane's own text words (loaded j bases early).  Lanes 2 and
+// 3 leave {Pv after, Mv before} of columns 64 .. 127 in LDS; all four lanes then walk the traceback (bpm_windowed.c:504-
+// 561) redundantly from those words, so the quad agrees on the next window's anchor without another exchange.
+// x86 SSE semantics (bpm_windowed.c:283-445): the boundary pattern of the top carries, and block 1's last
+// column taking the carries of block 0's column one past the window -- here lanes 0 and 1 run that extra column and lanes
+// 2 and 3 run their last column two steps later than the skew alone would have them.
+// Only full windows: a task's chain stops at its first clamped window (or at once: N / non-canonical symbols) and
+// k_windowed takes it up from WindowArgs::state.
+// ===========================================================================
+__device__ __forceinline__ u32 quad_ror1(u32 x) {           // lane 4 q + j <- lane 4 q + (j + 3) % 4
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x93, 0xf, 0xf, false);
+}
+// block_step on a 32-bit block (bitop3 forms as in block_step_core); ph / mh = the pre-shift horizontal deltas
+__device__ __forceinline__ void sub_step(u32 e, u32& P, u32& M, u32 PHin, u32 MHin, u32& ph, u32& mh) {
+    const u32 xv = e | M;
+    const u32 ec = e | MHin;
+    const u32 sum = (ec & P) + P;
+    ph = bitop3<0xF3>(M, bitop3<0xFE>(sum, P, ec), 0u);           // M | ~(sum | P | Eqc)
+    mh = bitop3<0xB0>(P, sum, ec);                                // P & ((sum ^ P) | Eqc)
+    const u32 phs = (ph << 1) | PHin, mhs = (mh << 1) | MHin;
+    P = bitop3<0xF1>(mhs, xv, phs);                               // Mhs | ~(Xv | Phs)
+    M = phs & xv;
+}
+// one column of a lane's block: text bit `bit` of the lane's words (t0w, t1w), Eq masked by emask
+template <bool STORE>
+__device__ __forceinline__ void quad_col(u32 t0w, u32 t1w, int bit, u32 emask, u32 a, u32 b, u32& P, u32& M, u32 inP, u32 inM,
+                                         u32& oP, u32& oM, uint2* st) {
+    const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0w, bit, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1w, bit, 1);
+    const u32 e = bitop3<0x90>(~(a ^ m0), b, m1) & emask;
+    const u32 Mb = M;
+    u32 ph, mh;
+    sub_step(e, P, M, inP, inM, ph, mh);
+    oP = ph >> 31; oM = mh >> 31;
+    if (STORE) *st = make_uint2(P, Mb);
+}
+// code planes 0 / 1 of 64 bases at bit offset `bit`
+__device__ __forceinline__ void load_planes_ab(const u64* __restrict__ base, int bit, u64& a, u64& b) {
+    const int w = bit >> 6, sh = bit & 63;
+    const u64* q = base + 3 * (int64_t)w;
+    u64 a0 = q[0], b0 = q[1];
+    if (sh) {
+        a0 = (a0 >> sh) | (q[3] << (64 - sh));
+        b0 = (b0 >> sh) | (q[4] << (64 - sh));
+    }
+    a = a0; b = b0;
+}
+
+__global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
+    const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & 3;
+    const int t = wv * 16 + (lane >> 2);
+    if (wv * 16 >= A.T.ntasks) return;
+    uint2* const hist = (uint2*)((char*)qe_dyn_lds + (size_t)QE_WAVE_IN_BLOCK() * QE_WQ_LDS_PER_WAVE);   // [QE_WQ_SLOTS][64]
+    uint2* const hw_ = hist + lane;                                   // this lane's column of the slots
+    const uint2* const r2 = hist + ((lane & ~3) | 2);                 // lane 2's / lane 3's of this quad
+    const uint2* const r3 = hist + ((lane & ~3) | 3);
+    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    const bool valid = pair >= 0;
+    int m = 0, n = 0, p0 = 0, t0 = 0;
+    const u64* pp = A.P.pl_p; const u64* tp = A.P.pl_t;
+    u32 fl = 0;
+    if (valid) {
+        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
+        pp = A.P.pl_p + A.P.pl_p_off[pair]; tp = A.P.pl_t + A.P.pl_t_off[pair];
+        fl = A.P.flags[pair];
+    }
+    const bool ok = valid && (fl & (FLAG_HAS_N | FLAG_NONCANON)) == 0;
+    const bool sse = A.sse != 0;
+    const bool is0 = j == 0;
+    int pos_v = m - 1, pos_h = n - 1;
+    int score = 0, hew = 0;
+    u32 steps = 0;
+    RunSink R; R.init(nullptr, 0);                                    // score only: never written
+    while (__any(ok && pos_v >= 127 && pos_h >= 127)) {
+        const bool on = ok && pos_v >= 127 && pos_h >= 127;
+        const int v0 = on ? pos_v - 127 : 0, h0 = on ? pos_h - 127 : 0;
+        // pattern: this lane's 32 rows; rows 64 .. 127 (the traceback's) for the walk's Eq words
+        u64 pa = 0, pb = 0, a1 = 0, b1 = 0;
+        if (on) {
+            load_planes_ab(pp, p0 + v0 + 32 * j, pa, pb);
+            load_planes_ab(pp, p0 + v0 + 64, a1, b1);
+        }
+        const u32 a = lo32(pa), b = lo32(pb);
+        // text: 192 bases from t0 + h0 - j, so that bit s of these words is column s - j (what this lane does at step s)
+        u64 SA[3] = {0, 0, 0}, SB[3] = {0, 0, 0};
+        if (on) {
+            const int ts = t0 + h0 - j, tsc = max(ts, 0), lsh = tsc - ts;
+            const int w = tsc >> 6, sh = tsc & 63;
+            const u64* q = tp + 3 * (int64_t)w;
+            const u64 x0 = q[0], x1 = q[3], x2 = q[6], x3 = q[9], y0 = q[1], y1 = q[4], y2 = q[7], y3 = q[10];
+            if (sh) {
+                SA[0] = (x0 >> sh) | (x1 << (64 - sh)); SA[1] = (x1 >> sh) | (x2 << (64 - sh)); SA[2] = (x2 >> sh) | (x3 << (64 - sh));
+                SB[0] = (y0 >> sh) | (y1 << (64 - sh)); SB[1] = (y1 >> sh) | (y2 << (64 - sh)); SB[2] = (y2 >> sh) | (y3 << (64 - sh));
+            } else { SA[0] = x0; SA[1] = x1; SA[2] = x2; SB[0] = y0; SB[1] = y1; SB[2] = y2; }
+            if (lsh) {                                                // the window starts at the text's first bases: j - ts bits of nothing first
+                SA[2] = (SA[2] << lsh) | (SA[1] >> (64 - lsh)); SA[1] = (SA[1] << lsh) | (SA[0] >> (64 - lsh)); SA[0] <<= lsh;
+                SB[2] = (SB[2] << lsh) | (SB[1] >> (64 - lsh)); SB[1] = (SB[1] << lsh) | (SB[0] >> (64 - lsh)); SB[0] <<= lsh;
+            }
+        }
+        const u32 tw0[5] = {lo32(SA[0]), hi32(SA[0]), lo32(SA[1]), hi32(SA[1]), lo32(SA[2])};
+        const u32 tw1[5] = {lo32(SB[0]), hi32(SB[0]), lo32(SB[1]), hi32(SB[1]), lo32(SB[2])};
+        // columns 64 .. 127 un-skewed, for the walk
+        const u64 X0 = j ? ((SA[1] >> j) | (SA[2] << (64 - j))) : SA[1];
+        const u64 X1 = j ? ((SB[1] >> j) | (SB[2] << (64 - j))) : SB[1];
+        // the window's boundaries (bpm_windowed.c:226-230, 260; SSE: 348, 393, 424)
+        const u64 ph_first = (v0 == 0) ? QE_ONES : 0;
+        const u32 pinit = (h0 == 0) ? ~0u : 0u;
+        const u64 hin0 = sse ? (0x5555555555555556ull | (ph_first & 1)) : ph_first;
+        const u64 hin1 = sse ? 0x5555555555555555ull : ph_first;
+        const u32 bw[5] = {lo32(hin0), hi32(hin0), lo32(hin1), hi32(hin1), 1u};
+        // the extra column's Eq (lanes 0 and 1, SSE): text[tlen] reads as N, which matches nothing here (A.7(4))
+        const u32 eqx = (on && pos_h + 1 < n) ? ~0u : 0u;
+        u32 P = pinit, M = 0, oP = 0, oM = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the walk of the window before has read its slots
+#pragma unroll
+        for (int s = 0; s < 129; ++s) {
+            u32 inP = quad_ror1(oP), inM = quad_ror1(oM);
+            const u32 bnd = __builtin_amdgcn_ubfe(bw[s >> 5], s & 31, 1);
+            inP = is0 ? bnd : inP; inM = is0 ? 0u : inM;
+            const u32 em = (s == 128 && is0) ? eqx : ~0u;
+            if (s < 3) {
+                if (j <= s) quad_col<false>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inP, inM, oP, oM, hw_);
+            } else if (s < 66) {
+                quad_col<false>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inP, inM, oP, oM, hw_);
+            } else {
+                quad_col<true>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inP, inM, oP, oM, hw_ + (s - 66) * 64);
+            }
+        }
+        {   // step 129: lane 1 runs the extra column (its carries reach lane 2 only under SSE semantics), lane 3 column 126
+            const u32 inP = quad_ror1(oP), inM = quad_ror1(oM);
+            const u32 kP = oP, kM = oM;
+            if (j & 1) quad_col<true>(tw0[4], tw1[4], 1, (j == 1) ? eqx : ~0u, a, b, P, M, inP, inM, oP, oM, hw_ + 63 * 64);
+            if (j == 1 && !sse) { oP = kP; oM = kM; }
+        }
+        {   // step 130: lane 2's column 127 (text bit 127 + 2)
+            const u32 inP = quad_ror1(oP), inM = quad_ror1(oM);
+            if (j == 2) quad_col<true>(tw0[4], tw1[4], 1, ~0u, a, b, P, M, inP, inM, oP, oM, hw_ + 63 * 64);
+        }
+        {   // step 131: lane 3's column 127 (text bit 127 + 3)
+            const u32 inP = quad_ror1(oP), inM = quad_ror1(oM);
+            if (j == 3) quad_col<true>(tw0[4], tw1[4], 2, ~0u, a, b, P, M, inP, inM, oP, oM, hw_ + 64 * 64);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lanes 2 / 3 wrote, every lane of the quad reads
+        if (on) steps += 256u;
+        // in-window traceback over the stored columns: window rows / columns 64 .. 127 (cf. k_windowed's on-chip path)
+        int vw = 127, hw = 127, wscore = 0;
+        bool inr = on;
+        const u32 alo = lo32(a1), ahi = hi32(a1), blo = lo32(b1), bhi = hi32(b1);
+#pragma unroll 1
+        for (int q = 7; q >= 0 && __any(inr); --q) {
+            const u32 t0s = (u32)(X0 >> (8 * q)), t1s = (u32)(X1 >> (8 * q));
+            u64 tP[8], tM[8], tE[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint2 l2 = r2[(8 * q + c) * 64], l3 = r3[(8 * q + c + 1) * 64];
+                const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0s, c, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1s, c, 1);
+                tE[c] = mk64(bitop3<0x90>(~(alo ^ m0), blo, m1), bitop3<0x90>(~(ahi ^ m0), bhi, m1));
+                tP[c] = mk64(l2.x, l3.x);
+                tM[c] = mk64(l2.y, l3.y);
+            }
+            window_walk_tile<true>(tP, tM, tE, inr, vw, hw, wscore, R);
+        }
+        if (on) {
+            if (wscore > 64 * A.hew_threshold / 100) ++hew;         // (W - O) * 64 * hew_threshold / 100, bpm_windowed.c:556-558
+            score += wscore;
+            pos_v = v0 + vw; pos_h = h0 + hw;
+        }
+    }
+    if (is0 && t < A.T.ntasks) {
+        const int64_t nt = A.T.ntasks;
+        A.state[t] = pos_v; A.state[nt + t] = pos_h; A.state[2 * nt + t] = score; A.state[3 * nt + t] = hew;
+        A.state[4 * nt + t] = (int32_t)steps;
+    }
+}
 
 // ===========================================================================
 // QuickEd without a host round trip after stage 1 (the common case: no pair leaves stage 1).  k_stage1_decide applies

@@ -576,8 +576,18 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
     a.o_score = O.score; a.o_hew = O.hew; a.o_nruns = O.nruns; a.o_nops = O.nops; a.o_edits = O.edits; a.o_steps = O.steps;
     // (2, 1) windows stay on chip (k_windowed); every other shape runs the checkpointed general path
     a.cp_path = env_int("QE_WINDOWED_CP", 1);
-    if (W == 2 && O_ == 1) launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192, /* chain */ true);
-    else launch_groups(C, k_windowed_cp, a, (size_t)ng, 8, 8192, /* chain */ true);
+    if (W == 2 && O_ == 1) {
+        // few waves: four lanes per alignment run the chain of full windows first (k_windowed_quad, a third of the one-lane
+        // chain's latency for 1.9 x its instructions), the one-lane kernel then only has every task's clamped last windows
+        // left.  Worth it while the launches in flight leave SIMDs idle; QE_WINDOWED_QUAD = 0 / 1: never / always (tests)
+        const int quad = env_int("QE_WINDOWED_QUAD", -1);
+        const size_t waves = (size_t)ng * 4 * (size_t)std::max(1, fetch ? 1 : C.in_flight);
+        if (score_only && (quad == 1 || (quad != 0 && waves <= 1100))) {
+            a.state = C.scratch_p->take<int32_t>(5 * nt);
+            launch_groups(C, k_windowed_quad, a, nt / 16, 4, (size_t)QE_WQ_LDS_PER_WAVE, /* chain */ true);
+        }
+        launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192, /* chain */ true);
+    } else launch_groups(C, k_windowed_cp, a, (size_t)ng, 8, 8192, /* chain */ true);
     if (d_score_out) *d_score_out = O.score;
     if (dev_out) *dev_out = O;
     if (dev_tasks) *dev_tasks = T;

@@ -134,7 +134,14 @@ struct WindowArgs {
     uint8_t* ws;  const int64_t* g_ws_off;
     u32* runs;  const int64_t* g_runs_off;  const int32_t* g_runs_cap;
     int32_t* o_score;  int32_t* o_hew;  int32_t* o_nruns;  int32_t* o_nops;  int32_t* o_edits;  u32* o_steps;
+    // chain state [5][ntasks] = {pos_v, pos_h, score, hew, steps} per task: k_windowed_quad (four lanes per alignment, full
+    // (2, 1) windows only) leaves every task's chain where its first clamped window begins, k_windowed takes it up from
+    // there; null: k_windowed runs the whole chain
+    int32_t* state = nullptr;
 };
+// k_windowed_quad: LDS per wave = {Pv after, Mv before} of the traceback's 64 columns, [slot][lane] x 8 B, 65 slots
+// (the lanes of a quad run one column apart)
+enum : int { QE_WQ_SLOTS = 65, QE_WQ_LDS_PER_WAVE = QE_WQ_SLOTS * 64 * 8 };
 
 // QuickEd's stage-1 rule on the device (quicked.c:201-202): the WindowEd(2,1) score of a task is its bound unless too many
 // of its windows were high-error ones; est = the cutoff the host sized the align step for

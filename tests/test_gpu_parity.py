@@ -344,6 +344,55 @@ def test_windowed_checkpoint_and_history_paths(cp, monkeypatch):
     assert cnt[2] == sum(O.oracle_align(p, t, trace=True, algo=1, only_score=True)[3]["window_block_steps"] for p, t in b.pairs())
 
 
+@pytest.mark.parametrize("quad", ["1", "0"])
+def test_windowed_quad_forced(quad, golden, monkeypatch):
+    """WindowEd(2, 1) score-only with four lanes per alignment (k_windowed_quad: 32-bit blocks in a systolic array, the
+    chain of full windows; k_windowed finishes every task's clamped windows) against one lane per alignment
+    (QE_WINDOWED_QUAD = 0): the goldens captured from the compiled reference (scalar and x86-SSE window semantics, the
+    QuickEd stages the HEW counts drive), the oracle on ragged / N / lower-case input, indel-heavy pairs whose windows
+    leave the diagonal, windows that start at the text's first bases, and the work counters."""
+    monkeypatch.setenv("QE_WINDOWED_QUAD", quad)
+    for name in ("cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len128", "len130", "len1024"):
+        entry = golden["datasets"][name]
+        batch = datagen.generate(**entry["gen"])
+        for label, run in entry["runs"].items():
+            if run["params"].get("algo") not in (0, 1):
+                continue
+            scores, status, cig, _ = gpu_batch(batch, **run["params"])
+            assert status.tolist() == run["status"], (name, label)
+            assert scores.tolist() == run["score"], (name, label)
+            if "cigar_sha256" in run:
+                assert [sha(c) for c in cig] == run["cigar_sha256"], (name, label)
+    rng = np.random.default_rng(91)
+    pairs = mixed_batch()
+    for i in range(60):
+        L = int(rng.choice([127, 128, 129, 130, 191, 192, 193, 255, 256, 257, 700, 2500, 6000]))
+        e = float(rng.choice([0.0, 0.03, 0.1, 0.3]))
+        b = datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=9100 + i,
+                             indels_num=int(rng.integers(0, 3)) if L >= 2500 else 0, indels_len=150)
+        p, t = next(b.pairs())
+        if rng.random() < 0.3:
+            t = t[: max(1, len(t) - int(rng.integers(0, max(1, len(t) // 3))))]
+        pairs.append((p, t))
+    for kw in (dict(algo=1, only_score=True, window_size=2, overlap_size=1),
+               dict(algo=1, only_score=True, window_size=2, overlap_size=1, force_scalar=True),
+               dict(algo=0), dict(algo=0, force_scalar=True), dict(algo=0, only_score=True),
+               dict(algo=0, hew_threshold=(10, 10), hew_percentage=(1, 1))):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            if k in ("hew_threshold", "hew_percentage"):
+                getattr(al._params, k)[0], getattr(al._params, k)[1] = v
+            else:
+                setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            assert out[i] == O.oracle_align(p, t, **kw), (quad, kw, i, len(p), len(t))
+    b = datagen.generate(80, 3000, 0.1, seed=92, indels_num=1, indels_len=300)
+    for kw in (dict(algo=1, only_score=True, window_size=2, overlap_size=1), dict(algo=0)):
+        _, _, _, cnt = gpu_batch(b, **kw)
+        assert cnt[2] == sum(O.oracle_align(p, t, trace=True, **kw)[3]["window_block_steps"] for p, t in b.pairs()), kw
+
+
 @pytest.mark.parametrize("multi", ["1", "0"])
 def test_fill_multi_slot_passes_forced(multi, monkeypatch):
     """the BandEd fill runs K = 3 band slots per skewed pass, every lane masked to its own band (QE_FILL_MULTI = 1, default),
