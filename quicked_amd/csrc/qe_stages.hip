@@ -908,6 +908,16 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
                 a.only_if = O.hew + o;
             }
         }
+        // tight bands (QuickEd's bound, exact child distances) in a launch of few waves: sixteen lanes per leaf, the band's
+        // rows as a systolic array (k_banded_sys); what it flags -- N, a band of more than 15 slots -- stays with the
+        // one-lane kernel.  QE_FILL_SYS = 0 / 1: never / wherever the bound is tight (tests)
+        const int sys = env_int("QE_FILL_SYS", -1);
+        if (Gfill < 2 && a.only_if == nullptr && tight_runs && hew_init.empty() &&
+            (sys == 1 || (sys != 0 && (size_t)(g1 - g0) * 16 * (size_t)std::max(1, fetch ? 1 : C.in_flight) <= 4096))) {
+            a.o_abort = O.hew + o;
+            launch_groups(C, k_banded_sys, a, (size_t)(g1 - g0) * 16, 4, 0);
+            a.only_if = O.hew + o;
+        }
         a.fill_multi = env_int("QE_FILL_MULTI", 1);
         a.lane_rel = env_int("QE_LANE_REL", 1);
         launch_groups(C, k_banded<true>, a, (size_t)(g1 - g0), 8, 0);     // everything, or what the cooperative fill flagged

@@ -417,6 +417,66 @@ def test_fill_multi_slot_passes_forced(multi, monkeypatch):
                 assert out[i] == want, (multi, kw, i, len(p), len(t))
 
 
+@pytest.mark.parametrize("sys_", ["1", "0"])
+def test_fill_systolic_forced(sys_, golden, monkeypatch):
+    """the fill of TIGHT bands (QuickEd's bound, the exact child distances of a Hirschberg split) with sixteen lanes per
+    leaf -- the band's rows as a systolic array, the reference's 64-column bookkeeping at every chunk's end
+    (k_banded_sys; QE_FILL_SYS = 1) -- against one lane per leaf (0): the goldens captured from the compiled reference
+    (CIGAR bytes), the oracle on ragged / N / lower-case input (flagged leaves fall back), forced deep splits whose
+    children start anywhere in their pair's pattern, pairs with large indels (bands of more than 15 slots fall back),
+    and the fill's block-advance counter."""
+    monkeypatch.setenv("QE_FILL_SYS", sys_)
+    for name in ("cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len63", "len64", "len65", "len128", "len130", "len1024"):
+        entry = golden["datasets"][name]
+        batch = datagen.generate(**entry["gen"])
+        for label, run in entry["runs"].items():
+            if run["params"].get("algo") != 0:
+                continue
+            scores, status, cig, _ = gpu_batch(batch, **run["params"])
+            assert status.tolist() == run["status"], (name, label)
+            assert scores.tolist() == run["score"], (name, label)
+            if "cigar_sha256" in run:
+                assert [sha(c) for c in cig] == run["cigar_sha256"], (name, label)
+    rng = np.random.default_rng(17)
+    pairs = mixed_batch()
+    for i in range(72):
+        L = int(rng.choice([1, 63, 64, 65, 200, 1000, 1023, 1024, 1025, 2500, 6000]))
+        e = float(rng.choice([0.0, 0.01, 0.05, 0.2]))
+        b = datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=1700 + i,
+                             indels_num=int(rng.integers(0, 2)) if L >= 2500 else 0, indels_len=150)
+        p, t = next(b.pairs())
+        if rng.random() < 0.25:
+            t = t[: max(1, len(t) - int(rng.integers(0, max(1, len(t) // 4))))]
+        pairs.append((p, t))
+    for kw in (dict(algo=0), dict(algo=0, force_scalar=True), dict(algo=0, only_score=True)):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            assert out[i] == O.oracle_align(p, t, **kw), (sys_, kw, i, len(p), len(t))
+    # forced deep splits (the oracle's Hirschberg with the same threshold, cf. test_hirschberg_forced_deep_splits)
+    import ctypes as C
+    monkeypatch.setenv("QE_SPLIT_BYTES", str(1 << 15))
+    lib = O.oracle()
+    batch = datagen.generate(count=70, length=3000, error=0.08, seed=1801)
+    scores, status, cig, _ = gpu_batch(batch, algo=0)
+    for i, (p, t) in enumerate(batch.pairs()):
+        st, sc, cg, tr = O.oracle_align(p, t, trace=True, algo=0)
+        ops = C.create_string_buffer(len(p) + len(t) + 1)
+        nn = C.c_int64()
+        lib.qo_hirschberg(p, len(p), t, len(t), tr["bound"], 1 << 15, ops, C.byref(nn), None)
+        buf = C.create_string_buffer(2 * nn.value + 16)
+        lib.qo_cigar_rle(ops, nn.value, buf)
+        assert scores[i] == sc and cig[i] == buf.value.decode(), (sys_, i)
+    monkeypatch.delenv("QE_SPLIT_BYTES")
+    b = datagen.generate(96, 3000, 0.05, seed=18)
+    _, _, _, cnt = gpu_batch(b, algo=0)
+    tr = [O.oracle_align(p, t, trace=True, algo=0)[3] for p, t in b.pairs()]
+    assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
+    assert cnt[3] == sum(x["traceback_steps"] for x in tr)
+
+
 @pytest.mark.parametrize("tall", ["1", "0"])
 def test_tall_band_cooperative_fill(tall, monkeypatch):
     """QuickEd's align step on pairs with LARGE bounds (large indels: bands of 30-50 slots) in a launch of few waves: the
