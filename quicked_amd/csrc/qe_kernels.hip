@@ -2224,6 +2224,15 @@ struct RunSink {
         nops += pred ? count : 0;
         edits += (pred && op != (int)OP_M) ? count : 0;
     }
+    // emit without the op / edit counters (walk_tile_lean derives them from its step and match counts)
+    __device__ __forceinline__ void emit_run(int op, int count, bool pred) {
+        const bool brk = pred && op != cur_op;
+        const bool st = brk && cur_len > 0;
+        if (st && nruns < cap) runs[(int64_t)nruns * stride] = ((u32)cur_len << 2) | (u32)cur_op;
+        nruns += st ? 1 : 0;
+        cur_len = brk ? count : cur_len + (pred ? count : 0);
+        cur_op = brk ? op : cur_op;
+    }
     __device__ __forceinline__ void flush() {
         if (cur_len > 0) {
             if (nruns < cap) runs[(int64_t)nruns * stride] = ((u32)cur_len << 2) | (u32)cur_op;
@@ -2292,6 +2301,51 @@ __device__ __forceinline__ void walk_tile(const u64 (&tP)[TW], const u64 (&tM)[T
     }
 }
 
+// walk_tile for canonical input with the rare things behind branches the wave skips when no lane takes them
+// (s_cbranch_execz): a column costs ~30 instructions instead of ~85 while no lane of the wave starts a deletion run or
+// ends a run of equal operations at it (a path is mostly a diagonal of matches).  The same steps and the same runs; the operation / edit counters are not kept per
+// column: nops = steps (+ the leftovers), edits = steps - nmatch.
+template <int TW>
+__device__ __forceinline__ void walk_tile_lean(const u64 (&tP)[TW], const u64 (&tM)[TW], const u64 (&tE)[TW], bool in_tile,
+                                               u32 inb_same, u32 inb_7, int Rb, int& v, int& h, u32& steps, int& nmatch, RunSink& R) {
+#pragma unroll
+    for (int j = TW - 1; j >= 0; --j) {
+        const bool mine = in_tile && (h & (TW - 1)) == j;
+        const u32 inb = (j == TW - 1) ? inb_7 : inb_same;
+        const int bit = v & 63;
+        const u32 pb = inb & (u32)(tP[j] >> bit) & 1u;
+        int r = 0, b1 = bit;
+        if (mine && pb != 0) {                        // deletions: Pv bits bit, bit-1, ... while set (v moves up, h stays)
+            const u64 x = tP[j] << (63 - bit);
+            r = min(__clzll((long long)~x), bit + 1);
+            R.emit_run((int)OP_D, r, true);
+            b1 = (bit - r) & 63;
+        }
+        const bool up = r == bit + 1;                 // the run reached the top of the block: next round, same column
+        const bool go = mine && !up;
+        const u32 isI = inb & (u32)(tM[j] >> b1) & 1u;
+        const u32 eq = (u32)(tE[j] >> b1) & 1u;
+        const int op = isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X);
+        const bool brk = go && op != R.cur_op;
+        if (brk) {
+            if (R.cur_len > 0) {
+                if (R.nruns < R.cap) R.runs[(int64_t)R.nruns * R.stride] = ((u32)R.cur_len << 2) | (u32)R.cur_op;
+                ++R.nruns;
+            }
+            R.cur_len = 0; R.cur_op = op;
+        }
+        R.cur_len += go ? 1 : 0;
+        nmatch += (go && !isI && eq) ? 1 : 0;
+        v -= r + ((go && !isI) ? 1 : 0);
+        h -= go ? 1 : 0;
+        steps += (u32)r + (go ? 1u : 0u);
+        in_tile = in_tile && !(mine && up) && v >= 0 && (v >> 6) == Rb;
+        // opaque to the optimizer: InstCombine's known-bits walk over the v / h phi chains of TW conditional columns inside
+        // a loop is exponential in TW (28 s of a 29 s compile at TW = 16 in isolation, no end in the kernels)
+        asm("" : "+v"(v), "+v"(h));
+    }
+}
+
 // ===========================================================================
 // BandEd traceback (bpm_banded.c:967-1036): priority D -> I -> M/X.  One lane per task walks its own
 // path.  The fill left a checkpoint {Pv, Mv} every QE_CP_COLS (16) columns and the carry-in words of every
@@ -2304,8 +2358,10 @@ __device__ __forceinline__ void walk_tile(const u64 (&tP)[TW], const u64 (&tM)[T
 __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
     if (g * 64 >= A.T.ntasks) return;
-    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    if (A.only_if != nullptr && pair >= 0 && A.only_if[t] == 0) pair = -1;
     const bool valid = pair >= 0;
+    if (!__any(valid)) return;
     int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0;
     const u64* pp = A.P.pl_p; const u64* tp = A.P.pl_t;
     EqTest E; E.pp = pp; E.tp = tp; E.ap = nullptr; E.at = nullptr; E.raw = false;
@@ -2333,6 +2389,7 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     }
     int h = n - 1, v = m - 1;
     u32 steps = 0;
+    int nmatch = 0;
     // what a round needs besides the checkpoint changes rarely: band-edge records and text planes per chunk (every 8
     // tiles), carry words per (chunk, slot), pattern planes per block row -- kept in registers, reloaded on change
     int ck = -1, cs = -1, cR = -1;
@@ -2420,9 +2477,10 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
         // walk, column by column, straight-line: at its column a lane takes the whole run of deletions
         // (consecutive set Pv bits below its row) and then the one step that leaves the column
         if (any_raw) walk_tile<true, TW>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, R, E, p0, t0);
-        else walk_tile<false, TW>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, R, E, p0, t0);
+        else walk_tile_lean<TW>(tP, tM, tE, act, inb_same, inb_7, Rb, v, h, steps, nmatch, R);
     }
     if (!valid) return;
+    if (!any_raw) { R.nops = (int)steps; R.edits = (int)steps - nmatch; }      // what walk_tile_lean does not count per column
     R.push_n(OP_I, h + 1);
     R.push_n(OP_D, v + 1);
     R.flush();
@@ -2433,6 +2491,145 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     A.o_edits[t] = R.edits;
     A.o_steps[t] = steps;
 }
+
+// ===========================================================================
+// BandEd traceback with G = 4 / 8 / 16 LANES PER ALIGNMENT (k_traceback_sys<log2 G>), for launches of few waves: there
+// k_traceback's duration is one lane's chain of ~(n / 16 + m / 64) rounds, each a dependent load (the checkpoint the walk
+// has just decided on), 16 block steps of recompute and the walk of 16 columns.  Here a round of the group rebuilds G tiles
+// at once -- the G / 2 column tiles to the left of the walk's position, for each the block row the path is expected in
+// (a path runs along its diagonal: 16 rows up per column tile) and the block row above it; every lane loads its tile's
+// checkpoint / carry words / planes and runs the 16 block steps, all in the time one tile takes -- and then the walk
+// visits them in path order: the walker's state (v, h, the run under construction) is the same in all G lanes, the lane
+// whose tile the walker is in walks it (walk_tile, the same code and therefore the same steps, runs and bytes as
+// k_traceback), its state is broadcast to the group, and the next owner takes over.  A path that leaves the predicted
+// tiles (an indel run longer than the prediction's slack) just ends the round early; the next round starts from where
+// the walker really is.  One memory latency and one recompute per ~8 G columns instead of per 16.
+// Tasks with N or non-canonical symbols are flagged (o_abort) and left to k_traceback.
+// ===========================================================================
+template <int LG>
+__global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
+    constexpr int GL = 1 << LG, NT = 64 >> LG;                        // lanes per task, tasks per wave
+    const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & (GL - 1), gl = lane & ~(GL - 1);
+    const int t = wv * NT + (lane >> LG);
+    if (wv * NT >= A.T.ntasks) return;
+    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    const bool valid = pair >= 0;
+    int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0;
+    const u64* pp = A.P.pl_p; const u64* tp = A.P.pl_t;
+    u32 fl = 0;
+    if (valid) {
+        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t]; cut_in = A.T.cutoff[t];
+        pp = A.P.pl_p + A.P.pl_p_off[pair]; tp = A.P.pl_t + A.P.pl_t_off[pair];
+        fl = A.P.flags[pair];
+    }
+    const bool ok = valid && (fl & (FLAG_HAS_N | FLAG_NONCANON)) == 0;
+    if (valid && j == 0) A.o_abort[t] = ok ? 0 : 1;
+    if (!__any(ok)) return;
+    const Geom G = band_geometry(m, n, cut_in);
+    const int nw = (m + 63) >> 6;
+    const int g = ok ? (t >> 6) : 0, col = t & 63;
+    const int gns = A.g_nslots[g], gnch = A.g_nch[g];
+    const GroupWs W = group_ws(const_cast<uint8_t*>(A.ws), A.g_ws_off[g], gns, A.g_nrows[g], gnch);
+    const int16_t* cf = W.cf + col;
+    const int16_t* cl = W.cl + col;
+    const uint4* cp = A.mat + A.g_mat_off[g] + col;
+    const int64_t cps = (int64_t)gns * 64;
+    const uint4* hw = cp + (int64_t)QE_CPC * gnch * cps;
+    RunSink R;
+    {
+        const int cap = ok ? A.g_runs_cap[g] : 0;
+        R.init(ok ? A.runs + A.g_runs_off[g] + (A.runs_by_task ? (int64_t)col * cap : (int64_t)col) : nullptr, cap, A.runs_by_task ? 1 : 64);
+    }
+    int h = n - 1, v = m - 1;
+    u32 steps = 0;
+    int nmatch = 0;
+    constexpr int TW = QE_CP_COLS;
+    while (__any(ok && v >= 0 && h >= 0)) {
+        const bool live = ok && v >= 0 && h >= 0;
+        // this lane's tile: column tile q0 - x, block row b0(x) or the one above
+        const int x = j >> 1;
+        const int q = (h / TW) - x;
+        const int v_in = (x == 0) ? v : v - (h - (TW * q + TW - 1));          // where the diagonal meets the tile's right edge
+        const int Rb = (max(v_in, 0) >> 6) - (j & 1);
+        const bool act = live && q >= 0 && Rb >= 0;
+        const int k = max(q, 0) / (64 / TW);
+        u64 tP[TW], tM[TW], tE[TW];
+#pragma unroll
+        for (int c = 0; c < TW; ++c) { tP[c] = 0; tM[c] = 0; tE[c] = 0; }
+        u32 inb_same = 0, inb_7 = 0;
+        u64 P = 0, M = 0, T0 = 0, T1 = 0, hinP = 0, hinM = 0, pa = 0, pb = 0;
+        bool computed = false;
+        int cl_b = -1;
+        if (act) {
+            const int cf_a = cf[(int64_t)(k + 1) * 64], cf_b = cf[(int64_t)k * 64];
+            cl_b = cl[(int64_t)k * 64];
+            load_planes_ab(tp, t0 + 64 * k, T0, T1);
+            load_planes_ab(pp, p0 + 64 * Rb, pa, pb);
+            const int pos_v = k - G.prolog, s = Rb - pos_v;
+            // a step at column h reads Pv of stored column h + 1: inside the band of THAT column's chunk or 0 (oracle header)
+            inb_same = (u32)((s >= 0) & (s >= cf_b) & (s <= cl_b));
+            inb_7 = ((q & (64 / TW - 1)) == 64 / TW - 1) ? (u32)((s >= 1) & (s - 1 >= cf_a) & (s - 1 <= cl_b)) : inb_same;
+            computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
+            if (computed) {
+                const uint4 c0 = cp[(int64_t)q * cps + (int64_t)s * 64];
+                const uint4 w0 = hw[((int64_t)k * gns + s) * 64];
+                hinP = mk64(w0.x, w0.y); hinM = mk64(w0.z, w0.w);
+                P = mk64(c0.x, c0.y); M = mk64(c0.z, c0.w);
+            }
+        }
+        {   // TW block steps from the checkpoint: the fill's arithmetic, so its bits
+            const int c_first = (TW * max(q, 0)) & 63;
+            const u32 alo = lo32(pa), ahi = hi32(pa), blo = lo32(pb), bhi = hi32(pb);
+            const u32 t0s = (u32)(T0 >> c_first), t1s = (u32)(T1 >> c_first);
+            const u32 hp = (u32)(hinP >> c_first), hm = (u32)(hinM >> c_first);
+            u32 Plo = lo32(P), Phi = hi32(P), Mlo = lo32(M), Mhi = hi32(M), gP = 0, gM = 0;
+#pragma unroll
+            for (int c = 0; c < TW; ++c) {
+                const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0s, c, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1s, c, 1);
+                const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1), ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
+                tE[c] = mk64(elo, ehi);
+                tM[c] = mk64(Mlo, Mhi);
+                block_step_fused(elo, ehi, Plo, Phi, Mlo, Mhi, __builtin_amdgcn_ubfe(hp, c, 1), __builtin_amdgcn_ubfe(hm, c, 1), gP, gM);
+                tP[c] = mk64(Plo, Phi);
+            }
+        }
+        if (!computed) {
+#pragma unroll
+            for (int c = 0; c < TW; ++c) { tP[c] = 0; tM[c] = 0; }
+            // the row the band bookkeeping creates at the end of a chunk: Pv = ~0, Mv = 0 (bpm_banded.c:910)
+            if (act && (Rb - (k - G.prolog)) == cl_b + 1 && (q & (64 / TW - 1)) == 64 / TW - 1) tP[TW - 1] = QE_ONES;
+        }
+        // the walk, tile by tile in path order
+        bool first_phase = true;
+        while (true) {
+            const bool mine = act && live && v >= 0 && h >= 0 && (h / TW) == q && (v >> 6) == Rb;
+            const u64 bal = __ballot(mine);
+            const u32 grp = (u32)(bal >> gl) & ((1u << GL) - 1u);
+            if (!__any(grp != 0)) break;
+            walk_tile_lean<TW>(tP, tM, tE, mine, inb_same, inb_7, Rb, v, h, steps, nmatch, R);
+            if (grp != 0) {                                         // (uniform over the lanes of a group)
+                const int own = gl | (__ffs((int)grp) - 1);
+                v = __shfl(v, own); h = __shfl(h, own); steps = (u32)__shfl((int)steps, own); nmatch = __shfl(nmatch, own);
+                R.nruns = __shfl(R.nruns, own); R.cur_op = __shfl(R.cur_op, own); R.cur_len = __shfl(R.cur_len, own);
+            }
+            first_phase = false;
+        }
+        (void)first_phase;
+    }
+    if (!ok || j != 0) return;
+    R.nops = (int)steps; R.edits = (int)steps - nmatch;
+    R.push_n(OP_I, h + 1);
+    R.push_n(OP_D, v + 1);
+    R.flush();
+    A.o_nruns[t] = (R.nruns <= R.cap) ? R.nruns : -1;
+    A.o_nops[t] = R.nops;
+    A.o_edits[t] = R.edits;
+    A.o_steps[t] = steps;
+}
+
+template __global__ void k_traceback_sys<2>(TraceArgs);
+template __global__ void k_traceback_sys<3>(TraceArgs);
+template __global__ void k_traceback_sys<4>(TraceArgs);
 
 // In-window traceback over one recomputed 8-column tile of the window's last block row (W = 2, O = 1:
 // the walk stays in window rows 64..127 and columns 64..127, bpm_windowed.c:448-561).  vw / hw are window

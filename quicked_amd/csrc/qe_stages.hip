@@ -18,7 +18,8 @@ namespace qe {
 // slots the first one left empty, at no cost to either.
 // ---------------------------------------------------------------------------
 template <typename Kernel, typename Args>
-static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ngroups, int max_waves, size_t lds_per_wave, bool chain = false) {
+static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ngroups, int max_waves, size_t lds_per_wave, bool chain = false,
+                          size_t pin_override = 0) {
     if (ngroups == 0) return;
     const int wpb = std::min(4, max_waves);
     const unsigned blocks = (unsigned)((ngroups + wpb - 1) / wpb);
@@ -30,6 +31,7 @@ static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ng
     // waves of 1563 windows each).  108 KB: no 54 KB workgroup fits beside it, so its waves have their SIMDs to themselves
     // instead of sharing them with the fill of the run before (config 4: the stage took 59 ms beside that fill, 36 alone)
     if (chain && (size_t)blocks * (size_t)std::max(1, C.in_flight) <= 128) pin = (size_t)108 * 1024;
+    if (pin_override) pin = pin_override;
     const size_t lds = std::max(pin, lds_per_wave * (size_t)wpb);
     static thread_local std::vector<std::pair<const void*, int>> configured;      // per host thread and device
     const void* fn = reinterpret_cast<const void*>(kernel);
@@ -471,7 +473,10 @@ static bool wave_formatter_wanted(const quicked_batch& B, const SegList& SL, boo
     size_t pool_bytes = 0;
     if (want_strings) for (size_t b : SL.bound) pool_bytes += b;
     const int wave_env = env_int("QE_FORMAT_WAVE", -1);      // tests force either form
-    return B.cigar_style != 2 && nr > 0 && (wave_env >= 0 ? wave_env != 0 : (nr <= 32768 && nseg > 0 && pool_bytes / nr >= 16384));
+    // ... and a launch so small that every alignment's wave is resident at once (a single pair, a few hundred): one lane's
+    // chain over ~1 000 runs is 0.75 ms there, a wave's a tenth of it
+    const bool few = nr <= 2048 && nseg > 0 && pool_bytes / nr >= 2048;
+    return B.cigar_style != 2 && nr > 0 && (wave_env >= 0 ? wave_env != 0 : (few || (nr <= 32768 && nseg > 0 && pool_bytes / nr >= 16384)));
 }
 
 static AlignOut format_segments(const quicked_batch& B, Context& C, const SegList& SL, const u32* runs, const int64_t* g_runs_off,
@@ -911,11 +916,14 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         // tight bands (QuickEd's bound, exact child distances) in a launch of few waves: sixteen lanes per leaf, the band's
         // rows as a systolic array (k_banded_sys); what it flags -- N, a band of more than 15 slots -- stays with the
         // one-lane kernel.  QE_FILL_SYS = 0 / 1: never / wherever the bound is tight (tests)
+        // the cooperative kernels need few registers and no LDS: four workgroups per CU (40 KB each), so that a launch of up
+        // to 4 096 waves is resident at once instead of running in two rounds of 2 048 (12.5 k leaves x 16 lanes = 3 125 waves)
+        const size_t sys_pin = (size_t)40 * 1024;
         const int sys = env_int("QE_FILL_SYS", -1);
         if (Gfill < 2 && a.only_if == nullptr && tight_runs && hew_init.empty() &&
             (sys == 1 || (sys != 0 && (size_t)(g1 - g0) * 16 * (size_t)std::max(1, fetch ? 1 : C.in_flight) <= 4096))) {
             a.o_abort = O.hew + o;
-            launch_groups(C, k_banded_sys, a, (size_t)(g1 - g0) * 16, 4, 0);
+            launch_groups(C, k_banded_sys, a, (size_t)(g1 - g0) * 16, 4, 0, false, sys_pin);
             a.only_if = O.hew + o;
         }
         a.fill_multi = env_int("QE_FILL_MULTI", 1);
@@ -929,6 +937,23 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         tr.runs = d_runs; tr.g_runs_off = d_runs_off + g0; tr.g_runs_cap = d_runs_cap + g0;
         tr.o_nruns = O.nruns + o; tr.o_nops = O.nops + o; tr.o_edits = O.edits + o; tr.o_steps = O.steps + o;
         tr.runs_by_task = wave_fmt ? 1 : 0;
+        // a launch of few waves: sixteen lanes per leaf rebuild the tiles along the path's diagonal together and hand the
+        // walk from tile to tile (k_traceback_sys); what it flags (N, non-canonical symbols) stays with the one-lane kernel.
+        // QE_TRACE_SYS = 0 / 1: never / always (tests)
+        // lanes per leaf: 16 while the launch stays under ~one wave per SIMD, 8 / 4 up to ~1 600 waves (12.5 k / 25 k leaves)
+        const int tsys = env_int("QE_TRACE_SYS", -1);
+        const size_t gw = (size_t)(g1 - g0) * (size_t)std::max(1, fetch ? 1 : C.in_flight);      // one-lane waves in flight
+        int tlg = 0;
+        if (tsys > 1) tlg = tsys == 4 ? 2 : (tsys == 8 ? 3 : 4);
+        else if (tsys != 0) tlg = (gw * 16 <= 1100 || tsys == 1) ? 4 : (gw * 8 <= 1700 ? 3 : (gw * 4 <= 1700 ? 2 : 0));
+        if (tlg) {
+            tr.o_abort = C.scratch_p->take<int32_t>((size_t)(g1 - g0) * 64);
+            const size_t nwv = (size_t)(g1 - g0) << tlg;
+            if (tlg == 4) launch_groups(C, k_traceback_sys<4>, tr, nwv, 4, 0, false, sys_pin);
+            else if (tlg == 3) launch_groups(C, k_traceback_sys<3>, tr, nwv, 4, 0, false, sys_pin);
+            else launch_groups(C, k_traceback_sys<2>, tr, nwv, 4, 0, false, sys_pin);
+            tr.only_if = tr.o_abort;
+        }
         launch_groups(C, k_traceback, tr, (size_t)(g1 - g0), 8, 0);
         // the next sub-batch reuses this scratch: its kernels are behind this sub-batch's in the stream, no host wait
         if (sb + 2 < sub_start.size()) C.scratch_p->release(mark);

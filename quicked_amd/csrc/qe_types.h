@@ -122,6 +122,8 @@ struct TraceArgs {
     int32_t* o_nruns;  int32_t* o_nops;  int32_t* o_edits;  u32* o_steps;
     int32_t runs_by_task;    // != 0: task (g, lane) has the stretch [lane * cap, (lane + 1) * cap) of its group's buffer to itself
                              // (the wave-per-alignment formatter reads it sequentially; [idx][lane] rows cost it a 256-byte row per run)
+    const int32_t* only_if = nullptr;   // k_traceback: walk only tasks whose flag is non-zero (what k_traceback_sys left)
+    int32_t* o_abort = nullptr;         // k_traceback_sys: 1 where a task is left to k_traceback (N / non-canonical symbols)
 };
 
 // WindowEd chain (bpm_windowed.c:563-628)

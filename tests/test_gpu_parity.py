@@ -477,6 +477,67 @@ def test_fill_systolic_forced(sys_, golden, monkeypatch):
     assert cnt[3] == sum(x["traceback_steps"] for x in tr)
 
 
+@pytest.mark.parametrize("tsys", ["1", "8", "4", "0"])
+def test_traceback_systolic_forced(tsys, golden, monkeypatch):
+    """the BandEd traceback with sixteen lanes per leaf (k_traceback_sys: the tiles along the path's diagonal rebuilt
+    together, the walk handed from tile to tile; QE_TRACE_SYS = 1) against one lane per leaf (0): CIGAR bytes of the
+    goldens, the oracle on tight QuickEd bands, loose BandEd / Hirschberg bands (a user bandwidth), ragged / N / lower-case
+    input (flagged leaves fall back), pairs with large indels (long runs that leave the predicted tiles), forced deep
+    splits, and the traceback's step counter."""
+    monkeypatch.setenv("QE_TRACE_SYS", tsys)
+    for name in ("cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len63", "len64", "len65", "len128", "len130", "len1024", "err35_2kb"):
+        entry = golden["datasets"][name]
+        batch = datagen.generate(**entry["gen"])
+        for label, run in entry["runs"].items():
+            if "cigar_sha256" not in run or run["params"].get("algo") == 1:
+                continue
+            scores, status, cig, _ = gpu_batch(batch, **run["params"])
+            assert status.tolist() == run["status"], (name, label)
+            assert scores.tolist() == run["score"], (name, label)
+            assert [sha(c) for c in cig] == run["cigar_sha256"], (name, label)
+    rng = np.random.default_rng(23)
+    pairs = mixed_batch()
+    for i in range(72):
+        L = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 200, 1000, 2500, 6000]))
+        e = float(rng.choice([0.0, 0.01, 0.05, 0.2]))
+        b = datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=2300 + i,
+                             indels_num=int(rng.integers(0, 3)) if L >= 2500 else 0, indels_len=int(rng.choice([40, 150, 400])))
+        p, t = next(b.pairs())
+        if rng.random() < 0.25:
+            t = t[: max(1, len(t) - int(rng.integers(0, max(1, len(t) // 4))))]
+        pairs.append((p, t))
+    for kw in (dict(algo=0), dict(algo=2, bandwidth=30), dict(algo=3, bandwidth=30), dict(algo=2, bandwidth=60)):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            want = O.oracle_align(p, t, **kw)
+            in_domain = kw["algo"] == 0 or len(p) == 0 or len(t) == 0 or \
+                O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+            if in_domain:
+                assert out[i] == want, (tsys, kw, i, len(p), len(t))
+    import ctypes as C
+    monkeypatch.setenv("QE_SPLIT_BYTES", str(1 << 15))
+    lib = O.oracle()
+    batch = datagen.generate(count=70, length=3000, error=0.08, seed=2401)
+    scores, status, cig, _ = gpu_batch(batch, algo=0)
+    for i, (p, t) in enumerate(batch.pairs()):
+        st, sc, cg, tr = O.oracle_align(p, t, trace=True, algo=0)
+        ops = C.create_string_buffer(len(p) + len(t) + 1)
+        nn = C.c_int64()
+        lib.qo_hirschberg(p, len(p), t, len(t), tr["bound"], 1 << 15, ops, C.byref(nn), None)
+        buf = C.create_string_buffer(2 * nn.value + 16)
+        lib.qo_cigar_rle(ops, nn.value, buf)
+        assert scores[i] == sc and cig[i] == buf.value.decode(), (tsys, i)
+    monkeypatch.delenv("QE_SPLIT_BYTES")
+    b = datagen.generate(96, 3000, 0.05, seed=24, indels_num=1, indels_len=100)
+    _, _, _, cnt = gpu_batch(b, algo=0)
+    tr = [O.oracle_align(p, t, trace=True, algo=0)[3] for p, t in b.pairs()]
+    assert cnt[3] == sum(x["traceback_steps"] for x in tr)
+    assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
+
+
 @pytest.mark.parametrize("tall", ["1", "0"])
 def test_tall_band_cooperative_fill(tall, monkeypatch):
     """QuickEd's align step on pairs with LARGE bounds (large indels: bands of 30-50 slots) in a launch of few waves: the
