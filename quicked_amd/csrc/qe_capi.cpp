@@ -200,6 +200,7 @@ QE_API quicked_status_t quicked_batch_sync(quicked_batch_t* batch) {
         tl_device = B->device;
         Context& C = ctx();
         C.sync_all();
+        batch_quiesce(B);                      // runs of this batch queued by OTHER threads are over too
         B->pending = false;
         return QUICKED_OK;
     }, nullptr);

@@ -1020,6 +1020,14 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
         }
     }
     (void)hipGetLastError();
+    // the job's own batch first, THEN a context -- the order every API call takes them in (guard(): fin_mu, then the context's
+    // busy mutex).  A finisher that held a context while it waited here for a caller's long call on this batch kept its pools
+    // out of that caller's reach (reclaim level 3 skips busy contexts) and counted as at work in the book
+    std::unique_lock<std::mutex> lk0(B0.fin_mu);
+    if (B0.pending_fetch.get() != job.pf.get() && group.size() == 1) {
+        if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p already fetched / superseded\n", (void*)&B0);
+        return;
+    }
     ApiScope scope;
     tl_device = B0.device;
     Context& C = ctx();
@@ -1030,7 +1038,7 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
         quicked_batch& B = *group[x].B;
         PendingFetch& F = *static_cast<PendingFetch*>(group[x].pf.get());
         std::unique_lock<std::mutex> lk(B.fin_mu, std::defer_lock);
-        if (x == 0) lk.lock(); else if (!lk.try_lock()) continue;
+        if (x == 0) lk = std::move(lk0); else if (!lk.try_lock()) continue;
         if (B.pending_fetch.get() != group[x].pf.get()) { if (trace_on()) fprintf(stderr, "[qe] early finish: batch %p already fetched / superseded\n", (void*)&B); continue; }
         std::vector<int32_t> skip;
         d2h(skip, F.d_skip, F.L.pair.size(), C.stream);
@@ -1081,9 +1089,10 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
             }
         }
     }
-    catch (const HipError&) {
-        // e.g. out of memory next to the other threads' pools: nothing is lost -- the runs' results are still in the batches'
-        // result arenas, and the callers' fetches do the same work in their own contexts
+    catch (...) {
+        // e.g. out of memory next to the other threads' pools (a HipError), or std::bad_alloc in one of the host vectors:
+        // nothing is lost -- the runs' results are still in the batches' result arenas, and the callers' fetches do the same
+        // work in their own contexts
         (void)hipGetLastError();
         for (std::vector<MergeItem>* set : {&items, &left}) for (MergeItem& it : *set) {      // (an entry moved from one to the other owns no lock)
             if (!it.B || !it.lk.owns_lock() || it.B->shadow_ready) continue;
@@ -1129,10 +1138,10 @@ static void finisher_main(int index) {
         if (g_fin_stop.load()) continue;             // exiting: the batch objects may be gone
         taken.push_back(job);
         for (const FinishJob& j : taken) {
-            {
-                std::lock_guard<std::mutex> lk(j.B->fin_mu);
-                --j.B->fin_jobs;
-            }
+            // notified under the lock: quicked_batch_destroy, which waits for fin_jobs == 0 under fin_mu, must not be able to
+            // delete the batch between the decrement and the notify (its condition variable with it)
+            std::lock_guard<std::mutex> lk(j.B->fin_mu);
+            --j.B->fin_jobs;
             j.B->fin_cv.notify_all();
         }
     }

@@ -159,17 +159,98 @@ def test_counters_match_oracle_work():
     assert cnt[3] == sum(x["traceback_steps"] for x in tr)
 
 
-def test_hirschberg_split_100kb_golden(golden):
-    """configs[3] shape: 100 kb / 10 % pairs go through two Hirschberg split levels (bpm_hirschberg.c:63-243)"""
-    entry = golden["datasets"]["cfg4_100kb_10pct"]
+@pytest.mark.parametrize("name", ["cfg4_100kb_10pct", "cfg4_indel_100kb"])
+def test_hirschberg_split_100kb_golden(golden, name):
+    """configs[3] shape: 100 kb / 10 % pairs go through two Hirschberg split levels (bpm_hirschberg.c:63-243); six
+    ordinary pairs and two with 3 x 2 kb indels (stages 2 / 3 before the split), bytes of the compiled reference"""
+    entry = golden["datasets"][name]
     batch = datagen.generate(**entry["gen"])
-    for label in ("quicked", "hirschberg_bw15", "banded_so_bw15"):
+    for label in ("quicked", "hirschberg_bw15", "banded_so_bw15", "windowed_so_2_1_sse", "windowed_so_2_1_scalar"):
         run = entry["runs"][label]
         scores, status, cig, cnt = gpu_batch(batch, **run["params"])
         assert status.tolist() == run["status"], label
         assert scores.tolist() == run["score"], label
         if "cigar_sha256" in run:
             assert [sha(c) for c in cig] == run["cigar_sha256"], label
+
+
+def test_ont_real_data_fixture_on_the_gpu(golden):
+    """the reference's one real-data test (tests/CMakeLists.txt:32, tests/test_data/ONT.MiniION.1.seq: 508 596 x 505 792
+    bases, ~7.4 % error, all QuickEd stages + Hirschberg) through quicked_new / quicked_align / quicked_free: status, score
+    39 743 (edlib-confirmed) and the CIGAR bytes of the compiled reference (length + SHA-256 in golden.json)"""
+    import ctypes as C
+    import os
+    g = golden["ont_miniion_1"]
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ont_miniion_1.seq"), "rb") as f:
+        l1, l2 = f.read().split(b"\n")[:2]
+    pat, txt = (l1[1:], l2[1:]) if l1[:1] == b">" else (l2[1:], l1[1:])
+    assert (len(pat), len(txt)) == (g["plen"], g["tlen"])
+    lib = capi.lib()
+    p = capi.make_params(algo=0)
+    a = capi.Aligner()
+    assert lib.quicked_new(C.byref(a), C.byref(p)) == capi.QUICKED_WIP
+    st = lib.quicked_align(C.byref(a), pat, len(pat), txt, len(txt))
+    cg = a.cigar.decode() if a.cigar else None
+    score = a.score
+    lib.quicked_free(C.byref(a))
+    assert (st, score) == (g["status"], g["score"]) and score == 39743
+    assert cg is not None and len(cg) == g["cigar_len"] and sha(cg) == g["cigar_sha256"]
+
+
+def test_reference_crash_fuzz_at_its_own_scale():
+    """tests/CMakeLists.txt:15-21 + tests/random_test.sh:47-59: 10 000 pairs of 1 kb and 1 000 pairs of 10 kb with TEN edits
+    each (generate_dataset's -e 10 is a count) through quicked_new / quicked_align / quicked_free PER PAIR, default
+    parameters (QuickEd + CIGAR).  The reference's criterion is 'no crash'; here every status and score is checked
+    (score <= 10: ten edits; == the oracle's on a stride) and every CIGAR's edit count is its score."""
+    import ctypes as C
+    import re
+    lib = capi.lib()
+    p = capi.make_params(algo=0)
+    for count, length, stride in ((10000, 1000, 97), (1000, 10000, 53)):
+        batch = datagen.generate(count, length, 10, seed=4242 + length)       # error >= 1: a number of edits
+        for i, (pat, txt) in enumerate(batch.pairs()):
+            a = capi.Aligner()
+            assert lib.quicked_new(C.byref(a), C.byref(p)) == capi.QUICKED_WIP
+            st = lib.quicked_align(C.byref(a), pat, len(pat), txt, len(txt))
+            score, cg = a.score, (a.cigar.decode() if a.cigar else None)
+            lib.quicked_free(C.byref(a))
+            assert st == capi.QUICKED_WIP and 0 <= score <= 10 and cg is not None, (length, i, st, score)
+            if i % stride == 0:
+                assert (st, score, cg) == O.oracle_align(pat, txt, algo=0), (length, i)
+                assert sum(int(n) for n, op in re.findall(r"(\d+)([MXID])", cg) if op != "M") == score
+
+
+def test_configs_2_and_3_at_full_size():
+    """BASELINE configs[1] / [2] at their own size: 100 k pairs of 10 kb at 5 %.  BandEd score-only (bandwidth 15) and
+    QuickEd + CIGAR on the same pairs: the two exact distances agree on all 100 k pairs, every CIGAR passes the device-side
+    validator (cigar_check_alignment, cigar.c:363-434) and carries its score as edit count, a strided sample equals the
+    oracle's bytes -- and the compiled reference's where oracle/_ref exists (the build container)."""
+    N = 100000
+    whole = datagen.generate(N, 10000, 0.05, seed=0x51CED)
+    rb = capi.ResidentBatch(whole)
+    try:
+        assert rb.run(capi.make_params(algo=2, only_score=True, bandwidth=15), sync=True) == capi.QUICKED_WIP
+        s_b, st_b = rb.scores()
+        s_b = s_b.copy()
+        assert (st_b == capi.QUICKED_WIP).all()
+        rb.configure(check=True)
+        assert rb.run(capi.make_params(algo=0), sync=True) == capi.QUICKED_WIP
+        s_q, st_q = rb.scores()
+        assert (st_q == capi.QUICKED_WIP).all() and (s_q == s_b).all()
+        assert 440 < int(s_q.min()) and int(s_q.max()) < 520                 # SURVEY 8(d): 460-493 on this generator
+        assert bool(rb.check_results().all())
+        cig = rb.cigars()
+    finally:
+        rb.close()
+    pairs = whole.pairs()
+    for i, (p, t) in enumerate(pairs):
+        if i % 1999:
+            continue
+        want = O.oracle_align(p, t, algo=0)
+        assert (capi.QUICKED_WIP, int(s_q[i]), cig[i]) == want, i
+        assert O.oracle_align(p, t, algo=2, only_score=True, bandwidth=15)[1] == s_b[i], i
+        if O.have_ref():
+            assert O.ref_align(p, t, algo=0) == want, i
 
 
 def test_hirschberg_forced_deep_splits(monkeypatch):
@@ -244,7 +325,8 @@ def test_align_benchmark_worker_threads_write_the_same_file(tmp_path):
         for p, t in pairs:
             f.write(b">" + p + b"\n<" + t + b"\n")
     outs, sums = {}, {}
-    for tag, extra in (("t1", []), ("t2", ["-t", "2"]), ("t3", ["-t", "3", "--batch-size", "100"]), ("t4", ["-t", "4", "--devices", "1"])):
+    for tag, extra in (("t1", []), ("t2", ["-t", "2"]), ("t3", ["-t", "3", "--batch-size", "100"]), ("t4", ["-t", "4", "--devices", "1"]),
+                       ("t8", ["-t", "8", "--devices", "1", "--batch-size", "48"])):      # config 5's worker count on the one device
         out = tmp_path / f"{tag}.out"
         r = subprocess.run([exe, "-a", "quicked", "-i", str(seq), "-o", str(out), "-c", "correct", "--batch-size", "128"] + extra,
                            capture_output=True, text=True, timeout=600)
@@ -259,7 +341,7 @@ def test_align_benchmark_worker_threads_write_the_same_file(tmp_path):
         st, sc, cg = O.oracle_align(*pairs[i], algo=0)
         assert lines[i] == f"{sc}\t{cg}", i
     assert lines[len(pairs) - 2] == "-\t-"
-    for tag in ("t2", "t3", "t4"):
+    for tag in ("t2", "t3", "t4", "t8"):
         assert outs[tag] == outs["t1"], tag
         assert sums[tag] == sums["t1"], (tag, sums)
 
@@ -1310,3 +1392,33 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     assert two["strong"]["total_pairs"] == n and two["strong"]["pairs_per_gpu"] == n // 2 and two["strong"]["value"] > 0
     assert two["e2e"]["2bit_pinned"]["value"] > 0 and two["e2e"]["ascii_pinned"]["value"] > 0
     assert "cpu_baseline" not in two
+
+
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """configs[4]'s launch shape without the hardware: EIGHT ranks started exactly as the driver starts them
+    (torch.distributed.run --nproc-per-node 8), all on this box's one GPU (the gloo / shared-device test hooks).  Every rank
+    must show up in the final reduce (ranks_seen == 8), the 8 shards of 125 pairs must add up to the 1-rank run over the
+    same 1 000 pairs (checksum), the strong leg must split them 8 ways, and every rank must keep >= 1 host-pack thread of
+    the node's CPUs for its ASCII leg."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 125
+    common = ["--steps", "2", "--warmup", "1", "--length", "2000", "--no-cpu-baseline", "--no-workloads", "--e2e-batches", "2"]
+    env = dict(os.environ, QE_BENCH_SHARE_GPU="1", QE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                         "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "8", "--pairs", str(n)] + common,
+                        capture_output=True, text=True, env=env, timeout=1500)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    eight = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][-1])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--pairs", str(8 * n), "--no-e2e"] + common,
+                        capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert eight["n_gpus"] == 8 and eight["ranks_seen"] == 8 and eight["scaling"] == "weak" and eight["value"] > 0
+    assert eight["score_checksum"] == one["score_checksum"]                     # shard-of-8 == whole
+    assert eight["strong"]["total_pairs"] == n and eight["strong"]["value"] > 0
+    assert eight["e2e"]["ascii_hostpacked"]["host_pack_threads_per_uploader"] >= 1
+    assert eight["e2e"]["ascii_hostpacked"]["value"] > 0

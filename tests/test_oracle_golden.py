@@ -30,7 +30,7 @@ def test_status_messages():
 
 
 DATASETS = ["cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len50", "len63", "len64", "len65", "len128",
-            "len130", "len1024", "err35_2kb", "cfg4_100kb_10pct"]
+            "len130", "len1024", "err35_2kb", "cfg4_100kb_10pct", "cfg4_indel_100kb"]
 
 
 @pytest.mark.parametrize("name", DATASETS)

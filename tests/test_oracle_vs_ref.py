@@ -75,13 +75,12 @@ def test_sam_cigar_restatement_matches_the_reference_printer():
             assert buf.value.decode() == O.ref_sam_cigar(ops, show), (ops[:40], show)
 
 
-ONT_FILE = "/root/reference/tests/test_data/ONT.MiniION.1.seq"
+ONT_FILE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "ont_miniion_1.seq")
 
 
-@pytest.mark.skipif(not __import__("os").path.exists(ONT_FILE), reason="the reference's real-data fixture is not on this machine")
 def test_ont_miniion_real_data_fixture(golden):
-    """the reference's one real-data test (tests/CMakeLists.txt:32): 508 596 x 505 792 bases.  The file itself is
-    reference data and stays out of this repository; golden.json holds hashes and the compiled reference's result."""
+    """the reference's one real-data test (tests/CMakeLists.txt:32): 508 596 x 505 792 bases, kept as a data fixture
+    (tests/golden/ont_miniion_1.seq); golden.json holds its hashes and the compiled reference's result."""
     import hashlib
     g = golden["ont_miniion_1"]
     with open(ONT_FILE, "rb") as f:
