@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(256) void k_banded_wave(BandedArgs A) {
 }
 
 // ===========================================================================
-// BandEd fill for TIGHT bands, SIXTEEN LANES PER ALIGNMENT (k_banded_sys): the cooperative form of k_banded<true> for
+// BandEd with SIXTEEN (or 64) LANES PER ALIGNMENT (k_banded_sys): the cooperative form of k_banded<true> / <false> for
 // launches of few waves (one batch of a few thousand QuickEd pairs, a single pair), where one lane's serial chain over
 // the 6-10 slots of a band pruned to QuickEd's bound is what the launch lasts (bpm_banded.c:199-316).
 // Lane j of a 16-lane group owns the block row r with r mod 16 = j that lies in the band (a band of <= 15 slots has at
@@ -2001,55 +2001,71 @@ __global__ __launch_bounds__(256) void k_banded_wave(BandedArgs A) {
 // registers when a row passes them, stored at four fixed steps of the chunk; carry-in words per (chunk, slot); band
 // edges per chunk), so k_traceback runs unchanged.  Tasks with N or a taller band are flagged (o_abort) for k_banded<true>.
 // ===========================================================================
-__device__ __forceinline__ u32 row_ror1(u32 x) {            // lane 16 g + j <- lane 16 g + (j + 15) % 16
-    return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x121, 0xf, 0xf, false);
+template <int LG>
+__device__ __forceinline__ u32 grp_ror1(u32 x) {            // lane G g + j <- lane G g + (j + G - 1) % G;  G = 16: row_ror:1, G = 64: wave_ror:1
+    return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, LG == 4 ? 0x121 : 0x13C, 0xf, 0xf, false);
 }
 template <int N>
 __device__ __forceinline__ int row_ror_n(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xf, 0xf, false); }
 
+// LG = 4: sixteen lanes per task, four tasks per wave (bands of <= 15 slots: QuickEd's tight bounds); LG = 6: one task per
+// wave (bands of <= 63 slots: the bounds of pairs with large indels, a user bandwidth).  FILL = false is the score-only
+// pass (bpm_banded.c:791-964: its own narrower band and stop rule) for whole texts -- QuickEd's stage-3 doubling rounds, a
+// BandEd score-only call on few pairs; a pass that stops early (a Hirschberg half pass exports its band) is flagged.
+template <int LG, bool FILL>
 __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
-    const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & 15, gl = lane & ~15;
-    const int t = wv * 4 + (lane >> 4);
-    if (wv * 4 >= A.T.ntasks) return;
-    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    constexpr int GL = 1 << LG, NT = 64 >> LG, GM = GL - 1;
+    const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & GM, gl = lane & ~GM;
+    const int t = wv * NT + (lane >> LG);
+    if (wv * NT >= A.T.ntasks) return;
+    int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    if (A.only_if != nullptr && pair >= 0 && A.only_if[t] == 0) pair = -1;
     const bool valid = pair >= 0;
-    int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0;
+    int m = 1, n = 1, p0 = 0, t0 = 0, cut_in = 0, tfin = 1;
     const u64* pp = A.P.pl_p;
     const u64* tp = A.P.pl_t;
     u32 fl = 0;
     if (valid) {
         m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
         cut_in = A.T.cutoff[t];
+        tfin = FILL ? n : A.T.tfin[t];
         pp = A.P.pl_p + A.P.pl_p_off[pair];
         tp = A.P.pl_t + A.P.pl_t_off[pair];
         fl = A.P.flags[pair];
     }
     const Geom G = band_geometry(m, n, cut_in);
     const int nw = (m + 63) >> 6;
-    const int nsl = G.ebb;
-    const bool ok = valid && (fl & FLAG_HAS_N) == 0 && nsl <= 15;
+    const int nsl = FILL ? G.ebb : ((G.cutoff + 63) >> 6) + 1;    // the score-only kernels' own band (bpm_banded.c:801-803)
+    const bool ok = valid && (fl & FLAG_HAS_N) == 0 && nsl <= GM && tfin == n;
     if (valid && j == 0) A.o_abort[t] = ok ? 0 : 1;
     if (!__any(ok)) return;
-    const int stop_row = nw - 1;                                   // bpm_banded.c:295
+    const int stop_row = FILL ? nw - 1 : nw;                       // bpm_banded.c:295 / 917
     const u64 lvl_mask = (m & 63) ? (((u64)1 << (m & 63)) - 1) : QE_ONES;     // rows of the last block up to the pattern's end
     int first = G.prolog, last = nsl - 1, pos_v = -G.prolog, pos_h = 0;
     int max_row_init = nsl - 1;
     u32 adv = 0;
 
     const int g = ok ? (t >> 6) : 0, col = t & 63;
-    const int gns = A.g_nslots[g], gnr = A.g_nrows[g], gnch = A.g_nch[g];
-    const GroupWs W = group_ws(A.ws, A.g_ws_off[g], gns, gnr, gnch);
-    uint4* const cp = A.mat + A.g_mat_off[g] + col;
-    const int64_t cps = (int64_t)gns * 64;
-    uint4* const hw = cp + (int64_t)QE_CPC * gnch * cps;
+    int gns = 0, gnch = 0;
+    int16_t* cf = nullptr; int16_t* cl = nullptr;
+    uint4* cp = nullptr; uint4* hw = nullptr;
+    int64_t cps = 0;
+    if (FILL) {
+        gns = A.g_nslots[g]; gnch = A.g_nch[g];
+        const GroupWs W = group_ws(A.ws, A.g_ws_off[g], gns, A.g_nrows[g], gnch);
+        cf = W.cf + col; cl = W.cl + col;
+        cp = A.mat + A.g_mat_off[g] + col;
+        cps = (int64_t)gns * 64;
+        hw = cp + (int64_t)QE_CPC * gnch * cps;
+    }
 
     // bpm_reset_search (bpm_banded.c:180-197): lane j holds row j
     u32 Plo = ~0u, Phi = ~0u, Mlo = 0, Mhi = 0;
     int sc = 64 * (j + 1);
     u64 pa = 0, pb = 0;                                            // pattern planes of this lane's row
     if (ok) {
-        if (j < nsl) cp[(int64_t)j * 64] = make_uint4(~0u, ~0u, 0u, 0u);
-        if (j == 0) { W.cf[col] = (int16_t)first; W.cl[col] = (int16_t)last; }
+        if (FILL && j < nsl) cp[(int64_t)j * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+        if (FILL && j == 0) { cf[0] = (int16_t)first; cl[0] = (int16_t)last; }
         if (j < nw) load_planes_ab(pp, p0 + 64 * j, pa, pb);
     }
     const int nfull = n >> 6, tail = n & 63;
@@ -2066,38 +2082,39 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
         if (ok && k + 1 < my_chunks) load_planes_ab(tp, t0 + 64 * (k + 1), nT0, nT1);
         const int r_first = first + pos_v;
         const int rhi = min(last, nw - 1 - pos_v);                 // rows >= nw are never computed (A.7(2))
-        const int i = (j - r_first) & 15;                          // this lane's row of the band, counted from its top
+        const int i = (j - r_first) & GM;                          // this lane's row of the band, counted from its top
         const int si = first + i;                                  // its slot
         const bool inband = on && si <= rhi;
         const int my_row = r_first + i;
         // the row the bookkeeping will create at this chunk's end: its lane loads its planes now
         u64 qa = 0, qb = 0;
         const int new_row = last + pos_v + 1;
-        if (on && ncols == 64 && ((new_row & 15) == j) && new_row < nw) load_planes_ab(pp, p0 + 64 * new_row, qa, qb);
+        if (on && ncols == 64 && ((new_row & GM) == j) && new_row < nw) load_planes_ab(pp, p0 + 64 * new_row, qa, qb);
         const int Hm = __builtin_amdgcn_readfirstlane(wave_max(on ? rhi - first + 1 : 0));
         // bit s of these is the text's column s - i (mod 64)
-        const u64 R0 = i ? ((T0 << i) | (T0 >> (64 - i))) : T0, R1 = i ? ((T1 << i) | (T1 >> (64 - i))) : T1;
+        const int ri = i & 63;
+        const u64 R0 = ri ? ((T0 << ri) | (T0 >> (64 - ri))) : T0, R1 = ri ? ((T1 << ri) | (T1 >> (64 - ri))) : T1;
         const u64 vm = (my_row == nw - 1) ? lvl_mask : QE_ONES;
         const int Vb = __popcll(mk64(Plo, Phi) & vm) - __popcll(mk64(Mlo, Mhi) & vm);
         const u32 alo = lo32(pa), ahi = hi32(pa), blo = lo32(pb), bhi = hi32(pb);
-        u64 gP = 0, gM = 0;                                        // carry-ins of this row, column c at bit 63 - c ... shifted in from the right
+        u64 gP = 0, gM = 0;                                        // carry-ins of this row, shifted in from the right
         u32 oP = 0, oM = 0;
-        if (i == 15) { oP = 1u; oM = 0u; }                         // the lane above the top row: PHin = 1 into the band (bpm_banded.c:238)
-        u32 cPlo = Plo, cPhi = Phi, cMlo = Mlo, cMhi = Mhi;        // the checkpoint this row passed last
+        if (i == GM) { oP = 1u; oM = 0u; }                         // the lane above the top row: PHin = 1 into the band (bpm_banded.c:238)
+        u32 cPlo = Plo, cPhi = Phi, cMlo = Mlo, cMhi = Mhi;        // G = 16: the checkpoint this row passed last
         const u32 len = inband ? (u32)ncols : 0u;
         const int nsteps = 64 + Hm - 1;
         // where this row's checkpoints go: q = 1 .. 3 in this chunk's slot numbering, q = 4 = the next chunk's checkpoint 0
         // one slot up (the band shift, bpm_banded.c:279-287; slot -1 does not exist and is never read)
-        uint4* const cpk = cp + (int64_t)(QE_CPC * k) * cps + (int64_t)si * 64;
+        uint4* const cpk = FILL ? cp + (int64_t)(QE_CPC * k) * cps + (int64_t)si * 64 : nullptr;
 #pragma unroll 1
-        for (int blk = 0; blk < 3; ++blk) {
+        for (int blk = 0; blk < (LG == 4 ? 3 : 4); ++blk) {
             if (32 * blk >= nsteps) break;
-            const u32 w0 = (blk == 1) ? hi32(R0) : lo32(R0), w1 = (blk == 1) ? hi32(R1) : lo32(R1);
+            const u32 w0 = (blk & 1) ? hi32(R0) : lo32(R0), w1 = (blk & 1) ? hi32(R1) : lo32(R1);
 #pragma unroll
             for (int sb = 0; sb < 32; ++sb) {
                 const int s = 32 * blk + sb;
                 if (s >= nsteps) continue;                         // (uniform; a break would keep the loop rolled)
-                const u32 inP = row_ror1(oP), inM = row_ror1(oM);
+                const u32 inP = grp_ror1<LG>(oP), inM = grp_ror1<LG>(oM);
                 const u32 c = (u32)(s - i);
                 if (c < len) {
                     const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)w0, sb, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)w1, sb, 1);
@@ -2105,23 +2122,32 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
                     u32 phhi, mhhi;
                     block_step_core(elo, ehi, Plo, Phi, Mlo, Mhi, inP, inM, phhi, mhhi);
                     oP = phhi >> 31; oM = mhhi >> 31;
-                    gP = shl1_add_u64(gP, (u64)inP); gM = shl1_add_u64(gM, (u64)inM);
-                    const bool cap = (c & (QE_CP_COLS - 1)) == QE_CP_COLS - 1;
-                    cPlo = cap ? Plo : cPlo; cPhi = cap ? Phi : cPhi; cMlo = cap ? Mlo : cMlo; cMhi = cap ? Mhi : cMhi;
+                    if (FILL) {
+                        gP = shl1_add_u64(gP, (u64)inP); gM = shl1_add_u64(gM, (u64)inM);
+                        const bool cap = (c & (QE_CP_COLS - 1)) == QE_CP_COLS - 1;
+                        if (LG == 4) {
+                            cPlo = cap ? Plo : cPlo; cPhi = cap ? Phi : cPhi; cMlo = cap ? Mlo : cMlo; cMhi = cap ? Mhi : cMhi;
+                        } else if (cap && c != 63) {
+                            // a tall band's rows pass their checkpoints up to 62 steps apart: stored as they come
+                            cpk[(int64_t)((c >> 4) + 1) * cps] = make_uint4(Plo, Phi, Mlo, Mhi);
+                        }
+                    }
                 }
-                // every row of the band has passed column 16 q - 1 by step 16 q - 1 + 15 and none has passed 16 (q + 1) - 1
-                if ((s & 15) == 14 && s >= 30) {
+                // G = 16: every row of the band has passed column 16 q - 1 by step 16 q - 1 + 15 and none has passed 16 (q + 1) - 1
+                if (FILL && LG == 4 && (s & 15) == 14 && s >= 30) {
                     const int q = (s - 14) >> 4;                   // 1 .. 3
                     if (inband && 16 * q - 1 < ncols) cpk[(int64_t)q * cps] = make_uint4(cPlo, cPhi, cMlo, cMhi);
                 }
             }
         }
-        if (inband && ncols == 64 && si > 0) cpk[(int64_t)QE_CPC * cps - 64] = make_uint4(Plo, Phi, Mlo, Mhi);
+        if (FILL && inband && ncols == 64 && si > 0) cpk[(int64_t)QE_CPC * cps - 64] = make_uint4(Plo, Phi, Mlo, Mhi);
         if (inband) {
-            // carry-in words of (chunk, slot), bit c = column c
-            const int sh = 64 - ncols;
-            const u64 xP = __builtin_bitreverse64(sh ? (gP << sh) : gP), xM = __builtin_bitreverse64(sh ? (gM << sh) : gM);
-            hw[((int64_t)k * gns + si) * 64] = make_uint4(lo32(xP), hi32(xP), lo32(xM), hi32(xM));
+            if (FILL) {
+                // carry-in words of (chunk, slot), bit c = column c
+                const int sh = 64 - ncols;
+                const u64 xP = __builtin_bitreverse64(sh ? (gP << sh) : gP), xM = __builtin_bitreverse64(sh ? (gM << sh) : gM);
+                hw[((int64_t)k * gns + si) * 64] = make_uint4(lo32(xP), hi32(xP), lo32(xM), hi32(xM));
+            }
             adv += (u32)ncols;
         }
         // scores[] of the band's rows: carry-ins of the top row (ncols ones) plus the vertical-delta changes down to the row
@@ -2129,28 +2155,33 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
             const int Va = __popcll(mk64(Plo, Phi) & vm) - __popcll(mk64(Mlo, Mhi) & vm);
             int x = inband ? Va - Vb : 0;
             int y;
-            y = row_ror_n<1>(x); if (i >= 1) x += y;
-            y = row_ror_n<2>(x); if (i >= 2) x += y;
-            y = row_ror_n<4>(x); if (i >= 4) x += y;
-            y = row_ror_n<8>(x); if (i >= 8) x += y;
+            if (LG == 4) {
+                y = row_ror_n<1>(x); if (i >= 1) x += y;
+                y = row_ror_n<2>(x); if (i >= 2) x += y;
+                y = row_ror_n<4>(x); if (i >= 4) x += y;
+                y = row_ror_n<8>(x); if (i >= 8) x += y;
+            } else {
+#pragma unroll
+                for (int d = 1; d < GL; d <<= 1) { y = __shfl(x, gl | ((j - d) & GM)); if (i >= d) x += y; }
+            }
             if (inband) sc += ncols + x;
         }
         {
-            // every-64-columns bookkeeping (bpm_banded.c:264-301), the same for the 16 lanes of a group
-            const int s_top1 = __shfl(sc, gl | ((r_first + 1) & 15));
-            const int s_bot = __shfl(sc, gl | ((last + pos_v) & 15));
-            const int s_bot1 = __shfl(sc, gl | ((last + pos_v - 1) & 15));
+            // every-64-columns bookkeeping (bpm_banded.c:264-301 / 889-922), the same for all lanes of a group
+            const int s_top1 = __shfl(sc, gl | ((r_first + 1) & GM));
+            const int s_bot = __shfl(sc, gl | ((last + pos_v) & GM));
+            const int s_bot1 = __shfl(sc, gl | ((last + pos_v - 1) & GM));
             if (on && ncols == 64) {
                 const bool c1 = (first + 2 < last) && (G.fin > 64 * (first + 1));
                 const bool cut_lo = c1 && (s_top1 + (G.fin - 64 * (first + 1)) > G.cutoff);
                 if (cut_lo && pos_h >= G.prolog) first++;
                 else if (!cut_lo && pos_h < G.prolog) first--;
                 const int pos = last + pos_v;
-                if (((pos + 1) & 15) == j) {                       // the new bottom row is this lane's
+                if (((pos + 1) & GM) == j) {                       // the new bottom row is this lane's
                     Plo = ~0u; Phi = ~0u; Mlo = 0; Mhi = 0;
                     sc = s_bot + 64;
                     pa = qa; pb = qb;
-                    cp[(int64_t)(QE_CPC * k + QE_CPC) * cps + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+                    if (FILL) cp[(int64_t)(QE_CPC * k + QE_CPC) * cps + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
                 }
                 max_row_init = max(max_row_init, pos + 1);
                 const bool c2 = (first + 2 < last) && (64 * (last - 1) > G.fin);
@@ -2158,14 +2189,14 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
                 if (cut_hi || (pos_v + last >= stop_row)) last--;
                 pos_v++;
                 pos_h++;
-                if (j == 0) { W.cf[(int64_t)pos_h * 64 + col] = (int16_t)first; W.cl[(int64_t)pos_h * 64 + col] = (int16_t)last; }
+                if (FILL && j == 0) { cf[(int64_t)pos_h * 64] = (int16_t)first; cl[(int64_t)pos_h * 64] = (int16_t)last; }
             }
         }
     }
     // final score read-out (bpm_banded.c:952-961)
-    const int s_last = __shfl(sc, gl | ((nw - 1) & 15));
+    const int s_last = __shfl(sc, gl | ((nw - 1) & GM));
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) adv += __shfl_xor(adv, o);
+    for (int o = GL / 2; o > 0; o >>= 1) adv += __shfl_xor(adv, o);
     if (ok && j == 0) {
         int score = -1;
         if (nw - 1 <= max_row_init) {
@@ -2180,6 +2211,10 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
         A.o_adv[t] = adv;
     }
 }
+template __global__ void k_banded_sys<4, true>(BandedArgs);
+template __global__ void k_banded_sys<6, true>(BandedArgs);
+template __global__ void k_banded_sys<4, false>(BandedArgs);
+template __global__ void k_banded_sys<6, false>(BandedArgs);
 
 // ---------------------------------------------------------------------------
 // RLE emitter shared by the tracebacks: ops arrive back to front

@@ -445,14 +445,62 @@ static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskLi
     return S;
 }
 
+// k_banded_sys<.., false> over the list (16 lanes per task for bands of <= 15 slots, else a wave per task), then
+// k_banded<false> over the tasks it flagged (N, a taller band)
+static ScoreLaunch launch_banded_sys(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int lg, int timed) {
+    ScoreLaunch S;
+    S.nt = L.pair.size();
+    const BandLayout lay = band_layout(L, false, false);
+    S.T = upload_tasks(L, C);
+    S.D = upload_layout(lay, C);
+    S.O = take_out(C, S.nt);
+    BandedArgs a;
+    a.P = pair_view(B, reversed); a.T = S.T.v;
+    a.ws = S.D.ws; a.g_ws_off = S.D.ws_off; a.g_nslots = S.D.nslots; a.g_nrows = S.D.nrows; a.g_nch = S.D.nch;
+    a.mat = nullptr; a.g_mat_off = S.D.mat_off;
+    a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
+    a.o_maxrow = S.O.len;
+    a.only_if = nullptr; a.o_abort = S.O.hew;
+    a.lane_rel = env_int("QE_LANE_REL", 1);
+    auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;
+    if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
+    if (lg == 4) launch_groups(C, k_banded_sys<4, false>, a, S.nt / 4, 4, 0, false, (size_t)40 * 1024);
+    else launch_groups(C, k_banded_sys<6, false>, a, S.nt, 4, 0, false, (size_t)40 * 1024);
+    a.only_if = S.O.hew;
+    launch_groups(C, k_banded<false>, a, L.ngroups(), 8, 0);
+    if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
+    return S;
+}
+// whole-text passes on few tasks (QuickEd's stage-3 doubling rounds on the pairs a run left, a BandEd score-only call on one
+// pair or a few hundred): 0 = no, else log2 of the lanes per task.  QE_SCORE_SYS = 0 / 1: never / wherever eligible (tests)
+static int sys_score_lanes(const TaskList& L, int in_flight) {
+    const int env = env_int("QE_SCORE_SYS", -1);
+    if (env == 0) return 0;
+    size_t live = 0;
+    int max_nsl = 0;
+    for (size_t t = 0; t < L.pair.size(); ++t) {
+        if (L.pair[t] < 0) continue;
+        ++live;
+        if (L.tfin[t] != L.n[t]) return 0;                  // a stopped band is exported in k_banded's layout (Hirschberg half passes)
+        max_nsl = std::max(max_nsl, host_geometry(L.m[t], L.n[t], L.cutoff[t]).ebb_local);
+    }
+    if (live == 0 || max_nsl > 63) return 0;
+    const size_t nt = L.pair.size(), fl = (size_t)std::max(1, in_flight);
+    if (max_nsl <= 15) return (env == 1 || nt / 4 * fl <= 2048) ? 4 : 0;
+    return (env == 1 || nt * fl <= 1100) ? 6 : 0;
+}
+
 static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
                              bool fetch, int32_t** d_score_out, PendingFetch* pf = nullptr) {
     // one wavefront per alignment only where the cooperative on-chip form has no room (a band of fewer than 8 slots): with
     // G = 8 lanes per alignment and 4-slot passes that form does a 10 kb pair in 2.7 ms, the wave form in 4.3
-    const int G0 = coop_lanes(L, fetch ? 1 : C.in_flight);
-    const bool wave = wave_form_wanted(L) && (G0 < 2 || env_int("QE_WAVE", -1) == 1);
+    const bool forced = getenv("QE_COOP_G") != nullptr || env_int("QE_WAVE", -1) == 1;      // tests of the other forms
+    const int lg = forced ? 0 : sys_score_lanes(L, fetch ? 1 : C.in_flight);
+    const int G0 = lg ? 1 : coop_lanes(L, fetch ? 1 : C.in_flight);
+    const bool wave = !lg && wave_form_wanted(L) && (G0 < 2 || env_int("QE_WAVE", -1) == 1);
     const int G = wave ? 1 : G0;
-    const ScoreLaunch S = wave ? launch_banded_wave(B, C, L, reversed, 1)
+    const ScoreLaunch S = lg ? launch_banded_sys(B, C, L, reversed, lg, 1) :
+                          wave ? launch_banded_wave(B, C, L, reversed, 1)
                                : ((G >= 2) ? launch_banded_coop(B, C, L, reversed, G, 1) : launch_banded_score(B, C, L, reversed, 1));
     if (d_score_out) *d_score_out = S.O.score;
     if (pf && !fetch) {
@@ -587,7 +635,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
         // left.  Worth it while the launches in flight leave SIMDs idle; QE_WINDOWED_QUAD = 0 / 1: never / always (tests)
         const int quad = env_int("QE_WINDOWED_QUAD", -1);
         const size_t waves = (size_t)ng * 4 * (size_t)std::max(1, fetch ? 1 : C.in_flight);
-        if (score_only && (quad == 1 || (quad != 0 && waves <= 1100))) {
+        if (score_only && (quad == 1 || (quad != 0 && waves <= 2048))) {
             a.state = C.scratch_p->take<int32_t>(5 * nt);
             launch_groups(C, k_windowed_quad, a, nt / 16, 4, (size_t)QE_WQ_LDS_PER_WAVE, /* chain */ true);
         }
@@ -845,8 +893,14 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     // cutoffs are still on the device (the fast flow's chip-filling runs), and only for launches of at most 64 one-lane
     // waves: 20 k such pairs (313 waves one-lane, 3 750 cooperative) fill faster one lane each (76 against 85 ms per run),
     // the 813 pairs a 100 k-pair run leaves gain (50 -> 47 ms per batch of the mixed stream).
+    // tight bounds in a launch of few waves: the systolic fill (k_banded_sys, below) -- 16 lanes per leaf for bands of <= 15
+    // slots, a wave per leaf for bands of <= 63 (the bounds of pairs with large indels), the one-lane kernel for what is left.
+    // QE_FILL_SYS = 0 / 1: never / wherever the bound is tight (tests)
+    const int sys_env = env_int("QE_FILL_SYS", -1);
+    const size_t in_fl = (size_t)std::max(1, fetch ? 1 : C.in_flight);
+    const bool sys_fill = Gfill < 2 && tight_runs && (sys_env == 1 || (sys_env != 0 && (size_t)ng * 16 * in_fl <= 4096));
     std::vector<int32_t> hew_init;
-    if (Gfill < 2 && tight_runs && !fill_forced && !d_cut && env_int("QE_COOP_LDS", 1) != 0 && env_int("QE_COOP_TALL_FILL", 1) != 0 &&
+    if (!sys_fill && Gfill < 2 && tight_runs && !fill_forced && !d_cut && env_int("QE_COOP_LDS", 1) != 0 && env_int("QE_COOP_TALL_FILL", 1) != 0 &&
         (size_t)ng * (size_t)std::max(1, fetch ? 1 : C.in_flight) <= 64) {
         size_t live = 0;
         std::vector<int> ebb(nt, 0);
@@ -913,18 +967,18 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
                 a.only_if = O.hew + o;
             }
         }
-        // tight bands (QuickEd's bound, exact child distances) in a launch of few waves: sixteen lanes per leaf, the band's
-        // rows as a systolic array (k_banded_sys); what it flags -- N, a band of more than 15 slots -- stays with the
-        // one-lane kernel.  QE_FILL_SYS = 0 / 1: never / wherever the bound is tight (tests)
         // the cooperative kernels need few registers and no LDS: four workgroups per CU (40 KB each), so that a launch of up
         // to 4 096 waves is resident at once instead of running in two rounds of 2 048 (12.5 k leaves x 16 lanes = 3 125 waves)
         const size_t sys_pin = (size_t)40 * 1024;
-        const int sys = env_int("QE_FILL_SYS", -1);
-        if (Gfill < 2 && a.only_if == nullptr && tight_runs && hew_init.empty() &&
-            (sys == 1 || (sys != 0 && (size_t)(g1 - g0) * 16 * (size_t)std::max(1, fetch ? 1 : C.in_flight) <= 4096))) {
+        if (sys_fill && a.only_if == nullptr) {
+            int maxns = 0;
+            for (int g = g0; g < g1; ++g) maxns = std::max(maxns, (int)lay.nslots[g]);
             a.o_abort = O.hew + o;
-            launch_groups(C, k_banded_sys, a, (size_t)(g1 - g0) * 16, 4, 0, false, sys_pin);
+            launch_groups(C, k_banded_sys<4, true>, a, (size_t)(g1 - g0) * 16, 4, 0, false, sys_pin);
             a.only_if = O.hew + o;
+            // what it flagged for its height: one wave per leaf while the sub-batch is small enough for that
+            if (maxns > 15 && (sys_env == 1 || (size_t)(g1 - g0) * 64 * in_fl <= 4096))
+                launch_groups(C, k_banded_sys<6, true>, a, (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
         }
         a.fill_multi = env_int("QE_FILL_MULTI", 1);
         a.lane_rel = env_int("QE_LANE_REL", 1);

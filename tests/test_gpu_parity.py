@@ -620,6 +620,54 @@ def test_traceback_systolic_forced(tsys, golden, monkeypatch):
     assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
 
 
+@pytest.mark.parametrize("ssys", ["1", "0"])
+def test_score_systolic_forced(ssys, golden, monkeypatch):
+    """BandEd score-only over whole texts with the band's rows as a systolic array (k_banded_sys<.., false>: sixteen lanes
+    per task for bands of <= 15 slots, a wave per task up to 63; QE_SCORE_SYS = 1) against the other forms (0): the
+    goldens incl. the geometry-dependent low bandwidths, QuickEd's stage-3 doubling rounds (indel_10kb), the oracle on
+    ragged / N / lower-case input (flagged tasks fall back) and the block-advance counter."""
+    monkeypatch.setenv("QE_SCORE_SYS", ssys)
+    for name in ("cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len50", "len63", "len64", "len65", "len128", "len130", "len1024", "err35_2kb"):
+        entry = golden["datasets"][name]
+        batch = datagen.generate(**entry["gen"])
+        for label, run in entry["runs"].items():
+            prm = run["params"]
+            if not ((prm.get("algo") == 2 and prm.get("only_score")) or (prm.get("algo") == 0 and name == "indel_10kb")):
+                continue
+            scores, status, cig, _ = gpu_batch(batch, **prm)
+            assert status.tolist() == run["status"], (name, label)
+            assert scores.tolist() == run["score"], (name, label)
+            if "cigar_sha256" in run:
+                assert [sha(c) for c in cig] == run["cigar_sha256"], (name, label)
+    pairs = mixed_batch()
+    rng = np.random.default_rng(29)
+    for i in range(60):
+        L = int(rng.choice([1, 63, 64, 65, 127, 128, 129, 700, 2500, 6000]))
+        e = float(rng.choice([0.0, 0.02, 0.1, 0.3]))
+        b = datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=2900 + i,
+                             indels_num=int(rng.integers(0, 3)) if L >= 2500 else 0, indels_len=200)
+        p, t = next(b.pairs())
+        if rng.random() < 0.3:
+            t = t[: max(1, len(t) - int(rng.integers(0, max(1, len(t) // 3))))]
+        pairs.append((p, t))
+    for kw in (dict(algo=2, only_score=True, bandwidth=1), dict(algo=2, only_score=True, bandwidth=4),
+               dict(algo=2, only_score=True, bandwidth=15), dict(algo=2, only_score=True, bandwidth=40),
+               dict(algo=0, hew_threshold=(10, 10), hew_percentage=(1, 1))):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            if k in ("hew_threshold", "hew_percentage"):
+                getattr(al._params, k)[0], getattr(al._params, k)[1] = v
+            else:
+                setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            assert out[i] == O.oracle_align(p, t, **kw), (ssys, kw, i, len(p), len(t))
+    b = datagen.generate(64, 2000, 0.05, seed=30)
+    for bw in (3, 15):
+        _, _, _, cnt = gpu_batch(b, algo=2, only_score=True, bandwidth=bw)
+        assert cnt[0] == sum(O.oracle_align(p, t, trace=True, algo=2, only_score=True, bandwidth=bw)[3]["score_block_advances"] for p, t in b.pairs())
+
+
 @pytest.mark.parametrize("tall", ["1", "0"])
 def test_tall_band_cooperative_fill(tall, monkeypatch):
     """QuickEd's align step on pairs with LARGE bounds (large indels: bands of 30-50 slots) in a launch of few waves: the
