@@ -186,6 +186,8 @@ void batch_load_packed(quicked_batch* B, Context& C, int64_t n, int wire,
                        const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len);
 // every run of the batch that is still on the device (queued by any thread) is over
 void batch_quiesce(quicked_batch* B);
+// joins the early-finish threads while none of them has work (quicked_pool_trim; they start again on demand)
+void finisher_retire();
 // device-side cigar_check_alignment of caller-provided strings against the batch's resident pairs (quicked_batch_validate)
 quicked_status_t batch_validate(quicked_batch* B, Context& C, const char* cigar_pool, int64_t pool_bytes, const int64_t* cigar_off, int32_t* ok_out);
 void early_finish_stats(int64_t stats_out[4]);

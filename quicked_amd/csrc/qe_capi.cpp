@@ -173,17 +173,18 @@ QE_API quicked_status_t quicked_batch_fetch(quicked_batch_t* batch) {
 
 QE_API void quicked_batch_destroy(quicked_batch_t* batch) {
     if (!batch) return;
+    {   // early-finish jobs still queued for this batch find nothing to do and retire.  The batch's fin_mu BEFORE this thread
+        // takes its context, the order every other call takes them in (guard()); it is released before the context is taken
+        std::unique_lock<std::mutex> lk(batch->fin_mu);
+        batch->pending_fetch.reset();
+        batch->fin_cv.wait(lk, [&] { return batch->fin_jobs == 0; });
+    }
     ApiScope scope;
     try {
         tl_device = batch->device;
         (void)ctx();                           // binds the batch's device to this thread
         batch_quiesce(batch);                  // runs queued by any thread; hipFree then synchronises the device itself
     } catch (const HipError&) { (void)hipGetLastError(); }
-    {   // early-finish jobs still queued for this batch find nothing to do and retire
-        std::unique_lock<std::mutex> lk(batch->fin_mu);
-        batch->pending_fetch.reset();
-        batch->fin_cv.wait(lk, [&] { return batch->fin_jobs == 0; });
-    }
     delete batch;
 }
 
@@ -297,6 +298,7 @@ QE_API quicked_status_t quicked_pool_stats(int64_t stats_out[8]) {
 }
 
 QE_API quicked_status_t quicked_pool_trim(void) {
+    finisher_retire();                                      // the library's own idle threads (their contexts lose their leases)
     ApiScope scope;
     try {
         Context& C = ctx();

@@ -32,7 +32,12 @@
 #include "qe_types.h"
 #include "qe_pool.h"
 #include "qe_batch.h"
-#include "qe_kernels.hip"
+// the kernels: this translation unit's device half.  (QE_KERNELS_HEADER: the sanitizer build of the host half on a machine
+// without a GPU names tests/native/hip_stub/qe_kernels_stub.h here -- tests/test_host_sanitizers.py; never set in the product)
+#ifndef QE_KERNELS_HEADER
+#define QE_KERNELS_HEADER "qe_kernels.hip"
+#endif
+#include QE_KERNELS_HEADER
 
 
 namespace qe {
@@ -862,6 +867,9 @@ static std::mutex& g_fin_mu = *new std::mutex;                      // never des
 static std::condition_variable& g_fin_cv = *new std::condition_variable;
 static std::deque<FinishJob>& g_fin_q = *new std::deque<FinishJob>;
 static int g_fin_threads = 0, g_fin_idle = 0;
+static bool g_fin_retire = false;                    // quicked_pool_trim is joining the idle pool (under g_fin_mu)
+static std::mutex& g_fin_pool_mu = *new std::mutex;  // the pool's threads: created, retired and joined under this
+static std::vector<std::thread>& g_fin_pool = *new std::vector<std::thread>;
 static std::atomic<int> g_fin_busy{0};               // jobs being worked on
 static std::atomic<bool> g_fin_stop{false};          // the process is exiting: no new work
 
@@ -1121,8 +1129,9 @@ static void finisher_main(int index) {
         {
             std::unique_lock<std::mutex> lk(g_fin_mu);
             ++g_fin_idle;
-            g_fin_cv.wait(lk, [index] { return !g_fin_q.empty() && index < g_fin_limit; });
+            g_fin_cv.wait(lk, [index] { return g_fin_stop.load() || g_fin_retire || (!g_fin_q.empty() && index < g_fin_limit); });
             --g_fin_idle;
+            if (g_fin_stop.load() || g_fin_retire) return;         // the pool is being joined (process exit, quicked_pool_trim)
             job = std::move(g_fin_q.front());
             g_fin_q.pop_front();
             ++g_fin_busy;
@@ -1135,7 +1144,7 @@ static void finisher_main(int index) {
         }
         catch (const std::exception& e) { fprintf(stderr, "[quicked_hip] early finish: %s\n", e.what()); }
         --g_fin_busy;
-        if (g_fin_stop.load()) continue;             // exiting: the batch objects may be gone
+        if (g_fin_stop.load()) return;               // exiting: the batch objects may be gone
         taken.push_back(job);
         for (const FinishJob& j : taken) {
             // notified under the lock: quicked_batch_destroy, which waits for fin_jobs == 0 under fin_mu, must not be able to
@@ -1148,21 +1157,44 @@ static void finisher_main(int index) {
 }
 // at process exit (this library's destructors run before the HIP runtime's, which it depends on): no new early-finish work,
 // and a job in progress gets a few seconds to leave the runtime alone
+// The early-finish threads are an OWNED pool (g_fin_pool: joinable, never detached).  At process exit (this library's
+// destructors run before the HIP runtime's, which it depends on) no new work is taken, a job in progress notices the stop
+// flag at its next poll, and every thread is joined.
 __attribute__((destructor)) static void finisher_shutdown() {
+    std::lock_guard<std::mutex> pl(g_fin_pool_mu);
     g_fin_stop.store(true);
     { std::lock_guard<std::mutex> lk(g_fin_mu); g_fin_q.clear(); }
-    for (int i = 0; i < 5000 && g_fin_busy.load() > 0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    g_fin_cv.notify_all();
+    for (std::thread& t : g_fin_pool) if (t.joinable()) t.join();
+    g_fin_pool.clear();
+}
+// quicked_pool_trim(): a process that is done with its batches gives the threads back too -- only while none of them has
+// work (they start again on demand)
+void finisher_retire() {
+    std::lock_guard<std::mutex> pl(g_fin_pool_mu);
+    {
+        std::lock_guard<std::mutex> lk(g_fin_mu);
+        if (g_fin_pool.empty() || !g_fin_q.empty() || g_fin_busy.load() > 0) return;
+        g_fin_retire = true;
+    }
+    g_fin_cv.notify_all();
+    for (std::thread& t : g_fin_pool) if (t.joinable()) t.join();
+    g_fin_pool.clear();
+    std::lock_guard<std::mutex> lk(g_fin_mu);
+    g_fin_retire = false; g_fin_threads = 0; g_fin_idle = 0;
 }
 
 // called by run_batch with B.fin_mu held
 static void finisher_submit(quicked_batch& B, const std::shared_ptr<void>& pf) {
     const int max_threads = env_int("QE_FINISHERS", 3);           // read per call: tests switch it
     if (max_threads <= 0) return;
+    if (g_fin_stop.load()) return;
     ++B.fin_jobs;
+    std::lock_guard<std::mutex> pl(g_fin_pool_mu);                // (order: a batch's fin_mu, the pool, the queue)
     std::lock_guard<std::mutex> lk(g_fin_mu);
     g_fin_limit = max_threads;
     g_fin_q.push_back(FinishJob{&B, pf});
-    if (g_fin_idle == 0 && g_fin_threads < max_threads) { std::thread(finisher_main, g_fin_threads).detach(); ++g_fin_threads; }
+    if (g_fin_idle == 0 && g_fin_threads < max_threads) { g_fin_pool.emplace_back(finisher_main, g_fin_threads); ++g_fin_threads; }
     g_fin_cv.notify_all();
 }
 

@@ -610,12 +610,13 @@ inline void retire_idle_streams(int device) {
     std::unique_lock<std::shared_mutex> life(g_stream_life, std::try_to_lock);
     if (!life.owns_lock()) return;             // some thread is inside a call on an event of a set stream: another time
     for (Context* c : list) {
-        if (c == tl_ctx || c->device != device || !c->stream_w) continue;
+        if (c == tl_ctx || c->device != device || c->in_call.load()) continue;
+        // the context's stream handles are its owner's to write (init, ensure_set): read only with its `busy` mutex held
+        std::unique_lock<std::mutex> lk(c->busy, std::try_to_lock);
+        if (!lk.owns_lock() || !c->stream_w) continue;
         bool any = c->stream_x != nullptr || !c->leased.load();
         for (auto q : c->stream_a2) any |= q != nullptr;
-        if (!any || c->in_call.load()) continue;
-        std::unique_lock<std::mutex> lk(c->busy, std::try_to_lock);
-        if (!lk.owns_lock() || c->runs_on_device_locked()) continue;
+        if (!any || c->runs_on_device_locked()) continue;
         c->retire_streams(!c->leased.load());
     }
 }

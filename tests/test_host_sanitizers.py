@@ -1,0 +1,54 @@
+"""The HOST layer of libquicked_hip.so under sanitizers, without a GPU (the reference offers ASAN / UBSAN for its whole
+library, CMakeLists.txt:43-49).  quicked_amd/csrc/qe_driver.hip (host half), qe_stages.hip, qe_pool.h, qe_batch.h, qe_capi.cpp and
+qe_hostpack.cpp are built with g++ against tests/native/hip_stub -- a header-compatible fake of the HIP runtime calls they
+use, device memory = host memory under a byte budget, kernels = host stand-ins run at launch -- and driven through the C-ABI
+by tests/native/host_scenarios.cpp: rotation of queued runs and fetches, early finish and merged flows, thread churn on
+leased contexts, per-pair calls from several threads, reclaim under a device-memory budget."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NATIVE = os.path.join(ROOT, "tests", "native")
+CSRC = os.path.join(ROOT, "quicked_amd", "csrc")
+
+
+def build(tmp_path, tag, flags):
+    exe = str(tmp_path / f"host_scenarios_{tag}")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unused-parameter", "-Wno-class-memaccess",
+           "-DQE_KERNELS_HEADER=\"qe_kernels_stub.h\"", "-I" + os.path.join(NATIVE, "hip_stub"), "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + flags + \
+          ["-x", "c++", os.path.join(CSRC, "qe_driver.hip"), os.path.join(CSRC, "qe_capi.cpp"), os.path.join(CSRC, "qe_hostpack.cpp"),
+           os.path.join(NATIVE, "host_scenarios.cpp"), "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert built.returncode == 0, built.stderr[-4000:]
+    return exe
+
+
+def run(exe, env_extra, timeout=600):
+    env = dict(os.environ, QE_FINISHERS="3", **env_extra)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=timeout, env=env)
+    return r
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_layer_under_thread_sanitizer(tmp_path):
+    exe = build(tmp_path, "tsan", ["-fsanitize=thread"])
+    r = run(exe, {"TSAN_OPTIONS": "halt_on_error=1 second_deadlock_stack=1", "QE_STUB_HBM_BYTES": str(8 << 30)})
+    assert r.returncode == 0 and "host_scenarios ok" in r.stdout, (r.stdout + r.stderr)[-6000:]
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_layer_under_address_and_ub_sanitizers(tmp_path):
+    exe = build(tmp_path, "asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])
+    r = run(exe, {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1", "QE_STUB_HBM_BYTES": str(8 << 30)})
+    assert r.returncode == 0 and "host_scenarios ok" in r.stdout, (r.stdout + r.stderr)[-6000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-6000:]
+    # a device too small for two threads' pools: the staged out-of-memory path (qe_pool.h) must carry both through
+    r = subprocess.run([exe, "budget"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", QE_STUB_HBM_BYTES=str(700 << 20), QE_OOM_WAIT_MS="2000",
+                                QE_STUB_EXPECT_RECLAIM="1"))
+    assert r.returncode == 0 and "host_scenarios ok" in r.stdout, (r.stdout + r.stderr)[-6000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-6000:]
