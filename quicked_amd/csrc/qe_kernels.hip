@@ -3133,6 +3133,50 @@ __device__ __forceinline__ void quad_col(u32 t0w, u32 t1w, int bit, u32 emask, u
     if (STORE) *st = make_uint2(P, Mb);
 }
 
+// the same with the carries travelling as the RAW pre-shift delta words (bit 31 = the carry): the producer extracts nothing,
+// the consumer's "(Ph << 1) | PHin" is one v_alignbit with the incoming word; MHin arrives as a clean 0 / 1
+template <bool STORE>
+__device__ __forceinline__ void quad_col_w(u32 t0w, u32 t1w, int bit, u32 emask, u32 a, u32 b, u32& P, u32& M, u32 inPw, u32 MHin,
+                                           u32& oPw, u32& oMw, uint2* st) {
+    const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0w, bit, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1w, bit, 1);
+    const u32 e = bitop3<0x90>(~(a ^ m0), b, m1) & emask;
+    const u32 Mb = M;
+    const u32 xv = e | M;
+    const u32 ec = e | MHin;
+    const u32 sum = (ec & P) + P;
+    const u32 ph = bitop3<0xF3>(M, bitop3<0xFE>(sum, P, ec), 0u);     // M | ~(sum | P | Eqc)
+    const u32 mh = bitop3<0xB0>(P, sum, ec);                          // P & ((sum ^ P) | Eqc)
+    const u32 phs = __builtin_amdgcn_alignbit(ph, inPw, 31);          // (Ph << 1) | (inPw >> 31)
+    const u32 mhs = (mh << 1) | MHin;
+    P = bitop3<0xF1>(mhs, xv, phs);                                   // Mhs | ~(Xv | Phs)
+    M = phs & xv;
+    oPw = ph; oMw = mh;
+    if (STORE) *st = make_uint2(P, Mb);
+}
+// window_walk_tile<true> with the deletion run behind a branch the wave skips when no lane starts one at this column
+__device__ __forceinline__ void window_walk_tile_lean(const u64 (&tP)[8], const u64 (&tM)[8], const u64 (&tE)[8],
+                                                      bool& inr, int& vw, int& hw, int& wscore) {
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const bool mine = inr && (hw & 7) == j;
+        const int bit = vw & 63;
+        const u32 pb = (u32)(tP[j] >> bit) & 1u;
+        int r = 0, b1 = bit;
+        if (mine && pb != 0) {
+            r = min(__clzll((long long)~(tP[j] << (63 - bit))), bit + 1);
+            b1 = (bit - r) & 63;
+        }
+        const bool up = r == bit + 1;                                 // the run left the block row: window done
+        const bool go = mine && !up;
+        const u32 mb = (u32)(tM[j] >> b1) & 1u, eq = (u32)(tE[j] >> b1) & 1u;
+        wscore += r + (go ? (int)(mb | (eq ^ 1u)) : 0);
+        vw -= r + ((go && !mb) ? 1 : 0);
+        hw -= go ? 1 : 0;
+        inr = inr && !(mine && up) && vw >= 64;
+        asm("" : "+v"(vw), "+v"(hw));                                 // (see walk_tile_lean)
+    }
+}
+
 __global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
     const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & 3;
     const int t = wv * 16 + (lane >> 2);
@@ -3157,7 +3201,6 @@ __global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
     int pos_v = m - 1, pos_h = n - 1;
     int score = 0, hew = 0;
     u32 steps = 0;
-    RunSink R; R.init(nullptr, 0);                                    // score only: never written
     while (__any(ok && pos_v >= 127 && pos_h >= 127)) {
         const bool on = ok && pos_v >= 127 && pos_h >= 127;
         const int v0 = on ? pos_v - 127 : 0, h0 = on ? pos_h - 127 : 0;
@@ -3192,40 +3235,43 @@ __global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
         // the window's boundaries (bpm_windowed.c:226-230, 260; SSE: 348, 393, 424)
         const u64 ph_first = (v0 == 0) ? QE_ONES : 0;
         const u32 pinit = (h0 == 0) ? ~0u : 0u;
-        const u64 hin0 = sse ? (0x5555555555555556ull | (ph_first & 1)) : ph_first;
-        const u64 hin1 = sse ? 0x5555555555555555ull : ph_first;
-        const u32 bw[5] = {lo32(hin0), hi32(hin0), lo32(hin1), hi32(hin1), 1u};
+        // lane 0's carry-in words (bit 31 = the boundary's PHin): the real first row, or the SSE kernel's pattern -- column 0
+        // Ph_first, column 1 one, then one at even columns (and at the column one past the window)
+        const u32 Bf = (u32)(ph_first & 1) << 31;
+        const u32 BWe = sse ? 0x80000000u : Bf, BWo = sse ? 0u : Bf;
+        const u32 w0 = is0 ? 0u : 1u;                               // width of the MHin extract: lane 0's is always 0
         // the extra column's Eq (lanes 0 and 1, SSE): text[tlen] reads as N, which matches nothing here (A.7(4))
         const u32 eqx = (on && pos_h + 1 < n) ? ~0u : 0u;
-        u32 P = pinit, M = 0, oP = 0, oM = 0;
+        u32 P = pinit, M = 0, oPw = 0, oMw = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the walk of the window before has read its slots
 #pragma unroll
         for (int s = 0; s < 129; ++s) {
-            u32 inP = quad_ror1(oP), inM = quad_ror1(oM);
-            const u32 bnd = __builtin_amdgcn_ubfe(bw[s >> 5], s & 31, 1);
-            inP = is0 ? bnd : inP; inM = is0 ? 0u : inM;
+            u32 inPw = quad_ror1(oPw);
+            const u32 inMw = quad_ror1(oMw);
+            inPw = is0 ? ((s == 0) ? Bf : ((s & 1) && s != 1 ? BWo : BWe)) : inPw;
+            const u32 MHin = __builtin_amdgcn_ubfe(inMw, 31, w0);
             const u32 em = (s == 128 && is0) ? eqx : ~0u;
             if (s < 3) {
-                if (j <= s) quad_col<false>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inP, inM, oP, oM, hw_);
+                if (j <= s) quad_col_w<false>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inPw, MHin, oPw, oMw, hw_);
             } else if (s < 66) {
-                quad_col<false>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inP, inM, oP, oM, hw_);
+                quad_col_w<false>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inPw, MHin, oPw, oMw, hw_);
             } else {
-                quad_col<true>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inP, inM, oP, oM, hw_ + (s - 66) * 64);
+                quad_col_w<true>(tw0[s >> 5], tw1[s >> 5], s & 31, em, a, b, P, M, inPw, MHin, oPw, oMw, hw_ + (s - 66) * 64);
             }
         }
         {   // step 129: lane 1 runs the extra column (its carries reach lane 2 only under SSE semantics), lane 3 column 126
-            const u32 inP = quad_ror1(oP), inM = quad_ror1(oM);
-            const u32 kP = oP, kM = oM;
-            if (j & 1) quad_col<true>(tw0[4], tw1[4], 1, (j == 1) ? eqx : ~0u, a, b, P, M, inP, inM, oP, oM, hw_ + 63 * 64);
-            if (j == 1 && !sse) { oP = kP; oM = kM; }
+            const u32 inPw = quad_ror1(oPw), MHin = __builtin_amdgcn_ubfe(quad_ror1(oMw), 31, 1u);
+            const u32 kP = oPw, kM = oMw;
+            if (j & 1) quad_col_w<true>(tw0[4], tw1[4], 1, (j == 1) ? eqx : ~0u, a, b, P, M, inPw, MHin, oPw, oMw, hw_ + 63 * 64);
+            if (j == 1 && !sse) { oPw = kP; oMw = kM; }
         }
         {   // step 130: lane 2's column 127 (text bit 127 + 2)
-            const u32 inP = quad_ror1(oP), inM = quad_ror1(oM);
-            if (j == 2) quad_col<true>(tw0[4], tw1[4], 1, ~0u, a, b, P, M, inP, inM, oP, oM, hw_ + 63 * 64);
+            const u32 inPw = quad_ror1(oPw), MHin = __builtin_amdgcn_ubfe(quad_ror1(oMw), 31, 1u);
+            if (j == 2) quad_col_w<true>(tw0[4], tw1[4], 1, ~0u, a, b, P, M, inPw, MHin, oPw, oMw, hw_ + 63 * 64);
         }
         {   // step 131: lane 3's column 127 (text bit 127 + 3)
-            const u32 inP = quad_ror1(oP), inM = quad_ror1(oM);
-            if (j == 3) quad_col<true>(tw0[4], tw1[4], 2, ~0u, a, b, P, M, inP, inM, oP, oM, hw_ + 64 * 64);
+            const u32 inPw = quad_ror1(oPw), MHin = __builtin_amdgcn_ubfe(quad_ror1(oMw), 31, 1u);
+            if (j == 3) quad_col_w<true>(tw0[4], tw1[4], 2, ~0u, a, b, P, M, inPw, MHin, oPw, oMw, hw_ + 64 * 64);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // lanes 2 / 3 wrote, every lane of the quad reads
         if (on) steps += 256u;
@@ -3245,7 +3291,7 @@ __global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
                 tP[c] = mk64(l2.x, l3.x);
                 tM[c] = mk64(l2.y, l3.y);
             }
-            window_walk_tile<true>(tP, tM, tE, inr, vw, hw, wscore, R);
+            window_walk_tile_lean(tP, tM, tE, inr, vw, hw, wscore);
         }
         if (on) {
             if (wscore > 64 * A.hew_threshold / 100) ++hew;         // (W - O) * 64 * hew_threshold / 100, bpm_windowed.c:556-558
