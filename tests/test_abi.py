@@ -176,3 +176,73 @@ def test_wire_pack_pool_equals_the_per_sequence_serializer():
         L.quicked_wire_pack_isa(-1)
 
 
+
+
+def _newest_bench_line():
+    import glob
+    import json
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*_bench_line.json")),
+                   key=lambda f: re.match(r"(r\d+_[a-z]+)_bench_line", os.path.basename(f)).group(1))
+    assert files, "no committed bench line"
+    f = files[-1]
+    return f, json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+
+
+def test_newest_committed_bench_line_follows_the_contract():
+    """the line bench.py printed on the MI355X for the newest milestone under profiles/ (the driver's command): the contract
+    fields, roofline + cpu_baseline, the flat end-to-end / single-batch keys of round 5, every workload object with its own
+    baseline, the 12.5 k-pair share incl. the mixed leg's early-finish statistics"""
+    f, d = _newest_bench_line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "ranks_seen", "e2e", "workloads", "strong_share",
+              "value_definition", "kernel_value", "e2e_value", "e2e_ascii_link_value", "single_batch_value"):
+        assert k in d, (f, k)
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"] and "DEVICE-RESIDENT" in d["config"]["workload"]
+    assert abs(d["value"] - d["config"]["pairs_per_gpu"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-6
+    assert d["kernel_value"] == d["value"] and d["e2e_value"] == d["e2e"]["ascii_hostpacked"]["value"]
+    assert d["value"] > d["single_batch_value"] > 0 and d["e2e"]["2bit_pinned"]["value"] > d["e2e_ascii_link_value"] > 0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "frac_of_measured_copy"):
+        assert k in r, (f, k)
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < r["frac_of_measured_copy"] <= 1
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, (f, k)
+    assert c["kind"] in ("reference", "port") and c["gpu_scores_identical_on_sample"] is True
+    w = d["workloads"]
+    for wl in ("quicked", "cfg4", "quicked_indels", "quicked_mixed"):
+        assert w[wl]["value"] > 0 and w[wl]["cpu_baseline"]["value"] > 0, (f, wl)
+    assert w["quicked"]["score_checksum"] == d["score_checksum"]            # BandEd (bandwidth 15) and QuickEd agree on every distance
+    assert w["quicked_indels"]["quicked_flow"]["stage2_pairs"] > 0 and w["quicked_indels"]["quicked_flow"]["stage3_pairs"] > 0
+    s = d["strong_share"]
+    assert s["pairs_per_gpu"] == 12500
+    for wl in ("banded_score", "quicked"):
+        assert s[wl]["value"] > s[wl]["single_batch_value"] > 0 and s[wl]["runs_in_flight"] >= 3
+    assert s["quicked_mixed"]["value"] > 0 and s["quicked_mixed"]["early_finish_flows"]["merged_flows"] >= 0
+
+
+def test_readme_numbers_are_generated_from_the_committed_bench_line():
+    """README.md's measured paragraph is tools/readme_numbers.py's output for the newest profiles/<tag>_bench_line.json"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("readme_numbers", os.path.join(ROOT, "tools", "readme_numbers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(ROOT, "README.md")).read()
+    held = text[text.index(mod.BEGIN) + len(mod.BEGIN):text.index(mod.END)].strip()
+    assert held == mod.paragraph().strip()
+
+
+def test_committed_kernel_resource_table_has_no_scratch():
+    """profiles/<newest tag>_kernel_resources.txt (tools/kernel_resources.sh): every kernel of the build it describes fits
+    its registers -- incl. round 5's cooperative forms"""
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_resources.txt"))
+    assert files
+    lines = [l for l in open(os.path.join(ROOT, "profiles", files[-1])).read().splitlines() if l.strip()]
+    assert len(lines) >= 20
+    for l in lines:
+        assert "ScratchSize [bytes/lane]: 0" in l, l
+    for name in ("k_banded<true>", "k_windowed_cp", "k_windowed_quad", "k_banded_sys<4, true>", "k_banded_sys<6, false>", "k_traceback_sys<4>"):
+        assert any(name in l for l in lines), name
