@@ -3205,28 +3205,31 @@ __global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
         const bool on = ok && pos_v >= 127 && pos_h >= 127;
         const int v0 = on ? pos_v - 127 : 0, h0 = on ? pos_h - 127 : 0;
         // pattern: this lane's 32 rows; rows 64 .. 127 (the traceback's) for the walk's Eq words
+        // every load of the window first, then the funnel shifts (branch-free: a conditional second load per call made the
+        // three groups wait for each other -- three memory round trips per window where one does)
         u64 pa = 0, pb = 0, a1 = 0, b1 = 0;
-        if (on) {
-            load_planes_ab(pp, p0 + v0 + 32 * j, pa, pb);
-            load_planes_ab(pp, p0 + v0 + 64, a1, b1);
-        }
-        const u32 a = lo32(pa), b = lo32(pb);
-        // text: 192 bases from t0 + h0 - j, so that bit s of these words is column s - j (what this lane does at step s)
         u64 SA[3] = {0, 0, 0}, SB[3] = {0, 0, 0};
         if (on) {
+            const int bpj = p0 + v0 + 32 * j, bp1 = p0 + v0 + 64;
+            const u64* qj = pp + 3 * (int64_t)(bpj >> 6);
+            const u64* q1 = pp + 3 * (int64_t)(bp1 >> 6);
+            // text: 192 bases from t0 + h0 - j, so that bit s of these words is column s - j (what this lane does at step s)
             const int ts = t0 + h0 - j, tsc = max(ts, 0), lsh = tsc - ts;
-            const int w = tsc >> 6, sh = tsc & 63;
-            const u64* q = tp + 3 * (int64_t)w;
+            const u64* q = tp + 3 * (int64_t)(tsc >> 6);
+            const u64 ja0 = qj[0], jb0 = qj[1], ja1 = qj[3], jb1 = qj[4];
+            const u64 ra0 = q1[0], rb0 = q1[1], ra1 = q1[3], rb1 = q1[4];
             const u64 x0 = q[0], x1 = q[3], x2 = q[6], x3 = q[9], y0 = q[1], y1 = q[4], y2 = q[7], y3 = q[10];
-            if (sh) {
-                SA[0] = (x0 >> sh) | (x1 << (64 - sh)); SA[1] = (x1 >> sh) | (x2 << (64 - sh)); SA[2] = (x2 >> sh) | (x3 << (64 - sh));
-                SB[0] = (y0 >> sh) | (y1 << (64 - sh)); SB[1] = (y1 >> sh) | (y2 << (64 - sh)); SB[2] = (y2 >> sh) | (y3 << (64 - sh));
-            } else { SA[0] = x0; SA[1] = x1; SA[2] = x2; SB[0] = y0; SB[1] = y1; SB[2] = y2; }
+            const int shj = bpj & 63, sh1 = bp1 & 63, sh = tsc & 63;
+            pa = (ja0 >> shj) | ((ja1 << 1) << (63 - shj)); pb = (jb0 >> shj) | ((jb1 << 1) << (63 - shj));
+            a1 = (ra0 >> sh1) | ((ra1 << 1) << (63 - sh1)); b1 = (rb0 >> sh1) | ((rb1 << 1) << (63 - sh1));
+            SA[0] = (x0 >> sh) | ((x1 << 1) << (63 - sh)); SA[1] = (x1 >> sh) | ((x2 << 1) << (63 - sh)); SA[2] = (x2 >> sh) | ((x3 << 1) << (63 - sh));
+            SB[0] = (y0 >> sh) | ((y1 << 1) << (63 - sh)); SB[1] = (y1 >> sh) | ((y2 << 1) << (63 - sh)); SB[2] = (y2 >> sh) | ((y3 << 1) << (63 - sh));
             if (lsh) {                                                // the window starts at the text's first bases: j - ts bits of nothing first
                 SA[2] = (SA[2] << lsh) | (SA[1] >> (64 - lsh)); SA[1] = (SA[1] << lsh) | (SA[0] >> (64 - lsh)); SA[0] <<= lsh;
                 SB[2] = (SB[2] << lsh) | (SB[1] >> (64 - lsh)); SB[1] = (SB[1] << lsh) | (SB[0] >> (64 - lsh)); SB[0] <<= lsh;
             }
         }
+        const u32 a = lo32(pa), b = lo32(pb);
         const u32 tw0[5] = {lo32(SA[0]), hi32(SA[0]), lo32(SA[1]), hi32(SA[1]), lo32(SA[2])};
         const u32 tw1[5] = {lo32(SB[0]), hi32(SB[0]), lo32(SB[1]), hi32(SB[1]), lo32(SB[2])};
         // columns 64 .. 127 un-skewed, for the walk
