@@ -94,7 +94,9 @@ void qe_gen_batch(uint64_t seed, uint64_t first, int64_t count, int64_t length, 
                   char* pattern_pool, int64_t* pattern_off, int32_t* pattern_len,
                   char* text_pool, int64_t* text_off, int32_t* text_len) {
     const int64_t cap = qe_gen_pattern_capacity(length, error, indels_num, indels_len);
-    #pragma omp parallel for schedule(dynamic, 64)
+    /* a team only where there is work for one (a team of 256 threads costs 0.1 s to wake on a 256-thread box: callers
+     * that generate one pair at a time paid that per pair) */
+    #pragma omp parallel for schedule(dynamic, 64) if (count >= 256)
     for (int64_t i = 0; i < count; ++i) {
         pattern_off[i] = i * cap;
         text_off[i] = i * length;

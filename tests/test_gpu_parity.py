@@ -16,6 +16,30 @@ def sha(s):
     return hashlib.sha256(s.encode()).hexdigest() if s is not None else None
 
 
+_ORACLE_MEMO = {}
+
+
+def oracle_cached(p, t, trace=False, **kw):
+    """O.oracle_align, memoised per (pair, parameters): the forced-form tests run the same inputs once per kernel form"""
+    kw = dict(kw, trace=trace)
+    key = (bytes(p), bytes(t), tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in kw.items())))
+    r = _ORACLE_MEMO.get(key)
+    if r is None:
+        r = _ORACLE_MEMO[key] = O.oracle_align(p, t, **kw)
+    return r
+
+
+_EXACT_MEMO = {}
+
+
+def exact_cached(p, t):
+    """the oracle's full-height DP distance, memoised (it is the slow part of the in-domain checks)"""
+    key = (bytes(p), bytes(t))
+    if key not in _EXACT_MEMO:
+        _EXACT_MEMO[key] = O.oracle().qo_exact_distance(p, len(p), t, len(t))
+    return _EXACT_MEMO[key]
+
+
 def gpu_batch(batch, **kw):
     """-> (scores, statuses, cigars or None, counters) through quicked_batch_*"""
     rb = capi.ResidentBatch(batch)
@@ -100,7 +124,7 @@ def test_oracle_parity_random(gen):
     for kw in RUNS:
         scores, status, cig, _ = gpu_batch(batch, **kw)
         for i, (p, t) in enumerate(pairs):
-            st, sc, cg = O.oracle_align(p, t, **kw)
+            st, sc, cg = oracle_cached(p, t, **kw)
             assert status[i] == st, (gen, kw, i)
             assert scores[i] == sc, (gen, kw, i)
             if cig is not None:
@@ -138,7 +162,7 @@ def test_ragged_empty_and_non_acgt(kw):
         setattr(al._params, k, v)
     st, out = al.alignBatch(pairs)
     for i, (p, t) in enumerate(pairs):
-        est, esc, ecg = O.oracle_align(p, t, **kw)
+        est, esc, ecg = oracle_cached(p, t, **kw)
         assert out[i][0] == est, (kw, i)
         if est >= 0:
             assert out[i][1] == esc, (kw, i, len(p), len(t))
@@ -150,10 +174,10 @@ def test_counters_match_oracle_work():
     batch = datagen.generate(count=64, length=2000, error=0.05, seed=77)
     pairs = list(batch.pairs())
     _, _, _, cnt = gpu_batch(batch, algo=2, only_score=True, bandwidth=15)
-    exp = sum(O.oracle_align(p, t, trace=True, algo=2, only_score=True, bandwidth=15)[3]["score_block_advances"] for p, t in pairs)
+    exp = sum(oracle_cached(p, t, trace=True, algo=2, only_score=True, bandwidth=15)[3]["score_block_advances"] for p, t in pairs)
     assert cnt[0] == exp
     _, _, _, cnt = gpu_batch(batch, algo=0)
-    tr = [O.oracle_align(p, t, trace=True, algo=0)[3] for p, t in pairs]
+    tr = [oracle_cached(p, t, trace=True, algo=0)[3] for p, t in pairs]
     assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
     assert cnt[2] == sum(x["window_block_steps"] for x in tr)
     assert cnt[3] == sum(x["traceback_steps"] for x in tr)
@@ -216,7 +240,7 @@ def test_reference_crash_fuzz_at_its_own_scale():
             lib.quicked_free(C.byref(a))
             assert st == capi.QUICKED_WIP and 0 <= score <= 10 and cg is not None, (length, i, st, score)
             if i % stride == 0:
-                assert (st, score, cg) == O.oracle_align(pat, txt, algo=0), (length, i)
+                assert (st, score, cg) == oracle_cached(pat, txt, algo=0), (length, i)
                 assert sum(int(n) for n, op in re.findall(r"(\d+)([MXID])", cg) if op != "M") == score
 
 
@@ -242,13 +266,14 @@ def test_configs_2_and_3_at_full_size():
         cig = rb.cigars()
     finally:
         rb.close()
+        capi.pool_trim()                  # 100 k-pair QuickEd pools (five sets): not this test's to leave to the ones after it
     pairs = whole.pairs()
     for i, (p, t) in enumerate(pairs):
         if i % 1999:
             continue
-        want = O.oracle_align(p, t, algo=0)
+        want = oracle_cached(p, t, algo=0)
         assert (capi.QUICKED_WIP, int(s_q[i]), cig[i]) == want, i
-        assert O.oracle_align(p, t, algo=2, only_score=True, bandwidth=15)[1] == s_b[i], i
+        assert oracle_cached(p, t, algo=2, only_score=True, bandwidth=15)[1] == s_b[i], i
         if O.have_ref():
             assert O.ref_align(p, t, algo=0) == want, i
 
@@ -263,7 +288,7 @@ def test_hirschberg_forced_deep_splits(monkeypatch):
         pairs = list(batch.pairs())
         scores, status, cig, cnt = gpu_batch(batch, algo=0)
         for i, (p, t) in enumerate(pairs):
-            st, sc, cg, tr = O.oracle_align(p, t, trace=True, algo=0)      # reference threshold: bound + score
+            st, sc, cg, tr = oracle_cached(p, t, trace=True, algo=0)      # reference threshold: bound + score
             ops = C.create_string_buffer(len(p) + len(t) + 1)
             n = C.c_int64()
             lib.qo_hirschberg(p, len(p), t, len(t), tr["bound"], 1 << 15, ops, C.byref(n), None)
@@ -294,7 +319,7 @@ def test_align_benchmark_harness(tmp_path):
         lines = out.read_text().splitlines()
         assert len(lines) == len(pairs)
         for (p, t), line in zip(pairs, lines):
-            st, sc, cg = O.oracle_align(p, t, **kw)
+            st, sc, cg = oracle_cached(p, t, **kw)
             assert line == f"{sc}\t{cg}", algo
         assert "INACCURATE SCORE" not in r.stderr or algo == "edit-windowed"      # WindowEd is a bound, not exact
         assert "Alignments.Correct     100/100" in r.stderr
@@ -338,7 +363,7 @@ def test_align_benchmark_worker_threads_write_the_same_file(tmp_path):
     lines = outs["t1"].decode().splitlines()
     assert len(lines) == len(pairs)
     for i in list(range(0, len(pairs), 37)) + [len(pairs) - 1]:
-        st, sc, cg = O.oracle_align(*pairs[i], algo=0)
+        st, sc, cg = oracle_cached(*pairs[i], algo=0)
         assert lines[i] == f"{sc}\t{cg}", i
     assert lines[len(pairs) - 2] == "-\t-"
     for tag in ("t2", "t3", "t4", "t8"):
@@ -379,10 +404,10 @@ def test_randomised_shapes_and_params(seed, monkeypatch):
                 setattr(al._params, k, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            est, esc, ecg = O.oracle_align(p, t, **kw)
+            est, esc, ecg = oracle_cached(p, t, **kw)
             # CIGAR-producing BandEd / Hirschberg below the true distance is outside the parity domain
             in_domain = not (algo in (2, 3) and not kw["only_score"]) or \
-                O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+                exact_cached(p, t) <= max(len(p), len(t)) * kw["bandwidth"] // 100
             assert out[i][0] == est or not in_domain, (kw, i)
             if est >= 0 and in_domain:
                 assert out[i][1] == esc, (kw, i, len(p), len(t))
@@ -419,11 +444,11 @@ def test_windowed_checkpoint_and_history_paths(cp, monkeypatch):
                 setattr(al._params, k, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            assert out[i] == O.oracle_align(p, t, **kw), (cp, kw, i, len(p), len(t))
+            assert out[i] == oracle_cached(p, t, **kw), (cp, kw, i, len(p), len(t))
     # work counters: block-advances of the windows are the oracle's whichever path ran
     b = datagen.generate(64, 3000, 0.1, seed=78, indels_num=1, indels_len=300)
     _, _, _, cnt = gpu_batch(b, algo=1, only_score=True)
-    assert cnt[2] == sum(O.oracle_align(p, t, trace=True, algo=1, only_score=True)[3]["window_block_steps"] for p, t in b.pairs())
+    assert cnt[2] == sum(oracle_cached(p, t, trace=True, algo=1, only_score=True)[3]["window_block_steps"] for p, t in b.pairs())
 
 
 @pytest.mark.parametrize("quad", ["1", "0"])
@@ -468,11 +493,11 @@ def test_windowed_quad_forced(quad, golden, monkeypatch):
                 setattr(al._params, k, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            assert out[i] == O.oracle_align(p, t, **kw), (quad, kw, i, len(p), len(t))
+            assert out[i] == oracle_cached(p, t, **kw), (quad, kw, i, len(p), len(t))
     b = datagen.generate(80, 3000, 0.1, seed=92, indels_num=1, indels_len=300)
     for kw in (dict(algo=1, only_score=True, window_size=2, overlap_size=1), dict(algo=0)):
         _, _, _, cnt = gpu_batch(b, **kw)
-        assert cnt[2] == sum(O.oracle_align(p, t, trace=True, **kw)[3]["window_block_steps"] for p, t in b.pairs()), kw
+        assert cnt[2] == sum(oracle_cached(p, t, trace=True, **kw)[3]["window_block_steps"] for p, t in b.pairs()), kw
 
 
 @pytest.mark.parametrize("multi", ["1", "0"])
@@ -493,8 +518,8 @@ def test_fill_multi_slot_passes_forced(multi, monkeypatch):
             setattr(al._params, k, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            want = O.oracle_align(p, t, **kw)
-            in_domain = kw["algo"] == 0 or O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+            want = oracle_cached(p, t, **kw)
+            in_domain = kw["algo"] == 0 or exact_cached(p, t) <= max(len(p), len(t)) * kw["bandwidth"] // 100
             if in_domain:
                 assert out[i] == want, (multi, kw, i, len(p), len(t))
 
@@ -536,7 +561,7 @@ def test_fill_systolic_forced(sys_, golden, monkeypatch):
             setattr(al._params, k, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            assert out[i] == O.oracle_align(p, t, **kw), (sys_, kw, i, len(p), len(t))
+            assert out[i] == oracle_cached(p, t, **kw), (sys_, kw, i, len(p), len(t))
     # forced deep splits (the oracle's Hirschberg with the same threshold, cf. test_hirschberg_forced_deep_splits)
     import ctypes as C
     monkeypatch.setenv("QE_SPLIT_BYTES", str(1 << 15))
@@ -544,7 +569,7 @@ def test_fill_systolic_forced(sys_, golden, monkeypatch):
     batch = datagen.generate(count=70, length=3000, error=0.08, seed=1801)
     scores, status, cig, _ = gpu_batch(batch, algo=0)
     for i, (p, t) in enumerate(batch.pairs()):
-        st, sc, cg, tr = O.oracle_align(p, t, trace=True, algo=0)
+        st, sc, cg, tr = oracle_cached(p, t, trace=True, algo=0)
         ops = C.create_string_buffer(len(p) + len(t) + 1)
         nn = C.c_int64()
         lib.qo_hirschberg(p, len(p), t, len(t), tr["bound"], 1 << 15, ops, C.byref(nn), None)
@@ -554,7 +579,7 @@ def test_fill_systolic_forced(sys_, golden, monkeypatch):
     monkeypatch.delenv("QE_SPLIT_BYTES")
     b = datagen.generate(96, 3000, 0.05, seed=18)
     _, _, _, cnt = gpu_batch(b, algo=0)
-    tr = [O.oracle_align(p, t, trace=True, algo=0)[3] for p, t in b.pairs()]
+    tr = [oracle_cached(p, t, trace=True, algo=0)[3] for p, t in b.pairs()]
     assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
     assert cnt[3] == sum(x["traceback_steps"] for x in tr)
 
@@ -594,9 +619,9 @@ def test_traceback_systolic_forced(tsys, golden, monkeypatch):
             setattr(al._params, k, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            want = O.oracle_align(p, t, **kw)
+            want = oracle_cached(p, t, **kw)
             in_domain = kw["algo"] == 0 or len(p) == 0 or len(t) == 0 or \
-                O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+                exact_cached(p, t) <= max(len(p), len(t)) * kw["bandwidth"] // 100
             if in_domain:
                 assert out[i] == want, (tsys, kw, i, len(p), len(t))
     import ctypes as C
@@ -605,7 +630,7 @@ def test_traceback_systolic_forced(tsys, golden, monkeypatch):
     batch = datagen.generate(count=70, length=3000, error=0.08, seed=2401)
     scores, status, cig, _ = gpu_batch(batch, algo=0)
     for i, (p, t) in enumerate(batch.pairs()):
-        st, sc, cg, tr = O.oracle_align(p, t, trace=True, algo=0)
+        st, sc, cg, tr = oracle_cached(p, t, trace=True, algo=0)
         ops = C.create_string_buffer(len(p) + len(t) + 1)
         nn = C.c_int64()
         lib.qo_hirschberg(p, len(p), t, len(t), tr["bound"], 1 << 15, ops, C.byref(nn), None)
@@ -615,7 +640,7 @@ def test_traceback_systolic_forced(tsys, golden, monkeypatch):
     monkeypatch.delenv("QE_SPLIT_BYTES")
     b = datagen.generate(96, 3000, 0.05, seed=24, indels_num=1, indels_len=100)
     _, _, _, cnt = gpu_batch(b, algo=0)
-    tr = [O.oracle_align(p, t, trace=True, algo=0)[3] for p, t in b.pairs()]
+    tr = [oracle_cached(p, t, trace=True, algo=0)[3] for p, t in b.pairs()]
     assert cnt[3] == sum(x["traceback_steps"] for x in tr)
     assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
 
@@ -661,11 +686,11 @@ def test_score_systolic_forced(ssys, golden, monkeypatch):
                 setattr(al._params, k, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            assert out[i] == O.oracle_align(p, t, **kw), (ssys, kw, i, len(p), len(t))
+            assert out[i] == oracle_cached(p, t, **kw), (ssys, kw, i, len(p), len(t))
     b = datagen.generate(64, 2000, 0.05, seed=30)
     for bw in (3, 15):
         _, _, _, cnt = gpu_batch(b, algo=2, only_score=True, bandwidth=bw)
-        assert cnt[0] == sum(O.oracle_align(p, t, trace=True, algo=2, only_score=True, bandwidth=bw)[3]["score_block_advances"] for p, t in b.pairs())
+        assert cnt[0] == sum(oracle_cached(p, t, trace=True, algo=2, only_score=True, bandwidth=bw)[3]["score_block_advances"] for p, t in b.pairs())
 
 
 @pytest.mark.parametrize("tall", ["1", "0"])
@@ -686,7 +711,7 @@ def test_tall_band_cooperative_fill(tall, monkeypatch):
     s, st, cg, cnt = gpu_batch(batch, algo=0)
     work = 0
     for i, (p, t) in enumerate(pairs):
-        est, esc, ecg, tr = O.oracle_align(p, t, trace=True, algo=0)
+        est, esc, ecg, tr = oracle_cached(p, t, trace=True, algo=0)
         work += tr["fill_block_advances"]
         assert (st[i], s[i], cg[i]) == (est, esc, ecg), (tall, i)
     assert cnt[1] == work, (tall, int(cnt[1]), work)
@@ -713,9 +738,9 @@ def test_lane_relative_band_walk_forced(rel, monkeypatch):
         s, st, cg, cnt = gpu_batch(batch, **kw)
         work = 0
         for i, (p, t) in enumerate(pairs):
-            est, esc, ecg, tr = O.oracle_align(p, t, trace=True, **kw)
+            est, esc, ecg, tr = oracle_cached(p, t, trace=True, **kw)
             work += tr[key]
-            in_domain = kw["algo"] == 0 or O.oracle().qo_exact_distance(p, len(p), t, len(t)) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+            in_domain = kw["algo"] == 0 or exact_cached(p, t) <= max(len(p), len(t)) * kw["bandwidth"] // 100
             if in_domain:
                 assert (st[i], s[i]) == (est, esc), (rel, kw, i)
                 if cg is not None:
@@ -735,7 +760,7 @@ def test_cooperative_kernel_forced(lds, monkeypatch):
     pairs = list(batch.pairs())
     ref = {}
     for bw in (8, 15, 40):
-        tr = [O.oracle_align(p, t, trace=True, algo=2, only_score=True, bandwidth=bw) for p, t in pairs]
+        tr = [oracle_cached(p, t, trace=True, algo=2, only_score=True, bandwidth=bw) for p, t in pairs]
         ref[bw] = ([x[1] for x in tr], sum(x[3]["score_block_advances"] for x in tr))
     for G in ("2", "4", "8", "16", "32"):
         monkeypatch.setenv("QE_COOP_G", G)
@@ -757,7 +782,7 @@ def test_cooperative_kernel_forced(lds, monkeypatch):
         rag.append((p, t))
     al = capi.QuickedAligner()
     al.setAlgorithm(capi.BANDED); al.setOnlyScore(True); al.setBandwidth(30)
-    exp = [O.oracle_align(p, t, algo=2, only_score=True, bandwidth=30)[:2] for p, t in rag]
+    exp = [oracle_cached(p, t, algo=2, only_score=True, bandwidth=30)[:2] for p, t in rag]
     for G in ("2", "4", "8"):
         monkeypatch.setenv("QE_COOP_G", G)
         st, out = al.alignBatch(rag)
@@ -772,7 +797,7 @@ def test_cooperative_kernel_forced(lds, monkeypatch):
         got = (scores.tolist(), status.tolist(), cig, int(cnt[0]))
         if hexp is None:
             hexp = got
-            assert all(s == O.oracle().qo_exact_distance(p, len(p), t, len(t)) for s, (p, t) in zip(got[0], hb.pairs()))
+            assert all(s == exact_cached(p, t) for s, (p, t) in zip(got[0], hb.pairs()))
         assert got == hexp, G
 
 
@@ -788,12 +813,12 @@ def test_cooperative_fill_forced(monkeypatch):
         monkeypatch.setenv("QE_COOP_FILL_G", G)
         for bw in (10, 15, 40):
             scores, status, cig, cnt = gpu_batch(batch, algo=2, bandwidth=bw)
-            tr = [O.oracle_align(p, t, trace=True, algo=2, bandwidth=bw) for p, t in pairs]
+            tr = [oracle_cached(p, t, trace=True, algo=2, bandwidth=bw) for p, t in pairs]
             assert [(int(a), int(b), c) for a, b, c in zip(status, scores, cig)] == [(x[0], x[1], x[2]) for x in tr], (G, bw)
             assert cnt[1] == sum(x[3]["fill_block_advances"] for x in tr), (G, bw)
         rb = capi.ResidentBatch(batch)
         p = capi.make_params(algo=capi.QUICKED)
-        exp = [O.oracle_align(pt, tt, algo=0) for pt, tt in pairs]
+        exp = [oracle_cached(pt, tt, algo=0) for pt, tt in pairs]
         for rep in range(3):                          # first run: classic flow; then the stage-1 rule on the device
             assert rb.run(p, sync=True) >= 0
             s, st = rb.scores()
@@ -813,7 +838,7 @@ def test_cooperative_fill_forced(monkeypatch):
     al.setAlgorithm(capi.BANDED); al.setBandwidth(30)
     st, out = al.alignBatch(mixed)
     for i, (pp, tt) in enumerate(mixed):
-        est, esc, ecg = O.oracle_align(pp, tt, algo=2, bandwidth=30)
+        est, esc, ecg = oracle_cached(pp, tt, algo=2, bandwidth=30)
         in_domain = est < 0 or O.oracle().qo_exact_distance(pp, len(pp), tt, len(tt)) <= max(len(pp), len(tt)) * 30 // 100
         if in_domain:
             assert out[i] == (est, esc if est >= 0 else out[i][1], ecg if est >= 0 else out[i][2]), i
@@ -911,7 +936,7 @@ def test_long_reads_like_the_reference_suite():
     for batch in (long_few, ont_like):
         scores, status, cig, _ = gpu_batch(batch, algo=0)
         for i, (p, t) in enumerate(batch.pairs()):
-            st, sc, cg = O.oracle_align(p, t, algo=0)
+            st, sc, cg = oracle_cached(p, t, algo=0)
             assert (status[i], scores[i]) == (st, sc)
             assert cig[i] == cg
 
@@ -922,7 +947,7 @@ def test_many_short_pairs():
     scores, status, cig, _ = gpu_batch(batch, algo=0)
     pairs = list(batch.pairs())
     for i in range(0, len(pairs), 97):
-        st, sc, cg = O.oracle_align(*pairs[i], algo=0)
+        st, sc, cg = oracle_cached(*pairs[i], algo=0)
         assert (status[i], scores[i], cig[i]) == (st, sc, cg)
     lib = O.oracle()
     for c, sc in zip(cig[:2000], scores[:2000]):
@@ -960,7 +985,7 @@ def test_pack_boundaries_forward_and_reversed(monkeypatch):
             setattr(al._params, key, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            est, esc, ecg = O.oracle_align(p, t, **kw)
+            est, esc, ecg = oracle_cached(p, t, **kw)
             assert out[i][0] == est, (kw, len(p), len(t))
             if est >= 0:
                 assert out[i][1] == esc, (kw, len(p), len(t))
@@ -992,12 +1017,12 @@ def test_interleaved_batches_and_async_runs():
     cc = rb.cigars()
     ra.sync()
     for i, (p, t) in enumerate(ba.pairs()):
-        st, s, _ = O.oracle_align(p, t, algo=2, only_score=True, bandwidth=15)
+        st, s, _ = oracle_cached(p, t, algo=2, only_score=True, bandwidth=15)
         assert (sta[i], sa[i]) == (st, s), i
     for i, (p, t) in enumerate(bb.pairs()):
-        st, s, cg = O.oracle_align(p, t, algo=0)
+        st, s, cg = oracle_cached(p, t, algo=0)
         assert (stb[i], sb[i], cb[i]) == (st, s, cg), i
-        st, s, cg = O.oracle_align(p, t, algo=3)
+        st, s, cg = oracle_cached(p, t, algo=3)
         assert (stc[i], sc[i], cc[i]) == (st, s, cg), i
     ra.close(); rb.close()
 
@@ -1011,7 +1036,7 @@ def test_sam_cigar_styles_and_device_validator(monkeypatch):
     rb = capi.ResidentBatch(batch)
     for algo in (capi.QUICKED, capi.BANDED, capi.WINDOWED, capi.HIRSCHBERG):
         kw = dict(algo=algo) if algo != capi.WINDOWED else dict(algo=algo, window_size=2)
-        exp = [O.oracle_align(p, t, **kw) for p, t in pairs]
+        exp = [oracle_cached(p, t, **kw) for p, t in pairs]
         for style in (0, 1, 2):
             assert rb.configure(cigar_style=style, check=True) == 0
             assert rb.run(capi.make_params(**kw), sync=True) >= 0
@@ -1025,7 +1050,7 @@ def test_sam_cigar_styles_and_device_validator(monkeypatch):
                 assert ok[i] == 1, (algo, style, i)
     rb.configure(cigar_style=0, check=False)
     # caller-supplied strings: good ones (all three styles), broken ones, missing ones
-    good = [O.oracle_align(p, t, algo=0)[2] for p, t in pairs]
+    good = [oracle_cached(p, t, algo=0)[2] for p, t in pairs]
     assert (rb.validate(good) == 1).all()
     assert (rb.validate([O.sam_cigar(c, True) for c in good]) == 1).all()
     bad = list(good)
@@ -1093,7 +1118,7 @@ def test_packed_wire_batches_equal_ascii_batches(wire, monkeypatch):
             if not kw.get("only_score"):
                 assert ra.cigars() == rp.cigars(), kw
         for i in (0, 1, 17, 44, 89):
-            est, esc, ecg = O.oracle_align(pairs[i][0], pairs[i][1], **kw)
+            est, esc, ecg = oracle_cached(pairs[i][0], pairs[i][1], **kw)
             assert (stp[i], sp[i]) == (est, esc)
     assert rp.configure(cigar_style=1, check=True) == capi.QUICKED_UNIMPLEMENTED
     with pytest.raises(capi.QuickedException):
@@ -1124,9 +1149,9 @@ def test_large_batch_rotates_three_stream_sets():
     rb.close()
     pairs = list(batch.pairs())
     for i in list(range(0, len(pairs), 1009)) + [len(pairs) - 1]:
-        st, sc, _ = O.oracle_align(*pairs[i], algo=2, only_score=True, bandwidth=30)
+        st, sc, _ = oracle_cached(*pairs[i], algo=2, only_score=True, bandwidth=30)
         assert (sta[i], sa[i]) == (st, sc), i
-        st, sc, cg = O.oracle_align(*pairs[i], algo=0)
+        st, sc, cg = oracle_cached(*pairs[i], algo=0)
         assert (stq[i], sq[i], cq[i]) == (st, sc, cg), i
     assert int(sa.astype(np.int64).sum()) == int(sq.astype(np.int64).sum())      # both are the exact distance here
 
@@ -1137,7 +1162,7 @@ def test_quicked_stage3_with_zero_cutoff_terminates():
     p = b"ACGTTGCAAGTCCGATAGCTAGCTAGGATCGATCGGGATATAGCGCATTACGCATCAGC"
     t = b"TTGACCAGTGACAGGGTTTACACAGATTTCCACGCGATACCCAGTTTCACGACAGA"
     kw = dict(algo=0, bandwidth=1, window_size=2, overlap_size=1, hew_threshold=(10, 10), hew_percentage=(15, 15))
-    est, esc, ecg = O.oracle_align(p, t, **kw)
+    est, esc, ecg = oracle_cached(p, t, **kw)
     al = capi.QuickedAligner()
     for k, v in kw.items():
         if k in ("hew_threshold", "hew_percentage"):
@@ -1168,7 +1193,7 @@ def test_async_run_fetch_and_reload():
     s1, st1 = rb.scores()
     cnt = rb.counters()
     for i, (p, t) in enumerate(ba.pairs()):
-        st, s, _ = O.oracle_align(p, t, algo=2, only_score=True, bandwidth=15)
+        st, s, _ = oracle_cached(p, t, algo=2, only_score=True, bandwidth=15)
         assert (st1[i], s1[i]) == (st, s), i
     assert cnt[0] > 0                                                             # block-advances of the fetched run
     # two async runs in flight (the documented limit), fetched in order
@@ -1178,7 +1203,7 @@ def test_async_run_fetch_and_reload():
         s, st = rb.scores()
         cg = rb.cigars()
         for i, (p, t) in enumerate(ba.pairs()):
-            assert (st[i], s[i], cg[i]) == O.oracle_align(p, t, **algo_kw), (algo_kw, i)
+            assert (st[i], s[i], cg[i]) == oracle_cached(p, t, **algo_kw), (algo_kw, i)
     # reload: fewer, longer pairs, then more, shorter ones
     for nb in (bb, bc):
         assert rb.reload(nb) >= 0
@@ -1188,7 +1213,7 @@ def test_async_run_fetch_and_reload():
         cg = rb.cigars()
         assert len(s) == len(nb)
         for i, (p, t) in enumerate(nb.pairs()):
-            assert (st[i], s[i], cg[i]) == O.oracle_align(p, t, algo=0), i
+            assert (st[i], s[i], cg[i]) == oracle_cached(p, t, algo=0), i
     # a fetch with nothing pending is a no-op, not an error
     assert rb.fetch() >= 0
     rb.close()
@@ -1206,7 +1231,7 @@ def test_quicked_device_side_stage1_equals_the_classic_flow(monkeypatch):
     pairs = [pairs[i] for i in order]
     mixed = datagen.PairBatch(*_pools(pairs))
     other = datagen.generate(count=130, length=1100, error=0.07, seed=917)
-    expect = {id(b): [O.oracle_align(p, t, algo=0) for p, t in b.pairs()] for b in (mixed, other)}
+    expect = {id(b): [oracle_cached(p, t, algo=0) for p, t in b.pairs()] for b in (mixed, other)}
     prm = capi.make_params(algo=capi.QUICKED)
 
     def check(rb, b, tag):
@@ -1284,7 +1309,7 @@ def test_cigar_strings_stay_valid_until_free():
             kept.append(C.c_void_p.from_buffer(a, capi.Aligner.cigar.offset).value)
         assert len(set(kept)) == len(kept)
         for addr, (p, t) in zip(kept, pairs):
-            assert C.string_at(addr).decode() == O.oracle_align(p, t, algo=0)[2]
+            assert C.string_at(addr).decode() == oracle_cached(p, t, algo=0)[2]
         assert lib.quicked_free(C.byref(a)) == capi.QUICKED_WIP
         assert not a.cigar
 
@@ -1340,7 +1365,7 @@ def test_wave_formatter_and_wave_join_forced(force, monkeypatch):
         batch = datagen.generate(**gen)
         scores, status, cig, _ = gpu_batch(batch, algo=0)
         for i, (p, t) in enumerate(batch.pairs()):
-            st, sc, cg, tr = O.oracle_align(p, t, trace=True, algo=0)      # the bound of the reference's stages
+            st, sc, cg, tr = oracle_cached(p, t, trace=True, algo=0)      # the bound of the reference's stages
             ops = C.create_string_buffer(len(p) + len(t) + 1)
             n = C.c_int64()
             hst = lib.qo_hirschberg(p, len(p), t, len(t), tr["bound"], 1 << 14, ops, C.byref(n), None)
@@ -1355,7 +1380,7 @@ def test_wave_formatter_and_wave_join_forced(force, monkeypatch):
         for kw in (dict(algo=0), dict(algo=3, bandwidth=20), dict(algo=2, bandwidth=20), dict(algo=1, window_size=2), dict(algo=1)):
             scores, status, cig, _ = gpu_batch(batch, **kw)
             for i, (p, t) in enumerate(batch.pairs()):
-                assert (status[i], scores[i], cig[i]) == O.oracle_align(p, t, **kw), (gen, kw, i)
+                assert (status[i], scores[i], cig[i]) == oracle_cached(p, t, **kw), (gen, kw, i)
     # byte identity with the oracle (same split threshold: the reference's) on ragged / empty / non-ACGT pairs
     pairs = mixed_batch()
     for kw in (dict(algo=0), dict(algo=2), dict(algo=1), dict(algo=3)):
@@ -1364,7 +1389,7 @@ def test_wave_formatter_and_wave_join_forced(force, monkeypatch):
             setattr(al._params, k, v)
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
-            est, esc, ecg = O.oracle_align(p, t, **kw)
+            est, esc, ecg = oracle_cached(p, t, **kw)
             assert out[i][0] == est and (est < 0 or (out[i][1], out[i][2]) == (esc, ecg)), (kw, i)
     rb = capi.ResidentBatch(datagen.generate(count=64, length=1200, error=0.1, seed=934))
     rb.configure(cigar_style=1, check=True)
@@ -1373,7 +1398,7 @@ def test_wave_formatter_and_wave_join_forced(force, monkeypatch):
     assert (rb.check_results() == 1).all()
     rb.close()
     for (p, t), c in zip(datagen.generate(count=64, length=1200, error=0.1, seed=934).pairs(), got):
-        assert c == O.sam_cigar(O.oracle_align(p, t, algo=0)[2], True)
+        assert c == O.sam_cigar(oracle_cached(p, t, algo=0)[2], True)
 
 
 def test_wave_per_alignment_kernel_forced(golden, monkeypatch):
@@ -1399,7 +1424,7 @@ def test_wave_per_alignment_kernel_forced(golden, monkeypatch):
             scores, status, _, cnt = gpu_batch(batch, algo=2, only_score=True, bandwidth=bw)
             adv = 0
             for i, (p, t) in enumerate(pairs):
-                st, sc, _, tr = O.oracle_align(p, t, trace=True, algo=2, only_score=True, bandwidth=bw)
+                st, sc, _, tr = oracle_cached(p, t, trace=True, algo=2, only_score=True, bandwidth=bw)
                 assert (status[i], scores[i]) == (st, sc), (gen, bw, i)
                 adv += tr["score_block_advances"]
             assert cnt[0] == adv, (gen, bw)
@@ -1408,7 +1433,7 @@ def test_wave_per_alignment_kernel_forced(golden, monkeypatch):
     al.setAlgorithm(capi.BANDED); al.setOnlyScore(True)
     st, out = al.alignBatch(pairs)
     for i, (p, t) in enumerate(pairs):
-        est, esc, _ = O.oracle_align(p, t, algo=2, only_score=True)
+        est, esc, _ = oracle_cached(p, t, algo=2, only_score=True)
         assert out[i][0] == est and (est < 0 or out[i][1] == esc), i
 
 
