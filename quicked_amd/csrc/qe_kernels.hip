@@ -2003,7 +2003,7 @@ __global__ __launch_bounds__(256) void k_banded_wave(BandedArgs A) {
 // ===========================================================================
 template <int LG>
 __device__ __forceinline__ u32 grp_ror1(u32 x) {            // lane G g + j <- lane G g + (j + G - 1) % G;  G = 16: row_ror:1, G = 64: wave_ror:1
-    return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, LG == 4 ? 0x121 : 0x13C, 0xf, 0xf, false);
+    return (u32)__builtin_amdgcn_mov_dpp((int)x, LG == 4 ? 0x121 : 0x13C, 0xf, 0xf, false);
 }
 template <int N>
 __device__ __forceinline__ int row_ror_n(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xf, 0xf, false); }
@@ -2381,6 +2381,54 @@ __device__ __forceinline__ void walk_tile_lean(const u64 (&tP)[TW], const u64 (&
     }
 }
 
+// walk_tile_lean for a wave with FEW walkers (k_traceback_sys with 16 lanes per leaf: four walkers per wave): a column whose
+// cell is a plain match continuing a run of matches -- tX = (Pv | Mv inside the band) | ~Eq has a zero at the walker's row --
+// costs ~22 instructions; everything else takes walk_tile_lean's column behind one branch.  Same steps, same runs.
+template <int TW>
+__device__ __forceinline__ void walk_tile_fast(const u64 (&tP)[TW], const u64 (&tM)[TW], const u64 (&tE)[TW], const u64 (&tX)[TW], bool in_tile,
+                                               u32 inb_same, u32 inb_7, int Rb, int& v, int& h, u32& steps, int& nmatch, RunSink& R) {
+#pragma unroll
+    for (int j = TW - 1; j >= 0; --j) {
+        const bool mine = in_tile && (h & (TW - 1)) == j;
+        const int bit = v & 63;
+        const u32 bad = (u32)(tX[j] >> bit) & 1u;
+        const bool slow = mine && (bad != 0 || R.cur_op != (int)OP_M);
+        bool up = false;
+        if (slow) {
+            const u32 inb = (j == TW - 1) ? inb_7 : inb_same;
+            const u32 pb = inb & (u32)(tP[j] >> bit) & 1u;
+            int r = 0, b1 = bit;
+            if (pb != 0) {                            // deletions: Pv bits bit, bit-1, ... while set (v moves up, h stays)
+                const u64 x = tP[j] << (63 - bit);
+                r = min(__clzll((long long)~x), bit + 1);
+                R.emit_run((int)OP_D, r, true);
+                b1 = (bit - r) & 63;
+            }
+            up = r == bit + 1;                        // the run reached the top of the block: next round, same column
+            const bool go = !up;
+            const u32 isI = inb & (u32)(tM[j] >> b1) & 1u;
+            const u32 eq = (u32)(tE[j] >> b1) & 1u;
+            const int op = isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X);
+            if (go && op != R.cur_op) {
+                if (R.cur_len > 0) {
+                    if (R.nruns < R.cap) R.runs[(int64_t)R.nruns * R.stride] = ((u32)R.cur_len << 2) | (u32)R.cur_op;
+                    ++R.nruns;
+                }
+                R.cur_len = 0; R.cur_op = op;
+            }
+            R.cur_len += go ? 1 : 0;
+            nmatch += (go && !isI && eq) ? 1 : 0;
+            v -= r + ((go && !isI) ? 1 : 0);
+            h -= go ? 1 : 0;
+            steps += (u32)r + (go ? 1u : 0u);
+        }
+        const int f = (mine && !slow) ? 1 : 0;        // a match that continues a run of matches
+        R.cur_len += f; nmatch += f; v -= f; h -= f; steps += (u32)f;
+        in_tile = in_tile && !up && v >= 0 && (v >> 6) == Rb;
+        asm("" : "+v"(v), "+v"(h));                   // (see walk_tile_lean)
+    }
+}
+
 // ===========================================================================
 // BandEd traceback (bpm_banded.c:967-1036): priority D -> I -> M/X.  One lane per task walks its own
 // path.  The fill left a checkpoint {Pv, Mv} every QE_CP_COLS (16) columns and the carry-in words of every
@@ -2634,6 +2682,10 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
             // the row the band bookkeeping creates at the end of a chunk: Pv = ~0, Mv = 0 (bpm_banded.c:910)
             if (act && (Rb - (k - G.prolog)) == cl_b + 1 && (q & (64 / TW - 1)) == 64 / TW - 1) tP[TW - 1] = QE_ONES;
         }
+        // 16 lanes per leaf (four walkers per wave): where the walker's cell is anything but a plain match
+        u64 tX[TW];
+#pragma unroll
+        for (int c = 0; c < TW; ++c) tX[c] = (LG == 4) ? ((((c == TW - 1) ? inb_7 : inb_same) ? (tP[c] | tM[c]) : (u64)0) | ~tE[c]) : (u64)0;
         // the walk, tile by tile in path order
         bool first_phase = true;
         while (true) {
@@ -2641,7 +2693,8 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
             const u64 bal = __ballot(mine);
             const u32 grp = (u32)(bal >> gl) & ((1u << GL) - 1u);
             if (!__any(grp != 0)) break;
-            walk_tile_lean<TW>(tP, tM, tE, mine, inb_same, inb_7, Rb, v, h, steps, nmatch, R);
+            if (LG == 4) walk_tile_fast<TW>(tP, tM, tE, tX, mine, inb_same, inb_7, Rb, v, h, steps, nmatch, R);
+            else walk_tile_lean<TW>(tP, tM, tE, mine, inb_same, inb_7, Rb, v, h, steps, nmatch, R);
             if (grp != 0) {                                         // (uniform over the lanes of a group)
                 const int own = gl | (__ffs((int)grp) - 1);
                 v = __shfl(v, own); h = __shfl(h, own); steps = (u32)__shfl((int)steps, own); nmatch = __shfl(nmatch, own);
@@ -3107,7 +3160,7 @@ __global__ __launch_bounds__(512) void k_windowed_cp(WindowArgs A) { windowed_bo
 // k_windowed takes it up from WindowArgs::state.
 // ===========================================================================
 __device__ __forceinline__ u32 quad_ror1(u32 x) {           // lane 4 q + j <- lane 4 q + (j + 3) % 4
-    return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x93, 0xf, 0xf, false);
+    return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x93, 0xf, 0xf, false);
 }
 // block_step on a 32-bit block (bitop3 forms as in block_step_core); ph / mh = the pre-shift horizontal deltas
 __device__ __forceinline__ void sub_step(u32 e, u32& P, u32& M, u32 PHin, u32 MHin, u32& ph, u32& mh) {
