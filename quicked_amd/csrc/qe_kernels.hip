@@ -3162,32 +3162,9 @@ __global__ __launch_bounds__(512) void k_windowed_cp(WindowArgs A) { windowed_bo
 __device__ __forceinline__ u32 quad_ror1(u32 x) {           // lane 4 q + j <- lane 4 q + (j + 3) % 4
     return (u32)__builtin_amdgcn_mov_dpp((int)x, 0x93, 0xf, 0xf, false);
 }
-// block_step on a 32-bit block (bitop3 forms as in block_step_core); ph / mh = the pre-shift horizontal deltas
-__device__ __forceinline__ void sub_step(u32 e, u32& P, u32& M, u32 PHin, u32 MHin, u32& ph, u32& mh) {
-    const u32 xv = e | M;
-    const u32 ec = e | MHin;
-    const u32 sum = (ec & P) + P;
-    ph = bitop3<0xF3>(M, bitop3<0xFE>(sum, P, ec), 0u);           // M | ~(sum | P | Eqc)
-    mh = bitop3<0xB0>(P, sum, ec);                                // P & ((sum ^ P) | Eqc)
-    const u32 phs = (ph << 1) | PHin, mhs = (mh << 1) | MHin;
-    P = bitop3<0xF1>(mhs, xv, phs);                               // Mhs | ~(Xv | Phs)
-    M = phs & xv;
-}
-// one column of a lane's block: text bit `bit` of the lane's words (t0w, t1w), Eq masked by emask
-template <bool STORE>
-__device__ __forceinline__ void quad_col(u32 t0w, u32 t1w, int bit, u32 emask, u32 a, u32 b, u32& P, u32& M, u32 inP, u32 inM,
-                                         u32& oP, u32& oM, uint2* st) {
-    const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0w, bit, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1w, bit, 1);
-    const u32 e = bitop3<0x90>(~(a ^ m0), b, m1) & emask;
-    const u32 Mb = M;
-    u32 ph, mh;
-    sub_step(e, P, M, inP, inM, ph, mh);
-    oP = ph >> 31; oM = mh >> 31;
-    if (STORE) *st = make_uint2(P, Mb);
-}
-
-// the same with the carries travelling as the RAW pre-shift delta words (bit 31 = the carry): the producer extracts nothing,
-// the consumer's "(Ph << 1) | PHin" is one v_alignbit with the incoming word; MHin arrives as a clean 0 / 1
+// One column of a lane's 32-bit block: block_step on 32-bit words (bitop3 forms as in block_step_core), text bit `bit` of the
+// lane's words (t0w, t1w), Eq masked by emask.  The carries travel as the RAW pre-shift delta words (bit 31 = the carry): the
+// producer extracts nothing, the consumer's "(Ph << 1) | PHin" is one v_alignbit with the incoming word; MHin arrives as a clean 0 / 1
 template <bool STORE>
 __device__ __forceinline__ void quad_col_w(u32 t0w, u32 t1w, int bit, u32 emask, u32 a, u32 b, u32& P, u32& M, u32 inPw, u32 MHin,
                                            u32& oPw, u32& oMw, uint2* st) {
