@@ -243,7 +243,30 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
             for (size_t t : idx3) B.note_pair(L.pair[t], 7, 1);
             // band doubling (quicked.c:248-278): relaunch on the subset that has not converged
             int rounds = 0;
+            bool device_tried = false;
             while (!idx3.empty()) {
+                if (!device_tried) {
+                    // all doubling rounds in one launch where every task can have a wave (the pairs a run left: a few hundred),
+                    // the convergence test on the device; what comes back flagged continues below from the cutoff it had reached
+                    device_tried = true;
+                    L3.pad();
+                    std::vector<int32_t> dsc, dfl, dcut; std::vector<u32> dadv;
+                    qe_timer_start(tl_timers.banded);
+                    const bool ran = stage3_on_device(B, C, L3, dsc, dadv, dfl, dcut);
+                    qe_timer_stop(tl_timers.banded);
+                    if (ran) {
+                        TaskList Ln; std::vector<size_t> idxn;
+                        for (size_t k = 0; k < idx3.size(); ++k) {
+                            const size_t t = idx3[k];
+                            B.counters[0] += (int64_t)dadv[k];
+                            B.note_pair(L3.pair[k], 0, (int64_t)dadv[k]);
+                            if (dfl[k]) { Ln.push(L.pair[t], 0, L.m[t], 0, L.n[t], dcut[k], L.n[t]); idxn.push_back(t); }
+                            else bound[t] = dsc[k];
+                        }
+                        L3 = Ln; idx3 = idxn;
+                        continue;
+                    }
+                }
                 if (++rounds > 40) {      // cutoffs double from >= 1: 40 rounds cannot happen for int32 lengths
                     for (size_t k = 0; k < idx3.size() && k < 8; ++k)
                         fprintf(stderr, "[quicked_hip] stage 3 does not converge: pair %d m %d n %d cutoff %d\n",

@@ -2033,17 +2033,34 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
         tp = A.P.pl_t + A.P.pl_t_off[pair];
         fl = A.P.flags[pair];
     }
-    const Geom G = band_geometry(m, n, cut_in);
     const int nw = (m + 63) >> 6;
-    const int nsl = FILL ? G.ebb : ((G.cutoff + 63) >> 6) + 1;    // the score-only kernels' own band (bpm_banded.c:801-803)
-    const bool ok = valid && (fl & FLAG_HAS_N) == 0 && nsl <= GM && tfin == n;
-    if (valid && j == 0) A.o_abort[t] = ok ? 0 : 1;
-    if (!__any(ok)) return;
     const int stop_row = FILL ? nw - 1 : nw;                       // bpm_banded.c:295 / 917
     const u64 lvl_mask = (m & 63) ? (((u64)1 << (m & 63)) - 1) : QE_ONES;     // rows of the last block up to the pattern's end
+    u32 adv = 0;
+    // A.doubling (score-only): QuickEd's stage-3 loop (quicked.c:248-278) on the device -- while the pass's score says the
+    // cutoff was too small ((score > max_len / 4 && cutoff * 3 / 2 < score) || score < 0) the cutoff doubles and the pass runs
+    // again, in this launch, every task at its own pace; a task whose doubled band no longer fits the group's lanes is
+    // handed back with the cutoff it was about to run (o_cutoff) and the block-advances it has counted so far
+    int cut_cur = cut_in;
+    bool want = valid;
+    for (;;) {
+    const Geom G = band_geometry(m, n, cut_cur);
+    const int nsl = FILL ? G.ebb : ((G.cutoff + 63) >> 6) + 1;    // the score-only kernels' own band (bpm_banded.c:801-803)
+    const bool elig = (fl & FLAG_HAS_N) == 0 && nsl <= GM && tfin == n;
+    const bool ok = want && elig;
+    if (want && !elig) {
+        u32 asum = adv;
+#pragma unroll
+        for (int o = GL / 2; o > 0; o >>= 1) asum += __shfl_xor(asum, o);
+        if (j == 0) {
+            A.o_abort[t] = 1;
+            if (A.o_cutoff) { A.o_cutoff[t] = cut_cur; A.o_adv[t] = asum; }
+        }
+        want = false;
+    }
+    if (!__any(ok)) break;
     int first = G.prolog, last = nsl - 1, pos_v = -G.prolog, pos_h = 0;
     int max_row_init = nsl - 1;
-    u32 adv = 0;
 
     const int g = ok ? (t >> 6) : 0, col = t & 63;
     int gns = 0, gnch = 0;
@@ -2195,20 +2212,36 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
     }
     // final score read-out (bpm_banded.c:952-961)
     const int s_last = __shfl(sc, gl | ((nw - 1) & GM));
+    u32 asum = adv;
 #pragma unroll
-    for (int o = GL / 2; o > 0; o >>= 1) adv += __shfl_xor(adv, o);
-    if (ok && j == 0) {
+    for (int o = GL / 2; o > 0; o >>= 1) asum += __shfl_xor(asum, o);
+    if (ok) {
         int score = -1;
         if (nw - 1 <= max_row_init) {
             score = s_last;
             if (m & 63) score -= 64 - (m & 63);
         }
-        A.o_score[t] = score;
-        A.o_first[t] = first;
-        A.o_last[t] = last;
-        A.o_posv[t] = pos_v;
-        A.o_maxrow[t] = max_row_init;
-        A.o_adv[t] = adv;
+        bool again = false;
+        if (!FILL && A.doubling) {
+            const int mx = max(m, n);
+            again = (score > mx / 4 && (int64_t)cut_cur * 3 / 2 < (int64_t)score) || score < 0;
+        }
+        if (again) cut_cur = (int)min((int64_t)max(cut_cur, 0) * 2 + (cut_cur <= 0 ? 1 : 0), (int64_t)1 << 30);      // a cutoff of 0 doubles to 1 (oracle header)
+        else {
+            want = false;
+            if (j == 0) {
+                A.o_abort[t] = 0;
+                A.o_score[t] = score;
+                A.o_first[t] = first;
+                A.o_last[t] = last;
+                A.o_posv[t] = pos_v;
+                A.o_maxrow[t] = max_row_init;
+                A.o_adv[t] = asum;
+                if (A.o_cutoff) A.o_cutoff[t] = cut_cur;
+            }
+        }
+    }
+    if (FILL || !A.doubling) break;
     }
 }
 template __global__ void k_banded_sys<4, true>(BandedArgs);

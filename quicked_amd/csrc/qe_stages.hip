@@ -490,6 +490,34 @@ static int sys_score_lanes(const TaskList& L, int in_flight) {
     return (env == 1 || nt * fl <= 1100) ? 6 : 0;
 }
 
+// QuickEd's stage 3 (quicked.c:248-278) in ONE launch: k_banded_sys<.., false> with the band doubling on the device.  Every
+// task comes back either converged (score = the exact distance within its last cutoff) or flagged with the cutoff it was about
+// to run (its band outgrew the group's lanes, N symbols): the host's rounds take those from there.  false: not tried
+// (too many tasks for a wave each).  QE_STAGE3_DEVICE = 0 / 1: never / whenever the list is not empty (tests)
+static bool stage3_on_device(quicked_batch& B, Context& C, const TaskList& L, std::vector<int32_t>& score, std::vector<u32>& adv,
+                             std::vector<int32_t>& flagged, std::vector<int32_t>& cutoff) {
+    const int env = env_int("QE_STAGE3_DEVICE", -1);
+    if (env == 0) return false;
+    size_t live = 0;
+    for (int32_t pr : L.pair) live += pr >= 0;
+    if (live == 0 || (env != 1 && L.pair.size() > 1100)) return false;
+    const size_t nt = L.pair.size();
+    const DevTasks T = upload_tasks(L, C);
+    const TaskOut O = take_out(C, nt);
+    int32_t* d_cut = C.scratch_p->take<int32_t>(nt);
+    HIP_CHECK(hipMemsetAsync(O.hew, 0, nt * sizeof(int32_t), C.stream));
+    BandedArgs a;
+    a.P = pair_view(B, false); a.T = T.v;
+    a.ws = nullptr; a.g_ws_off = nullptr; a.g_nslots = nullptr; a.g_nrows = nullptr; a.g_nch = nullptr;
+    a.mat = nullptr; a.g_mat_off = nullptr;
+    a.o_score = O.score; a.o_first = O.first; a.o_last = O.last; a.o_posv = O.posv; a.o_adv = O.adv; a.o_maxrow = O.len;
+    a.only_if = nullptr; a.o_abort = O.hew; a.doubling = 1; a.o_cutoff = d_cut;
+    launch_groups(C, k_banded_sys<6, false>, a, nt, 4, 0, false, (size_t)40 * 1024);
+    d2h(score, O.score, nt, C.stream); d2h(adv, O.adv, nt, C.stream); d2h(flagged, O.hew, nt, C.stream); d2h(cutoff, d_cut, nt, C.stream);
+    HIP_CHECK(hipStreamSynchronize(C.stream));
+    return true;
+}
+
 static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, StageResult* R,
                              bool fetch, int32_t** d_score_out, PendingFetch* pf = nullptr) {
     // one wavefront per alignment only where the cooperative on-chip form has no room (a band of fewer than 8 slots): with

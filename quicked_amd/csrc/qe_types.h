@@ -84,6 +84,8 @@ struct BandedArgs {
     int32_t fill_multi = 1;  // fill: K-slot skewed passes where no lane needs the general form (0: single-slot passes only; tests)
     int32_t lane_rel = 1;    // every lane walks ITS band (slot first + j at step j of a chunk) instead of the wave walking the union of its lanes' bands (0: tests)
     int32_t* o_abort = nullptr;   // k_banded_sys: 1 where a task is left to k_banded<true> (N in the pair, a band of more than 15 slots)
+    int32_t doubling = 0;         // k_banded_sys<.., false>: QuickEd's stage-3 band doubling in the launch (quicked.c:248-278)
+    int32_t* o_cutoff = nullptr;  // ... the cutoff of every task's last pass (or, flagged, of the pass it was handed back before)
 };
 
 // BandEd score-only, G lanes per alignment (cooperative form of k_banded<false>)

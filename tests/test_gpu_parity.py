@@ -693,6 +693,53 @@ def test_score_systolic_forced(ssys, golden, monkeypatch):
         assert cnt[0] == sum(oracle_cached(p, t, trace=True, algo=2, only_score=True, bandwidth=bw)[3]["score_block_advances"] for p, t in b.pairs())
 
 
+@pytest.mark.parametrize("dev", ["1", "0"])
+def test_stage3_band_doubling_on_the_device(dev, golden, monkeypatch):
+    """QuickEd's stage 3 (quicked.c:248-278: score-only BandEd, the cutoff doubled while the score says it was too small) as
+    ONE launch with the convergence test on the device (k_banded_sys<6, false> with `doubling`; QE_STAGE3_DEVICE = 1) against
+    the host-driven rounds (0): statuses, scores and CIGAR bytes of the compiled reference on the indel goldens, the oracle
+    on pairs whose bounds need several doublings (HEW parameters that send everything to stage 3, small bandwidths so that
+    the first cutoffs are far too small), ragged / N input (flagged tasks continue on the host), and the work counters --
+    block advances summed over every round, pairs that reached stage 3."""
+    monkeypatch.setenv("QE_STAGE3_DEVICE", dev)
+    for name in ("indel_10kb", "cfg1_1kb_5pct"):
+        entry = golden["datasets"][name]
+        batch = datagen.generate(**entry["gen"])
+        for label, run in entry["runs"].items():
+            if run["params"].get("algo") != 0:
+                continue
+            scores, status, cig, _ = gpu_batch(batch, **run["params"])
+            assert status.tolist() == run["status"], (name, label)
+            assert scores.tolist() == run["score"], (name, label)
+            if "cigar_sha256" in run:
+                assert [sha(c) for c in cig] == run["cigar_sha256"], (name, label)
+    rng = np.random.default_rng(31)
+    pairs = mixed_batch()
+    for i in range(56):
+        L = int(rng.choice([300, 1000, 2500, 6000, 9000]))
+        e = float(rng.choice([0.02, 0.1, 0.3]))
+        b = datagen.generate(1, L, e, seed=3100 + i, indels_num=int(rng.integers(0, 4)) if L >= 2500 else 0, indels_len=int(rng.choice([100, 400, 900])))
+        pairs.append(next(b.pairs()))
+    for kw in (dict(algo=0, hew_threshold=(1, 1), hew_percentage=(1, 1), bandwidth=1),
+               dict(algo=0, hew_threshold=(1, 1), hew_percentage=(1, 1), bandwidth=5),
+               dict(algo=0, hew_threshold=(10, 10), hew_percentage=(1, 1)), dict(algo=0)):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            if k in ("hew_threshold", "hew_percentage"):
+                getattr(al._params, k)[0], getattr(al._params, k)[1] = v
+            else:
+                setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            assert out[i] == oracle_cached(p, t, **kw), (dev, kw, i, len(p), len(t))
+    b = datagen.generate(48, 5000, 0.05, seed=32, indels_num=3, indels_len=500)
+    kw = dict(algo=0, bandwidth=2)
+    _, _, _, cnt = gpu_batch(b, **kw)
+    tr = [oracle_cached(p, t, trace=True, **kw)[3] for p, t in b.pairs()]
+    assert cnt[0] == sum(x["score_block_advances"] for x in tr), (dev, int(cnt[0]))
+    assert cnt[7] == sum(1 for x in tr if x["stage"] >= 3) and cnt[7] > 0
+
+
 @pytest.mark.parametrize("tall", ["1", "0"])
 def test_tall_band_cooperative_fill(tall, monkeypatch):
     """QuickEd's align step on pairs with LARGE bounds (large indels: bands of 30-50 slots) in a launch of few waves: the
