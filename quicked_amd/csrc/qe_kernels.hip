@@ -2249,6 +2249,210 @@ template __global__ void k_banded_sys<6, true>(BandedArgs);
 template __global__ void k_banded_sys<4, false>(BandedArgs);
 template __global__ void k_banded_sys<6, false>(BandedArgs);
 
+// ===========================================================================
+// k_banded_sys<6, ..> for bands of 64 .. 127 slots (k_banded_sys2): ONE WAVE PER TASK, TWO ROWS PER LANE.  Lane j holds the
+// band's rows r = j (mod 64) in two layers (layer = bit 6 of r: two rows of one lane are 64 apart, and a band of < 128
+// slots holds at most one of each); a chunk is walked in two SWEEPS of up to 64 rows -- band rows 0 .. 63, then 64 .. H - 1 --
+// each the systolic array of k_banded_sys.  Between the sweeps travels what travels between passes of k_banded: the 64
+// carry-out bits of row 63 as a carry word (collected by its lane, handed to the lane of row 64) and the sum of its deltas
+// for the scores[] chain.  The top row of a sweep takes its carries from a per-step select (the boundary (1, 0), or the
+// carry word's bit) instead of an idle lane.  Same cells, same bookkeeping (bpm_banded.c:264-301 / 889-922), same outputs
+// and layout as k_banded_sys; the bounds of pairs with several large indels (QuickEd's leaves and stage-3 passes there)
+// and wide user bandwidths.
+// ===========================================================================
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_banded_sys2(BandedArgs A) {
+    constexpr int GL = 64, GM = 63;
+    const int t = QE_GROUP_INDEX(), j = threadIdx.x & 63;
+    if (t >= A.T.ntasks) return;
+    int pair = A.T.pair[t];
+    if (A.only_if != nullptr && pair >= 0 && A.only_if[t] == 0) pair = -1;
+    if (pair < 0) return;                                          // (wave-uniform: one task per wave)
+    const int m = A.T.m[t], n = A.T.n[t], p0 = A.T.p0[t], t0 = A.T.t0[t], cut_in = A.T.cutoff[t];
+    const int tfin = FILL ? n : A.T.tfin[t];
+    const u64* pp = A.P.pl_p + A.P.pl_p_off[pair];
+    const u64* tp = A.P.pl_t + A.P.pl_t_off[pair];
+    const u32 fl = A.P.flags[pair];
+    const Geom G = band_geometry(m, n, cut_in);
+    const int nw = (m + 63) >> 6;
+    const int nsl = FILL ? G.ebb : ((G.cutoff + 63) >> 6) + 1;
+    const bool ok = (fl & FLAG_HAS_N) == 0 && nsl <= 2 * GL - 1 && tfin == n;
+    if (j == 0) A.o_abort[t] = ok ? 0 : 1;
+    if (!ok) return;
+    const int stop_row = FILL ? nw - 1 : nw;
+    const u64 lvl_mask = (m & 63) ? (((u64)1 << (m & 63)) - 1) : QE_ONES;
+    int first = G.prolog, last = nsl - 1, pos_v = -G.prolog, pos_h = 0;
+    int max_row_init = nsl - 1;
+    u32 adv = 0;
+    const int g = t >> 6, col = t & 63;
+    int gns = 0, gnch = 0;
+    int16_t* cf = nullptr; int16_t* cl = nullptr;
+    uint4* cp = nullptr; uint4* hw = nullptr;
+    int64_t cps = 0;
+    if (FILL) {
+        gns = A.g_nslots[g]; gnch = A.g_nch[g];
+        const GroupWs W = group_ws(A.ws, A.g_ws_off[g], gns, A.g_nrows[g], gnch);
+        cf = W.cf + col; cl = W.cl + col;
+        cp = A.mat + A.g_mat_off[g] + col;
+        cps = (int64_t)gns * 64;
+        hw = cp + (int64_t)QE_CPC * gnch * cps;
+    }
+    // bpm_reset_search: lane j holds row j (layer 0) and row j + 64 (layer 1)
+    u32 L0Plo = ~0u, L0Phi = ~0u, L0Mlo = 0, L0Mhi = 0, L1Plo = ~0u, L1Phi = ~0u, L1Mlo = 0, L1Mhi = 0;
+    int L0sc = 64 * (j + 1), L1sc = 64 * (j + 65);
+    u64 L0pa = 0, L0pb = 0, L1pa = 0, L1pb = 0;
+    if (FILL) {
+        if (j < nsl) cp[(int64_t)j * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+        if (j + 64 < nsl) cp[(int64_t)(j + 64) * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+        if (j == 0) { cf[0] = (int16_t)first; cl[0] = (int16_t)last; }
+    }
+    if (j < nw) load_planes_ab(pp, p0 + 64 * j, L0pa, L0pb);
+    if (j + 64 < nw) load_planes_ab(pp, p0 + 64 * (j + 64), L1pa, L1pb);
+    const int nfull = n >> 6, tail = n & 63;
+    const int nchunks = nfull + (tail ? 1 : 0);
+    u64 nT0 = 0, nT1 = 0;
+    load_planes_ab(tp, t0, nT0, nT1);
+
+    for (int k = 0; k < nchunks; ++k) {
+        const int ncols = (k < nfull) ? 64 : tail;
+        const u64 T0 = nT0, T1 = nT1;
+        if (k + 1 < nchunks) load_planes_ab(tp, t0 + 64 * (k + 1), nT0, nT1);
+        const int r_first = first + pos_v;
+        const int rhi = min(last, nw - 1 - pos_v);
+        const int H = rhi - first + 1;                             // rows computed in this chunk (wave-uniform)
+        u64 qa = 0, qb = 0;
+        const int new_row = last + pos_v + 1;
+        if (ncols == 64 && ((new_row & GM) == j) && new_row < nw) load_planes_ab(pp, p0 + 64 * new_row, qa, qb);
+        const int nsweeps = H > GL ? 2 : 1;
+        u64 cwP = 0, cwM = 0;                                      // carry words into sweep 1's top row, bit c = column c
+        int base_delta = ncols;                                    // sum of the carry-ins of the sweep's top row
+#pragma unroll 1
+        for (int q = 0; q < nsweeps; ++q) {
+            const int i_in = (j - (r_first + q * GL)) & GM;        // this lane's row of the sweep, counted from its top
+            const int i = q * GL + i_in, si = first + i, my_row = r_first + i;
+            const bool inband = si <= rhi;
+            const bool lay = ((my_row >> 6) & 1) != 0;
+            u32 Plo = lay ? L1Plo : L0Plo, Phi = lay ? L1Phi : L0Phi, Mlo = lay ? L1Mlo : L0Mlo, Mhi = lay ? L1Mhi : L0Mhi;
+            int sc = lay ? L1sc : L0sc;
+            const u64 pa = lay ? L1pa : L0pa, pb = lay ? L1pb : L0pb;
+            const u64 R0 = i_in ? ((T0 << i_in) | (T0 >> (64 - i_in))) : T0, R1 = i_in ? ((T1 << i_in) | (T1 >> (64 - i_in))) : T1;
+            const u64 vm = (my_row == nw - 1) ? lvl_mask : QE_ONES;
+            const int Vb = __popcll(mk64(Plo, Phi) & vm) - __popcll(mk64(Mlo, Mhi) & vm);
+            const u32 alo = lo32(pa), ahi = hi32(pa), blo = lo32(pb), bhi = hi32(pb);
+            u64 gP = 0, gM = 0, gOP = 0, gOM = 0;                  // this row's carry-ins / carry-outs, shifted in from the right
+            u32 oP = 0, oM = 0;
+            const bool top = i_in == 0;
+            const u32 len = inband ? (u32)ncols : 0u;
+            const int Hq = min(H - q * GL, GL);
+            const int nsteps = 64 + Hq - 1;
+            const bool more = q + 1 < nsweeps;
+            uint4* const cpk = FILL ? cp + (int64_t)(QE_CPC * k) * cps + (int64_t)si * 64 : nullptr;
+#pragma unroll 1
+            for (int blk = 0; blk < 4; ++blk) {
+                if (32 * blk >= nsteps) break;
+                const u32 w0 = (blk & 1) ? hi32(R0) : lo32(R0), w1 = (blk & 1) ? hi32(R1) : lo32(R1);
+                // the top row's carries: the band's boundary (1, 0) in sweep 0, row 63's carry words in sweep 1 (column = step)
+                const u32 twP = q ? ((blk == 0) ? lo32(cwP) : ((blk == 1) ? hi32(cwP) : 0u)) : ~0u;
+                const u32 twM = q ? ((blk == 0) ? lo32(cwM) : ((blk == 1) ? hi32(cwM) : 0u)) : 0u;
+#pragma unroll
+                for (int sb = 0; sb < 32; ++sb) {
+                    const int s = 32 * blk + sb;
+                    if (s >= nsteps) continue;
+                    u32 inP = grp_ror1<6>(oP), inM = grp_ror1<6>(oM);
+                    inP = top ? __builtin_amdgcn_ubfe(twP, sb, 1) : inP;
+                    inM = top ? __builtin_amdgcn_ubfe(twM, sb, 1) : inM;
+                    const u32 c = (u32)(s - i_in);
+                    if (c < len) {
+                        const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)w0, sb, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)w1, sb, 1);
+                        const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1), ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
+                        u32 phhi, mhhi;
+                        block_step_core(elo, ehi, Plo, Phi, Mlo, Mhi, inP, inM, phhi, mhhi);
+                        oP = phhi >> 31; oM = mhhi >> 31;
+                        if (more) { gOP = shl1_add_u64(gOP, (u64)oP); gOM = shl1_add_u64(gOM, (u64)oM); }
+                        if (FILL) {
+                            gP = shl1_add_u64(gP, (u64)inP); gM = shl1_add_u64(gM, (u64)inM);
+                            if ((c & (QE_CP_COLS - 1)) == QE_CP_COLS - 1 && c != 63)
+                                cpk[(int64_t)((c >> 4) + 1) * cps] = make_uint4(Plo, Phi, Mlo, Mhi);
+                        }
+                    }
+                }
+            }
+            if (FILL && inband && ncols == 64 && si > 0) cpk[(int64_t)QE_CPC * cps - 64] = make_uint4(Plo, Phi, Mlo, Mhi);
+            const int sh = 64 - ncols;
+            if (inband) {
+                if (FILL) {
+                    const u64 xP = __builtin_bitreverse64(sh ? (gP << sh) : gP), xM = __builtin_bitreverse64(sh ? (gM << sh) : gM);
+                    hw[((int64_t)k * gns + si) * 64] = make_uint4(lo32(xP), hi32(xP), lo32(xM), hi32(xM));
+                }
+                adv += (u32)ncols;
+            }
+            // scores[]: the sweep's rows from the sum of its top row's carry-ins down
+            const int Va = __popcll(mk64(Plo, Phi) & vm) - __popcll(mk64(Mlo, Mhi) & vm);
+            int x = inband ? Va - Vb : 0;
+#pragma unroll
+            for (int d = 1; d < GL; d <<= 1) { const int y = __shfl(x, (j - d) & GM); if (i_in >= d) x += y; }
+            const int dl = base_delta + x;                         // this row's sum of exported deltas
+            if (inband) sc += dl;
+            if (more) {
+                // to sweep 1: row 63's carry-outs and the sum of its deltas
+                const int src = (r_first + GL - 1) & GM;
+                const u64 oPn = __builtin_bitreverse64(sh ? (gOP << sh) : gOP), oMn = __builtin_bitreverse64(sh ? (gOM << sh) : gOM);
+                cwP = mk64((u32)__shfl((int)lo32(oPn), src), (u32)__shfl((int)hi32(oPn), src));
+                cwM = mk64((u32)__shfl((int)lo32(oMn), src), (u32)__shfl((int)hi32(oMn), src));
+                base_delta = __shfl(dl, src);
+            }
+            if (lay) { L1Plo = Plo; L1Phi = Phi; L1Mlo = Mlo; L1Mhi = Mhi; L1sc = sc; }
+            else { L0Plo = Plo; L0Phi = Phi; L0Mlo = Mlo; L0Mhi = Mhi; L0sc = sc; }
+        }
+        {
+            // every-64-columns bookkeeping (bpm_banded.c:264-301 / 889-922)
+            auto row_sc = [&](int row) {
+                const int a0 = __shfl(L0sc, row & GM), a1 = __shfl(L1sc, row & GM);
+                return ((row >> 6) & 1) ? a1 : a0;
+            };
+            const int s_top1 = row_sc(r_first + 1), s_bot = row_sc(last + pos_v), s_bot1 = row_sc(last + pos_v - 1);
+            if (ncols == 64) {
+                const bool c1 = (first + 2 < last) && (G.fin > 64 * (first + 1));
+                const bool cut_lo = c1 && (s_top1 + (G.fin - 64 * (first + 1)) > G.cutoff);
+                if (cut_lo && pos_h >= G.prolog) first++;
+                else if (!cut_lo && pos_h < G.prolog) first--;
+                const int pos = last + pos_v;
+                if (((pos + 1) & GM) == j) {                       // the new bottom row is this lane's, in the layer of its bit 6
+                    if (((pos + 1) >> 6) & 1) { L1Plo = ~0u; L1Phi = ~0u; L1Mlo = 0; L1Mhi = 0; L1sc = s_bot + 64; L1pa = qa; L1pb = qb; }
+                    else { L0Plo = ~0u; L0Phi = ~0u; L0Mlo = 0; L0Mhi = 0; L0sc = s_bot + 64; L0pa = qa; L0pb = qb; }
+                    if (FILL) cp[(int64_t)(QE_CPC * k + QE_CPC) * cps + (int64_t)last * 64] = make_uint4(~0u, ~0u, 0u, 0u);
+                }
+                max_row_init = max(max_row_init, pos + 1);
+                const bool c2 = (first + 2 < last) && (64 * (last - 1) > G.fin);
+                const bool cut_hi = c2 && (s_bot1 + (64 * (last - 1) - G.fin) > G.cutoff);
+                if (cut_hi || (pos_v + last >= stop_row)) last--;
+                pos_v++;
+                pos_h++;
+                if (FILL && j == 0) { cf[(int64_t)pos_h * 64] = (int16_t)first; cl[(int64_t)pos_h * 64] = (int16_t)last; }
+            }
+        }
+    }
+    const int row = nw - 1;
+    const int a0 = __shfl(L0sc, row & GM), a1 = __shfl(L1sc, row & GM);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) adv += __shfl_xor(adv, o);
+    if (j == 0) {
+        int score = -1;
+        if (row <= max_row_init) {
+            score = ((row >> 6) & 1) ? a1 : a0;
+            if (m & 63) score -= 64 - (m & 63);
+        }
+        A.o_score[t] = score;
+        A.o_first[t] = first;
+        A.o_last[t] = last;
+        A.o_posv[t] = pos_v;
+        A.o_maxrow[t] = max_row_init;
+        A.o_adv[t] = adv;
+    }
+}
+template __global__ void k_banded_sys2<true>(BandedArgs);
+template __global__ void k_banded_sys2<false>(BandedArgs);
+
 // ---------------------------------------------------------------------------
 // RLE emitter shared by the tracebacks: ops arrive back to front
 // ---------------------------------------------------------------------------

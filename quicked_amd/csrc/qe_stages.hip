@@ -451,6 +451,8 @@ static ScoreLaunch launch_banded_sys(quicked_batch& B, Context& C, const TaskLis
     ScoreLaunch S;
     S.nt = L.pair.size();
     const BandLayout lay = band_layout(L, false, false);
+    int max_nsl = 0;
+    for (int32_t v : lay.nslots) max_nsl = std::max(max_nsl, (int)v);
     S.T = upload_tasks(L, C);
     S.D = upload_layout(lay, C);
     S.O = take_out(C, S.nt);
@@ -467,6 +469,7 @@ static ScoreLaunch launch_banded_sys(quicked_batch& B, Context& C, const TaskLis
     if (lg == 4) launch_groups(C, k_banded_sys<4, false>, a, S.nt / 4, 4, 0, false, (size_t)40 * 1024);
     else launch_groups(C, k_banded_sys<6, false>, a, S.nt, 4, 0, false, (size_t)40 * 1024);
     a.only_if = S.O.hew;
+    if (lg == 6 && max_nsl > 63) launch_groups(C, k_banded_sys2<false>, a, S.nt, 4, 0, false, (size_t)40 * 1024);      // bands of 64 .. 127 slots
     launch_groups(C, k_banded<false>, a, L.ngroups(), 8, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
@@ -484,7 +487,7 @@ static int sys_score_lanes(const TaskList& L, int in_flight) {
         if (L.tfin[t] != L.n[t]) return 0;                  // a stopped band is exported in k_banded's layout (Hirschberg half passes)
         max_nsl = std::max(max_nsl, host_geometry(L.m[t], L.n[t], L.cutoff[t]).ebb_local);
     }
-    if (live == 0 || max_nsl > 63) return 0;
+    if (live == 0 || max_nsl > 127) return 0;
     const size_t nt = L.pair.size(), fl = (size_t)std::max(1, in_flight);
     if (max_nsl <= 15) return (env == 1 || nt / 4 * fl <= 2048) ? 4 : 0;
     return (env == 1 || nt * fl <= 1100) ? 6 : 0;
@@ -1005,8 +1008,11 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             launch_groups(C, k_banded_sys<4, true>, a, (size_t)(g1 - g0) * 16, 4, 0, false, sys_pin);
             a.only_if = O.hew + o;
             // what it flagged for its height: one wave per leaf while the sub-batch is small enough for that
-            if (maxns > 15 && (sys_env == 1 || (size_t)(g1 - g0) * 64 * in_fl <= 4096))
+            if (maxns > 15 && (sys_env == 1 || (size_t)(g1 - g0) * 64 * in_fl <= 4096)) {
                 launch_groups(C, k_banded_sys<6, true>, a, (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
+                // ... and what THAT flagged for its height (64 .. 127 slots): two rows per lane, two sweeps per chunk
+                if (maxns > 63) launch_groups(C, k_banded_sys2<true>, a, (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
+            }
         }
         a.fill_multi = env_int("QE_FILL_MULTI", 1);
         a.lane_rel = env_int("QE_LANE_REL", 1);

@@ -70,6 +70,10 @@ template <int LG, bool FILL> static void k_banded_sys(BandedArgs A) {
     for (int t = 0; t < A.T.ntasks; ++t) if (A.T.pair[t] >= 0 && A.o_abort) A.o_abort[t] = 0;
     stub_banded(A);
 }
+template <bool FILL> static void k_banded_sys2(BandedArgs A) {
+    for (int t = 0; t < A.T.ntasks; ++t) if (A.T.pair[t] >= 0 && A.o_abort && !(A.only_if && A.only_if[t] == 0)) A.o_abort[t] = 0;
+    stub_banded(A);
+}
 static void k_banded_coop(CoopArgs A) {
     for (int t = 0; t < A.T.ntasks; ++t) {
         if (A.T.pair[t] < 0) continue;

@@ -582,6 +582,15 @@ def test_fill_systolic_forced(sys_, golden, monkeypatch):
     tr = [oracle_cached(p, t, trace=True, algo=0)[3] for p, t in b.pairs()]
     assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
     assert cnt[3] == sum(x["traceback_steps"] for x in tr)
+    # bands of 64 .. 127 slots (bounds of 4 000 - 8 000: several large indels): two rows per lane, two sweeps (k_banded_sys2)
+    tall = datagen.generate(24, 12000, 0.05, seed=19, indels_num=6, indels_len=900)
+    s_, st_, cg_, cnt = gpu_batch(tall, algo=0)
+    work = 0
+    for i, (p, t) in enumerate(tall.pairs()):
+        est, esc, ecg, trc = oracle_cached(p, t, trace=True, algo=0)
+        work += trc["fill_block_advances"]
+        assert (st_[i], s_[i], cg_[i]) == (est, esc, ecg), (sys_, "tall", i)
+    assert cnt[1] == work
 
 
 @pytest.mark.parametrize("tsys", ["1", "8", "4", "0"])
@@ -687,6 +696,16 @@ def test_score_systolic_forced(ssys, golden, monkeypatch):
         st, out = al.alignBatch(pairs)
         for i, (p, t) in enumerate(pairs):
             assert out[i] == oracle_cached(p, t, **kw), (ssys, kw, i, len(p), len(t))
+    # bands of 64 .. 127 slots: k_banded_sys2<false>
+    tall = datagen.generate(24, 10000, 0.05, seed=33, indels_num=2, indels_len=700)
+    for bw in (45, 70):
+        sc_, st_, _, cnt = gpu_batch(tall, algo=2, only_score=True, bandwidth=bw)
+        tr = [oracle_cached(p, t, trace=True, algo=2, only_score=True, bandwidth=bw) for p, t in tall.pairs()]
+        assert sc_.tolist() == [x[1] for x in tr] and st_.tolist() == [x[0] for x in tr], (ssys, bw)
+        # (the cooperative LDS form that runs instead when the systolic form is off counts the slot a lane walks on a "no
+        # cut yet" guess that the bookkeeping later cuts: its block-advance counter may exceed the oracle's by a few slots)
+        if ssys == "1":
+            assert cnt[0] == sum(x[3]["score_block_advances"] for x in tr), (ssys, bw)
     b = datagen.generate(64, 2000, 0.05, seed=30)
     for bw in (3, 15):
         _, _, _, cnt = gpu_batch(b, algo=2, only_score=True, bandwidth=bw)
