@@ -3022,6 +3022,36 @@ __device__ __forceinline__ void window_walk_tile_g(const u64 (&tP)[8], const u64
     }
 }
 
+// window_walk_tile_g<true> for a wave with few walkers (k_windowed_sys): where the walker's cell is a plain match -- tX =
+// Pv | Mv | ~Eq has a zero at its row -- the step is v--, h-- at no cost; everything else takes the general column behind
+// one branch.  Same steps, same score.
+__device__ __forceinline__ void window_walk_tile_g_fast(const u64 (&tP)[8], const u64 (&tM)[8], const u64 (&tE)[8], const u64 (&tX)[8], bool inw, int Rb,
+                                                        int v0, int h0, int v_ov, int h_ov, int& v, int& h, int& wscore) {
+    bool in_tile = inw;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const bool mine = in_tile && ((h - h0) & 7) == j;
+        const int bit = (v - v0) & 63;
+        const bool slow = mine && ((u32)(tX[j] >> bit) & 1u) != 0;
+        if (slow) {
+            int r = min(__clzll((long long)~(tP[j] << (63 - bit))), bit + 1);
+            r = min(r, v - v_ov + 1);                                  // the region ends at row v_ov
+            const bool up = r == bit + 1;                             // the run left the block row
+            const bool go = !up && (v - r) >= v_ov;
+            const int b1 = (bit - r) & 63;
+            const u32 mb = (u32)(tM[j] >> b1) & 1u, eq = (u32)(tE[j] >> b1) & 1u;
+            wscore += r + (go ? (int)(mb | (eq ^ 1u)) : 0);
+            v -= r + ((go && !mb) ? 1 : 0);
+            h -= go ? 1 : 0;
+            in_tile = !up;
+        }
+        const int f = (mine && !slow) ? 1 : 0;                        // a plain match
+        v -= f; h -= f;
+        in_tile = in_tile && v >= v_ov && h >= h_ov && ((v - v0) >> 6) == Rb;
+        asm("" : "+v"(v), "+v"(h));                                   // (see walk_tile_lean)
+    }
+}
+
 // K vertically adjacent blocks i .. i + K - 1 of a window over the 64 columns of chunk j (window_cp_* state: see the
 // checkpointed general path of k_windowed)
 template <int K>
@@ -3064,8 +3094,10 @@ __device__ __forceinline__ void windowed_body(const WindowArgs& A) {
     uint4 (*wck)[64] = (uint4 (*)[64])(qe_dyn_lds + QE_WAVE_IN_BLOCK() * 512);    // [8][64] per wave
     const int g = QE_GROUP_INDEX(), lane = threadIdx.x & 63, t = g * 64 + lane;
     if (g * 64 >= A.T.ntasks) return;
-    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    if (A.only_if != nullptr && pair >= 0 && A.only_if[t] == 0) pair = -1;      // done by k_windowed_sys
     const bool valid = pair >= 0;
+    if (!__any(valid)) return;
     const int W = A.W, O = A.O;
     int m = 0, n = 0, p0 = 0, t0 = 0;
     const u64* pp = A.P.pl_p; const u64* tp = A.P.pl_t;
@@ -3573,6 +3605,177 @@ __global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
         const int64_t nt = A.T.ntasks;
         A.state[t] = pos_v; A.state[nt + t] = pos_h; A.state[2 * nt + t] = score; A.state[3 * nt + t] = hew;
         A.state[4 * nt + t] = (int32_t)steps;
+    }
+}
+
+// ===========================================================================
+// WindowEd for ANY window shape of up to 15 blocks, SIXTEEN LANES PER ALIGNMENT (k_windowed_sys): the cooperative form of
+// k_windowed_cp for launches of few waves -- QuickEd's stage 2 (WindowEd(9, 1), forward and reversed) on the pairs a run
+// left, the WINDOWED algorithm on a few hundred pairs (bpm_windowed.c:202-280, 504-628; score only).
+// Fill: lane i of a group is block row i of the window, the rows a systolic array skewed by one column per row (row i works
+// on column s - i at step s, carries by v_mov_dpp row_ror:1, the lane above row 0 holds the window's top boundary carry):
+// 64 W + W - 1 steps of one block step instead of W x 64 W.  A lane's text bit at step s is bit s mod 64 of a per-lane word
+// funnelled from the current and the previous chunk's plane words, so that every lane reads the same literal position.
+// What the in-window traceback needs is left exactly as k_windowed_cp leaves it ({Pv, Mv} before every 8th column of every
+// block it may visit, the carry-in words per (chunk, block), in the group's workspace).
+// Traceback: a round rebuilds SIXTEEN 8-column tiles at once -- the 8 column tiles to the left of the walk's position, for
+// each the block row the path's diagonal predicts and the one above -- and the walk then visits them in path order, its
+// state (v, h, the window's score) broadcast from the tile's owner after every tile (cf. k_traceback_sys).
+// Same windows, same anchors, same scores and HEW counts as k_windowed_cp; tasks with N or non-canonical symbols are
+// flagged (o_abort) and left to it.
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_windowed_sys(WindowArgs A) {
+    const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & 15, gl = lane & ~15;
+    const int t = wv * 4 + (lane >> 4);
+    if (wv * 4 >= A.T.ntasks) return;
+    const int pair = (t < A.T.ntasks) ? A.T.pair[t] : -1;
+    const bool valid = pair >= 0;
+    int m = 0, n = 0, p0 = 0, t0 = 0;
+    const u64* pp = A.P.pl_p; const u64* tp = A.P.pl_t;
+    u32 fl = 0;
+    if (valid) {
+        m = A.T.m[t]; n = A.T.n[t]; p0 = A.T.p0[t]; t0 = A.T.t0[t];
+        pp = A.P.pl_p + A.P.pl_p_off[pair]; tp = A.P.pl_t + A.P.pl_t_off[pair];
+        fl = A.P.flags[pair];
+    }
+    const int W = A.W, O = A.O;
+    const bool ok = valid && (fl & (FLAG_HAS_N | FLAG_NONCANON)) == 0;
+    if (valid && j == 0) A.o_abort[t] = ok ? 0 : 1;
+    if (!__any(ok)) return;
+    const int g = ok ? (t >> 6) : 0, col = t & 63;
+    uint8_t* wsb = A.ws + A.g_ws_off[g];
+    uint4* const cpb = (uint4*)(wsb + (int64_t)2 * W * 64 * 8) + col;      // [8 x chunks][W][64]: {Pv, Mv} before column 8 q
+    uint4* const hwb = cpb + (int64_t)8 * W * W * 64;                      // [chunks][W][64]: carry-in words
+    int pos_v = m - 1, pos_h = n - 1;
+    int score = 0, hew = 0;
+    u32 steps = 0;
+    while (__any(ok && pos_v >= 0 && pos_h >= 0)) {
+        const bool on = ok && pos_v >= 0 && pos_h >= 0;
+        const int v_fi = pos_v, h_fi = pos_h;
+        const int v0 = max(v_fi - 64 * W + 1, 0), h0 = max(h_fi - 64 * W + 1, 0);
+        const int steps_v = on ? (v_fi - v0) / 64 + 1 : 0;
+        const int ncols_total = on ? h_fi - h0 + 1 : 0;
+        const u32 ph_first = (v0 == 0) ? 1u : 0u;
+        const u32 pinit = (h0 == 0) ? ~0u : 0u;
+        const int v_ov = max(v_fi - 64 * (W - O) + 1, 0), h_ov = max(h_fi - 64 * (W - O) + 1, 0);
+        const int blk_min = (v_ov - v0) >> 6;
+        // ---- fill: lane i = block row i
+        const int i = j;
+        const bool rowon = on && i < steps_v;
+        u64 pa = 0, pb = 0, pn;
+        if (rowon) load_planes(pp, p0 + v0 + 64 * i, pa, pb, pn);
+        const u32 alo = lo32(pa), ahi = hi32(pa), blo = lo32(pb), bhi = hi32(pb);
+        u32 Plo = pinit, Phi = pinit, Mlo = 0, Mhi = 0;
+        u32 oP = 0, oM = 0;
+        if (i == 15) { oP = ph_first; oM = 0u; }                   // the lane above row 0: the window's top boundary carry
+        const u32 len = rowon ? (u32)ncols_total : 0u;
+        const bool rkeep = rowon && i >= blk_min;
+        const int nJ = __builtin_amdgcn_readfirstlane(wave_max((ncols_total + steps_v - 1 + 63) >> 6));       // 64-step blocks
+        u64 Tp0 = 0, Tp1 = 0;                                      // the previous chunk's text planes
+        u64 gP = 0, gM = 0;
+#pragma unroll 1
+        for (int J = 0; J < nJ; ++J) {
+            u64 Tc0 = 0, Tc1 = 0;
+            if (on && 64 * J < ncols_total) load_planes_ab(tp, t0 + h0 + 64 * J, Tc0, Tc1);
+            // bit s mod 64 of these is the text's column 64 J + (s mod 64) - i: this lane's column at step s
+            const u64 R0 = i ? ((Tc0 << i) | (Tp0 >> (64 - i))) : Tc0, R1 = i ? ((Tc1 << i) | (Tp1 >> (64 - i))) : Tc1;
+            Tp0 = Tc0; Tp1 = Tc1;
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                const u32 w0 = half ? hi32(R0) : lo32(R0), w1 = half ? hi32(R1) : lo32(R1);
+#pragma unroll
+                for (int sb = 0; sb < 32; ++sb) {
+                    const int s = 64 * J + 32 * half + sb;
+                    const u32 inP = grp_ror1<4>(oP), inM = grp_ror1<4>(oM);
+                    const u32 c = (u32)(s - i);
+                    if (c < len) {
+                        // {Pv, Mv} before every 8th column and the chunk's carry-in words, where the traceback may come
+                        const bool ckeep = rkeep && (int)(c | 63u) >= h_ov - h0;
+                        if ((c & 7u) == 0 && ckeep) cpb[((int64_t)(c >> 3) * W + i) * 64] = make_uint4(Plo, Phi, Mlo, Mhi);
+                        const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)w0, sb, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)w1, sb, 1);
+                        const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1), ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
+                        u32 phhi, mhhi;
+                        block_step_core(elo, ehi, Plo, Phi, Mlo, Mhi, inP, inM, phhi, mhhi);
+                        oP = phhi >> 31; oM = mhhi >> 31;
+                        gP = shl1_add_u64(gP, (u64)inP); gM = shl1_add_u64(gM, (u64)inM);
+                        if ((c & 63u) == 63u || c + 1 == len) {
+                            // the chunk's carry-in words, bit c' = column c' of the chunk
+                            const int nc = (int)(c & 63u) + 1;
+                            const u64 xP = __builtin_bitreverse64(gP << (64 - nc)), xM = __builtin_bitreverse64(gM << (64 - nc));
+                            if (ckeep) hwb[((int64_t)(c >> 6) * W + i) * 64] = make_uint4(lo32(xP), hi32(xP), lo32(xM), hi32(xM));
+                            gP = 0; gM = 0;
+                        }
+                    }
+                }
+            }
+        }
+        if (on && j == 0) steps += (u32)steps_v * (u32)ncols_total;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the rows' lanes stored, the tiles' lanes load (one wave, program order)
+        // ---- in-window traceback (bpm_windowed.c:504-561) over recomputed tiles, sixteen at a time
+        int v = pos_v, h = pos_h, wscore = 0;
+        while (__any(on && v >= v_ov && h >= h_ov)) {
+            const bool live = on && v >= v_ov && h >= h_ov;
+            const int x = j >> 1;
+            const int q = ((h - h0) >> 3) - x;
+            const int v_in = (x == 0) ? v : v - ((h - h0) - (8 * q + 7));            // where the diagonal meets the tile's right edge
+            const int Rb = ((max(v_in, v0) - v0) >> 6) - (j & 1);
+            const bool act = live && q >= 0 && Rb >= 0;
+            u64 tP[8], tM[8], tE[8];
+            {
+                u64 qa = 0, qb = 0, qn, X0 = 0, X1 = 0, hP = 0, hM = 0;
+                u32 cPlo = 0, cPhi = 0, cMlo = 0, cMhi = 0;
+                if (act) {
+                    const int jc = q >> 3;
+                    load_planes(pp, p0 + v0 + 64 * Rb, qa, qb, qn);
+                    load_planes_ab(tp, t0 + h0 + 64 * jc, X0, X1);
+                    const uint4 w0 = hwb[((int64_t)jc * W + Rb) * 64];
+                    const uint4 c0 = cpb[((int64_t)q * W + Rb) * 64];
+                    hP = mk64(w0.x, w0.y); hM = mk64(w0.z, w0.w);
+                    cPlo = c0.x; cPhi = c0.y; cMlo = c0.z; cMhi = c0.w;
+                }
+                const int sh = 8 * (max(q, 0) & 7);
+                const u32 xlo = lo32(qa), xhi = hi32(qa), ylo = lo32(qb), yhi = hi32(qb);
+                const u32 t0s = (u32)(X0 >> sh), t1s = (u32)(X1 >> sh);
+                const u32 hp = (u32)(hP >> sh), hm = (u32)(hM >> sh);
+                u32 aP = 0, aM = 0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)t0s, c, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)t1s, c, 1);
+                    const u32 elo = bitop3<0x90>(~(xlo ^ m0), ylo, m1), ehi = bitop3<0x90>(~(xhi ^ m0), yhi, m1);
+                    tE[c] = mk64(elo, ehi);
+                    tM[c] = mk64(cMlo, cMhi);
+                    block_step_fused(elo, ehi, cPlo, cPhi, cMlo, cMhi, __builtin_amdgcn_ubfe(hp, c, 1), __builtin_amdgcn_ubfe(hm, c, 1), aP, aM);
+                    tP[c] = mk64(cPlo, cPhi);
+                }
+            }
+            u64 tX[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tX[c] = tP[c] | tM[c] | ~tE[c];
+            while (true) {
+                const bool mine = act && v >= v_ov && h >= h_ov && ((h - h0) >> 3) == q && ((v - v0) >> 6) == Rb;
+                const u64 bal = __ballot(mine);
+                const u32 grp = (u32)(bal >> gl) & 0xffffu;
+                if (!__any(grp != 0)) break;
+                window_walk_tile_g_fast(tP, tM, tE, tX, mine, Rb, v0, h0, v_ov, h_ov, v, h, wscore);
+                if (grp != 0) {
+                    const int own = gl | (__ffs((int)grp) - 1);
+                    v = __shfl(v, own); h = __shfl(h, own); wscore = __shfl(wscore, own);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // ... and the next window's stores come after these loads
+        if (on) {
+            if (wscore > (W - O) * 64 * A.hew_threshold / 100) ++hew;
+            score += wscore;
+            pos_v = v; pos_h = h;
+        }
+    }
+    if (ok && j == 0) {
+        if (pos_h >= 0) score += pos_h + 1;
+        if (pos_v >= 0) score += pos_v + 1;
+        A.o_score[t] = score;
+        A.o_hew[t] = hew;
+        A.o_steps[t] = steps;
     }
 }
 

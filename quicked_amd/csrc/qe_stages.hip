@@ -671,7 +671,19 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
             launch_groups(C, k_windowed_quad, a, nt / 16, 4, (size_t)QE_WQ_LDS_PER_WAVE, /* chain */ true);
         }
         launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192, /* chain */ true);
-    } else launch_groups(C, k_windowed_cp, a, (size_t)ng, 8, 8192, /* chain */ true);
+    } else {
+        // few waves: sixteen lanes per alignment (k_windowed_sys: the window's block rows as a systolic array, sixteen traceback
+        // tiles rebuilt at a time); what it flags (N, non-canonical symbols) stays with the one-lane kernel.
+        // QE_WINDOWED_SYS = 0 / 1: never / wherever eligible (tests)
+        const int wsys = env_int("QE_WINDOWED_SYS", -1);
+        const size_t waves = (size_t)ng * 16 * (size_t)std::max(1, fetch ? 1 : C.in_flight);
+        if (score_only && W <= 15 && a.cp_path != 0 && (wsys == 1 || (wsys != 0 && waves <= 4096))) {
+            a.o_abort = C.scratch_p->take<int32_t>(nt);
+            launch_groups(C, k_windowed_sys, a, nt / 4, 4, 0, /* chain */ false, (size_t)40 * 1024);
+            a.only_if = a.o_abort;
+        }
+        launch_groups(C, k_windowed_cp, a, (size_t)ng, 8, 8192, /* chain */ true);
+    }
     if (d_score_out) *d_score_out = O.score;
     if (dev_out) *dev_out = O;
     if (dev_tasks) *dev_tasks = T;

@@ -143,6 +143,9 @@ struct WindowArgs {
     // (2, 1) windows only) leaves every task's chain where its first clamped window begins, k_windowed takes it up from
     // there; null: k_windowed runs the whole chain
     int32_t* state = nullptr;
+    // k_windowed_sys (16 lanes per alignment, any window shape of up to 15 blocks, score only) flags what it leaves to
+    // k_windowed_cp -- N / non-canonical symbols -- in o_abort; k_windowed_cp then runs only the tasks whose flag is set
+    int32_t* o_abort = nullptr;  const int32_t* only_if = nullptr;
 };
 // k_windowed_quad: LDS per wave = {Pv after, Mv before} of the traceback's 64 columns, [slot][lane] x 8 B, 65 slots
 // (the lanes of a quad run one column apart)

@@ -49,13 +49,17 @@ static void k_apply_cutoffs(int nt, int32_t* cutoff, int32_t* pair, const int32_
 static void stub_windowed(const WindowArgs& A) {
     const int bound = stub_env("QE_STUB_BOUND", 70);
     for (int t = 0; t < A.T.ntasks; ++t) {
-        if (A.T.pair[t] < 0) continue;
+        if (A.T.pair[t] < 0 || (A.only_if && A.only_if[t] == 0)) continue;
         A.o_score[t] = bound; A.o_hew[t] = 0; A.o_steps[t] = 1;
         if (!A.score_only) { A.o_nruns[t] = 0; A.o_nops[t] = 0; A.o_edits[t] = 0; }
     }
 }
 static void k_windowed(WindowArgs A) { stub_windowed(A); }
 static void k_windowed_cp(WindowArgs A) { stub_windowed(A); }
+static void k_windowed_sys(WindowArgs A) {
+    for (int t = 0; t < A.T.ntasks; ++t) if (A.T.pair[t] >= 0 && A.o_abort) A.o_abort[t] = 0;
+    stub_windowed(A);
+}
 static void k_windowed_quad(WindowArgs A) { if (A.state) memset(A.state, 0, (size_t)5 * A.T.ntasks * sizeof(int32_t)); }
 // BandEd: a score per task, nothing flagged
 static void stub_banded(const BandedArgs& A) {

@@ -500,6 +500,57 @@ def test_windowed_quad_forced(quad, golden, monkeypatch):
         assert cnt[2] == sum(oracle_cached(p, t, trace=True, **kw)[3]["window_block_steps"] for p, t in b.pairs()), kw
 
 
+@pytest.mark.parametrize("wsys", ["1", "0"])
+def test_windowed_systolic_forced(wsys, golden, monkeypatch):
+    """WindowEd score-only for any window shape of up to 15 blocks with sixteen lanes per alignment (k_windowed_sys: the
+    window's block rows as a systolic array, sixteen traceback tiles rebuilt at a time; QE_WINDOWED_SYS = 1) against
+    k_windowed_cp (0): the goldens (WindowEd(9, 1) scores, the QuickEd stages the HEW counts of stage 2 drive -- forward and
+    reversed), the oracle on ragged lengths, clamped windows, pairs with large indels, N / lower-case input (flagged tasks
+    fall back), several window shapes, and the window-step counter."""
+    monkeypatch.setenv("QE_WINDOWED_SYS", wsys)
+    for name in ("cfg1_1kb_5pct", "cfg2_10kb_5pct", "indel_10kb", "len128", "len130", "len1024"):
+        entry = golden["datasets"][name]
+        batch = datagen.generate(**entry["gen"])
+        for label, run in entry["runs"].items():
+            prm = run["params"]
+            if not ((prm.get("algo") == 1 and prm.get("only_score") and prm.get("window_size", 9) != 2) or (prm.get("algo") == 0 and name == "indel_10kb")):
+                continue
+            scores, status, cig, _ = gpu_batch(batch, **prm)
+            assert status.tolist() == run["status"], (name, label)
+            assert scores.tolist() == run["score"], (name, label)
+            if "cigar_sha256" in run:
+                assert [sha(c) for c in cig] == run["cigar_sha256"], (name, label)
+    rng = np.random.default_rng(37)
+    pairs = mixed_batch()
+    for i in range(70):
+        L = int(rng.choice([1, 63, 64, 65, 300, 575, 576, 577, 1200, 3000, 5000, 9000]))
+        e = float(rng.choice([0.0, 0.03, 0.1, 0.25]))
+        b = datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=3700 + i,
+                             indels_num=int(rng.integers(0, 3)) if L >= 3000 else 0, indels_len=int(rng.choice([200, 700])))
+        p, t = next(b.pairs())
+        if rng.random() < 0.2:
+            t = t[: max(1, len(t) - int(rng.integers(0, max(1, len(t) // 3))))]
+        pairs.append((p, t))
+    for kw in (dict(algo=1, only_score=True), dict(algo=1, only_score=True, window_size=3, overlap_size=1),
+               dict(algo=1, only_score=True, window_size=4, overlap_size=2), dict(algo=1, only_score=True, window_size=7, overlap_size=5),
+               dict(algo=1, only_score=True, window_size=15, overlap_size=1),
+               dict(algo=0, hew_threshold=(10, 10), hew_percentage=(1, 1)),
+               dict(algo=0, window_size=5, overlap_size=2, hew_threshold=(10, 40), hew_percentage=(1, 15))):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            if k in ("hew_threshold", "hew_percentage"):
+                getattr(al._params, k)[0], getattr(al._params, k)[1] = v
+            else:
+                setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            assert out[i] == oracle_cached(p, t, **kw), (wsys, kw, i, len(p), len(t))
+    b = datagen.generate(64, 3000, 0.1, seed=38, indels_num=1, indels_len=300)
+    for kw in (dict(algo=1, only_score=True), dict(algo=1, only_score=True, window_size=4, overlap_size=2), dict(algo=0, hew_threshold=(10, 10), hew_percentage=(1, 1))):
+        _, _, _, cnt = gpu_batch(b, **kw)
+        assert cnt[2] == sum(oracle_cached(p, t, trace=True, **kw)[3]["window_block_steps"] for p, t in b.pairs()), (wsys, kw)
+
+
 @pytest.mark.parametrize("multi", ["1", "0"])
 def test_fill_multi_slot_passes_forced(multi, monkeypatch):
     """the BandEd fill runs K = 3 band slots per skewed pass, every lane masked to its own band (QE_FILL_MULTI = 1, default),
