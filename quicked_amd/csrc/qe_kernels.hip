@@ -650,14 +650,13 @@ __device__ __forceinline__ void load_planes2(const u64* __restrict__ base, int b
 
 // code planes 0 / 1 of 64 bases at bit offset `bit`
 __device__ __forceinline__ void load_planes_ab(const u64* __restrict__ base, int bit, u64& a, u64& b) {
-    const int w = bit >> 6, sh = bit & 63;
+    // no branch: both word pairs are loaded whatever the offset is (the first pair twice when it is 0, so nothing past the
+    // words the branchy form read), and a wait for them comes where the planes are first used, not inside an `if`
+    const int w = bit >> 6, sh = bit & 63, o = sh ? 3 : 0;
     const u64* q = base + 3 * (int64_t)w;
-    u64 a0 = q[0], b0 = q[1];
-    if (sh) {
-        a0 = (a0 >> sh) | (q[3] << (64 - sh));
-        b0 = (b0 >> sh) | (q[4] << (64 - sh));
-    }
-    a = a0; b = b0;
+    const u64 a0 = q[0], b0 = q[1], a1 = q[o], b1 = q[o + 1];
+    a = (a0 >> sh) | ((a1 << 1) << (63 - sh));
+    b = (b0 >> sh) | ((b1 << 1) << (63 - sh));
 }
 
 // base code (0..3, 4 = not ACGT) at position `pos` of a packed sequence
@@ -2014,6 +2013,7 @@ __device__ __forceinline__ int row_ror_n(int x) { return __builtin_amdgcn_update
 // BandEd score-only call on few pairs; a pass that stops early (a Hirschberg half pass exports its band) is flagged.
 template <int LG, bool FILL>
 __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
+    if (A.prio) __builtin_amdgcn_s_setprio(3);          // few waves, each a serial chain: first in line at the SIMD's issue arbiter
     constexpr int GL = 1 << LG, NT = 64 >> LG, GM = GL - 1;
     const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & GM, gl = lane & ~GM;
     const int t = wv * NT + (lane >> LG);
@@ -2262,6 +2262,7 @@ template __global__ void k_banded_sys<6, false>(BandedArgs);
 // ===========================================================================
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_banded_sys2(BandedArgs A) {
+    if (A.prio) __builtin_amdgcn_s_setprio(3);          // few waves, each a serial chain: first in line at the SIMD's issue arbiter
     constexpr int GL = 64, GM = 63;
     const int t = QE_GROUP_INDEX(), j = threadIdx.x & 63;
     if (t >= A.T.ntasks) return;
@@ -2618,53 +2619,6 @@ __device__ __forceinline__ void walk_tile_lean(const u64 (&tP)[TW], const u64 (&
     }
 }
 
-// walk_tile_lean for a wave with FEW walkers (k_traceback_sys with 16 lanes per leaf: four walkers per wave): a column whose
-// cell is a plain match continuing a run of matches -- tX = (Pv | Mv inside the band) | ~Eq has a zero at the walker's row --
-// costs ~22 instructions; everything else takes walk_tile_lean's column behind one branch.  Same steps, same runs.
-template <int TW>
-__device__ __forceinline__ void walk_tile_fast(const u64 (&tP)[TW], const u64 (&tM)[TW], const u64 (&tE)[TW], const u64 (&tX)[TW], bool in_tile,
-                                               u32 inb_same, u32 inb_7, int Rb, int& v, int& h, u32& steps, int& nmatch, RunSink& R) {
-#pragma unroll
-    for (int j = TW - 1; j >= 0; --j) {
-        const bool mine = in_tile && (h & (TW - 1)) == j;
-        const int bit = v & 63;
-        const u32 bad = (u32)(tX[j] >> bit) & 1u;
-        const bool slow = mine && (bad != 0 || R.cur_op != (int)OP_M);
-        bool up = false;
-        if (slow) {
-            const u32 inb = (j == TW - 1) ? inb_7 : inb_same;
-            const u32 pb = inb & (u32)(tP[j] >> bit) & 1u;
-            int r = 0, b1 = bit;
-            if (pb != 0) {                            // deletions: Pv bits bit, bit-1, ... while set (v moves up, h stays)
-                const u64 x = tP[j] << (63 - bit);
-                r = min(__clzll((long long)~x), bit + 1);
-                R.emit_run((int)OP_D, r, true);
-                b1 = (bit - r) & 63;
-            }
-            up = r == bit + 1;                        // the run reached the top of the block: next round, same column
-            const bool go = !up;
-            const u32 isI = inb & (u32)(tM[j] >> b1) & 1u;
-            const u32 eq = (u32)(tE[j] >> b1) & 1u;
-            const int op = isI ? (int)OP_I : (eq ? (int)OP_M : (int)OP_X);
-            if (go && op != R.cur_op) {
-                if (R.cur_len > 0) {
-                    if (R.nruns < R.cap) R.runs[(int64_t)R.nruns * R.stride] = ((u32)R.cur_len << 2) | (u32)R.cur_op;
-                    ++R.nruns;
-                }
-                R.cur_len = 0; R.cur_op = op;
-            }
-            R.cur_len += go ? 1 : 0;
-            nmatch += (go && !isI && eq) ? 1 : 0;
-            v -= r + ((go && !isI) ? 1 : 0);
-            h -= go ? 1 : 0;
-            steps += (u32)r + (go ? 1u : 0u);
-        }
-        const int f = (mine && !slow) ? 1 : 0;        // a match that continues a run of matches
-        R.cur_len += f; nmatch += f; v -= f; h -= f; steps += (u32)f;
-        in_tile = in_tile && !up && v >= 0 && (v >> 6) == Rb;
-        asm("" : "+v"(v), "+v"(h));                   // (see walk_tile_lean)
-    }
-}
 
 // ===========================================================================
 // BandEd traceback (bpm_banded.c:967-1036): priority D -> I -> M/X.  One lane per task walks its own
@@ -2812,6 +2766,185 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
     A.o_steps[t] = steps;
 }
 
+// ---------------------------------------------------------------------------
+// The walk of k_traceback_sys<4> (walk_round_diag): a path is mostly plain matches along a diagonal, so the walker does not
+// visit them column by column, and it is not handed from lane to lane either: its state (v, h, the run under construction,
+// the counters) is kept THE SAME IN ALL 16 LANES of its group, every lane runs the same code, and what a lane contributes
+// is what its own tile says.  When a round's tiles are rebuilt, every lane lays three bit planes of its tile out ALONG THE
+// DIAGONALS near the one the walker is on at the round's start (d0 = v - h): for o = 0 .. 15 a 16-bit word whose bit u
+// (u = 15 - column: the walk's direction) is the cell of that column on diagonal d0 + o - 7 --
+//   X: the cell is anything but a plain match (Pv | Mv inside the band, or Eq clear); cells outside the block row count as X
+//   P: Pv inside the band (a deletion, bpm_banded.c:994-1003);   M: Mv inside the band (an insertion, 1004-1010)
+// (diag_words: three windows per column, two 16 x 16 bit transposes).  A step of the walk: every lane looks up its X word
+// for the walker's diagonal, finds the first X cell at or after the walker's column, and a min-reduction over the group
+// (four row_ror DPP steps) gives the first such cell of the whole round's 128 columns together with its class bits; the run
+// of matches up to it is taken in one go, then the cell's own step: a mismatch stays on the diagonal; a deletion takes the
+// whole vertical run (the owner lane's Pv word of that column, count-leading-ones); an insertion one step, or, when the
+// cell to its left is an insertion too, the whole horizontal run (every lane gathers its tile's row).  The round ends
+// when the walker leaves the 128 columns or the predicted tiles, or has drifted more than 7 / 8 diagonals from d0.
+// Same steps, runs and bytes as k_traceback (test_traceback_systolic_forced; priority D -> I -> M / X as there).
+// ---------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ void transpose16x2_stage(u32 (&r)[16]) {  // both 16-bit halves of every word at once
+    constexpr u32 m16 = (S == 8) ? 0x00FFu : (S == 4) ? 0x0F0Fu : (S == 2) ? 0x3333u : 0x5555u, mask = m16 | (m16 << 16);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int i = ((n & ~(S - 1)) << 1) | (n & (S - 1));               // the rows with bit S clear
+        const u32 a = r[i], b = r[i + S];
+        const u32 t = ((a >> S) ^ b) & mask;          // (what a shift drags across the halves' border lands on masked-out bits)
+        r[i] = a ^ (t << S); r[i + S] = b ^ t;
+    }
+}
+__device__ __forceinline__ void transpose16x2(u32 (&r)[16]) {        // r[i] bit j <-> r[j] bit i, in the low and in the high halves
+    transpose16x2_stage<8>(r); transpose16x2_stage<4>(r); transpose16x2_stage<2>(r); transpose16x2_stage<1>(r);
+}
+
+// 16 bits of `w` from bit sc on (sc may be negative or beyond the word); what comes from outside the word is 0
+__device__ __forceinline__ u32 window16(u64 w, int sc) {
+    const u32 t = (sc >= 0) ? (u32)(w >> min(sc, 63)) : ((u32)w << min(-sc, 31));
+    return ((sc > 63) ? 0u : t) & 0xFFFFu;
+}
+
+template <int TW>
+__device__ __forceinline__ void diag_words(const u64 (&tP)[TW], const u64 (&tM)[TW], const u64 (&tE)[TW], u32 inb_same, u32 inb_7, int base,
+                                           u32 (&X8)[8], u32 (&P8)[8], u32 (&M8)[8]) {
+    static_assert(TW == 16, "sixteen columns per tile");
+    u32 r1[16], r2[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int sc = base + c - 7;                               // the window's first bit in the column's words
+        const bool inb = ((c == TW - 1) ? inb_7 : inb_same) != 0;
+        const u64 Pc = inb ? tP[c] : (u64)0, Mc = inb ? tM[c] : (u64)0;
+        const u32 wx = ~window16(~((Pc | Mc) | ~tE[c]), sc) & 0xFFFFu;      // outside the word: 1
+        r1[15 - c] = wx | (window16(Pc, sc) << 16);
+        r2[15 - c] = window16(Mc, sc);
+    }
+    transpose16x2(r1); transpose16x2(r2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        X8[i] = (r1[2 * i] & 0xFFFFu) | (r1[2 * i + 1] << 16);
+        P8[i] = (r1[2 * i] >> 16) | (r1[2 * i + 1] & 0xFFFF0000u);
+        M8[i] = (r2[2 * i] & 0xFFFFu) | (r2[2 * i + 1] << 16);
+    }
+}
+
+__device__ __forceinline__ u32 sel16(const u32 (&D8)[8], u32 o) {    // word o of the sixteen 16-bit words in eight registers
+    const u32 i = o >> 1;
+    const u32 a0 = (i & 1u) ? D8[1] : D8[0], a1 = (i & 1u) ? D8[3] : D8[2], a2 = (i & 1u) ? D8[5] : D8[4], a3 = (i & 1u) ? D8[7] : D8[6];
+    const u32 b0 = (i & 2u) ? a1 : a0, b1 = (i & 2u) ? a3 : a2;
+    const u32 w = (i & 4u) ? b1 : b0;
+    return (o & 1u) ? (w >> 16) : (w & 0xFFFFu);
+}
+template <int TW>
+__device__ __forceinline__ u64 sel_col(const u64 (&t)[TW], u32 c) {  // t[c], c a lane's own value
+    // (a tree of selects on values, level by level: written over one array the optimizer turns it into an indexed load from scratch)
+    const bool c8 = (c & 8u) != 0, c4 = (c & 4u) != 0, c2 = (c & 2u) != 0, c1 = (c & 1u) != 0;
+    const u64 a0 = c8 ? t[8] : t[0], a1 = c8 ? t[9] : t[1], a2 = c8 ? t[10] : t[2], a3 = c8 ? t[11] : t[3];
+    const u64 a4 = c8 ? t[12] : t[4], a5 = c8 ? t[13] : t[5], a6 = c8 ? t[14] : t[6], a7 = c8 ? t[15] : t[7];
+    const u64 b0 = c4 ? a4 : a0, b1 = c4 ? a5 : a1, b2 = c4 ? a6 : a2, b3 = c4 ? a7 : a3;
+    const u64 d0 = c2 ? b2 : b0, d1 = c2 ? b3 : b1;
+    return c1 ? d1 : d0;
+}
+__device__ __forceinline__ u32 pair_swap(u32 x) { return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, false); }     // quad_perm:[1,0,3,2]
+__device__ __forceinline__ u32 row_min(u32 x) {                      // the minimum over the 16 lanes of a row, in all of them
+    x = min(x, (u32)row_ror_n<1>((int)x)); x = min(x, (u32)row_ror_n<2>((int)x));
+    x = min(x, (u32)row_ror_n<4>((int)x)); return min(x, (u32)row_ror_n<8>((int)x));
+}
+__device__ __forceinline__ u32 row_max(u32 x) {
+    x = max(x, (u32)row_ror_n<1>((int)x)); x = max(x, (u32)row_ror_n<2>((int)x));
+    x = max(x, (u32)row_ror_n<4>((int)x)); return max(x, (u32)row_ror_n<8>((int)x));
+}
+
+// one round's walk.  act / q / Rb / base: this lane's tile (base = d0 + 16 q - 64 Rb); x = the tile's place in the round
+// (0 = the walker's column tile at the round's start, 7 = the leftmost); col_r = the round's rightmost column (u = 0)
+template <int TW>
+__device__ __forceinline__ void walk_round_diag(const u64 (&tP)[TW], const u64 (&tM)[TW], const u32 (&X8)[8], const u32 (&P8)[8], const u32 (&M8)[8],
+                                                bool live, bool act, int x, int Rb, int base, int d0, int col_r, u32 inb_same, u32 inb_7, bool writer,
+                                                int& v, int& h, u32& steps, int& nmatch, RunSink& R) {
+    const int u_base = 16 * x;
+    bool going = live;
+    auto switch_op = [&](int op) {                    // the run under construction ends where the operation changes (RunSink::emit_run)
+        if (R.cur_op != op) {
+            if (R.cur_len > 0) {
+                if (writer && R.nruns < R.cap) R.runs[(int64_t)R.nruns * R.stride] = ((u32)R.cur_len << 2) | (u32)R.cur_op;
+                ++R.nruns;
+            }
+            R.cur_len = 0; R.cur_op = op;
+        }
+    };
+    while (__any(going)) {
+        const u32 o = (u32)((v - h) - d0 + 7);
+        const bool step = going && o <= 15u;          // (else: drifted off the diagonals the words cover -- the next round re-centres)
+        const u32 oc = o & 15u;
+        const int u0 = col_r - h;                     // the walker's place in the round's columns, 0 .. 127
+        // the first cell at or after the walker's that is not a plain match, with its class bits
+        const int lo = u0 - u_base;
+        const u32 keep = (lo <= 0) ? 0xFFFFu : ((lo > 15) ? 0u : ((0xFFFFu << lo) & 0xFFFFu));
+        u32 wx = sel16(X8, oc);
+        wx &= pair_swap(wx);                          // the pair's two block rows: the cell is in one of them, the other says 1
+        const u32 wm = wx & keep;
+        const u32 cu = wm ? (u32)__builtin_ctz(wm) : 0u;
+        const u32 pcell = wm ? (u32)u_base + cu : 128u;
+        const int bitpos = base + (15 - (int)cu) + (int)o - 7;
+        const bool inr = act && wm != 0 && (u32)bitpos < 64u;       // the cell is in THIS lane's block row
+        const u32 pb = inr ? ((sel16(P8, oc) >> cu) & 1u) : 0u, mb = inr ? ((sel16(M8, oc) >> cu) & 1u) : 0u;
+        u32 pay = (pcell << 3) | (inr ? 4u : 0u) | (pb << 1) | mb;
+        pay |= pair_swap(pay) & 7u;
+        pay = row_min(pay);
+        const int ub = (int)(pay >> 3);
+        const u32 cls = pay & 7u;
+        const int r = step ? ub - u0 : 0;             // plain matches up the diagonal
+        if (r > 0) { switch_op((int)OP_M); R.cur_len += r; nmatch += r; steps += (u32)r; v -= r; h -= r; }
+        const bool cont = step && v >= 0 && h >= 0 && ub < 128 && (cls & 4u) != 0;       // (no owner: the path left the predicted tiles)
+        const bool isD = cont && (cls & 2u) != 0, isI = cont && !isD && (cls & 1u) != 0, isX = cont && !isD && !isI;
+        const bool owner = inr && (int)pcell == ub;
+        if (isX) { switch_op((int)OP_X); R.cur_len += 1; steps += 1u; v -= 1; h -= 1; }
+        if (__any(isD)) {                             // the vertical run: Pv bits from the cell's row upwards while set
+            const int bit = v & 63;
+            u32 rd = 0;
+            if (isD && owner) {
+                const u64 Pw = sel_col<TW>(tP, 15u - cu);
+                rd = (u32)min(__clzll((long long)~(Pw << (63 - bit))), bit + 1);
+            }
+            rd = row_max(rd);
+            if (isD) { switch_op((int)OP_D); R.cur_len += (int)rd; steps += rd; v -= (int)rd; }
+        }
+        if (__any(isI)) {
+            // one step -- or the whole horizontal run when the cell to the left is an insertion as well
+            u32 more = 0;
+            if (isI && owner && cu < 15u && o < 15u) {
+                const u32 o1 = o + 1u;
+                more = ((sel16(M8, o1) >> (cu + 1u)) & 1u) & ~((sel16(P8, o1) >> (cu + 1u)) & 1u);
+            }
+            more = row_max(more);
+            int ri = 1;
+            if (__any(isI && more != 0)) {
+                const int bit = v & 63;
+                const bool match = act && Rb == (v >> 6);
+                u32 go16 = 0;                         // bit u: the cell of column 15 - u in the walker's row is an insertion (Mv set, Pv clear)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const u32 mm = (bit & 32) ? hi32(tM[c]) : lo32(tM[c]), pp = (bit & 32) ? hi32(tP[c]) : lo32(tP[c]);
+                    go16 |= (((mm & ~pp) >> (bit & 31)) & 1u) << (15 - c);
+                }
+                go16 &= (inb_same ? 0xFFFEu : 0u) | (inb_7 ? 1u : 0u);
+                const int un = u0 + r, ln = un - u_base;           // the walker's place now, after the run of matches
+                const u32 keep_n = (ln <= 0) ? 0xFFFFu : ((ln > 15) ? 0u : ((0xFFFFu << ln) & 0xFFFFu));
+                const u32 st = ~go16 & keep_n;
+                u32 pi = (match && (isI && more != 0)) ? (st ? (u32)u_base + (u32)__builtin_ctz(st) : 1000u) : 2000u;
+                pi = min(pi, pair_swap(pi));
+                // no tile of this column pair is in the walker's row: the run's data ends at the pair's right edge
+                if (pi == 2000u) pi = (u_base + 15 < un) ? 1000u : (u32)max(u_base, un + 1);
+                pi = row_min(pi);
+                ri = (more != 0) ? (int)min(pi, 128u) - un : 1;
+            }
+            if (isI) { switch_op((int)OP_I); R.cur_len += ri; steps += (u32)ri; h -= ri; }
+        }
+        going = cont;
+        asm("" : "+v"(v), "+v"(h));                   // (see walk_tile_lean)
+    }
+}
+
 // ===========================================================================
 // BandEd traceback with G = 4 / 8 / 16 LANES PER ALIGNMENT (k_traceback_sys<log2 G>), for launches of few waves: there
 // k_traceback's duration is one lane's chain of ~(n / 16 + m / 64) rounds, each a dependent load (the checkpoint the walk
@@ -2828,6 +2961,7 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
 // ===========================================================================
 template <int LG>
 __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
+    if (A.prio) __builtin_amdgcn_s_setprio(3);          // few waves, each a serial chain: first in line at the SIMD's issue arbiter
     constexpr int GL = 1 << LG, NT = 64 >> LG;                        // lanes per task, tasks per wave
     const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & (GL - 1), gl = lane & ~(GL - 1);
     const int t = wv * NT + (lane >> LG);
@@ -2864,6 +2998,12 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
     u32 steps = 0;
     int nmatch = 0;
     constexpr int TW = QE_CP_COLS;
+#ifdef QE_TBS_PROF      // tools/tbs_prof.sh: where a round's cycles go (s_memtime at the phase boundaries, printed by the first lane)
+    long long pf_t = __builtin_readcyclecounter(), pf_load = 0, pf_comp = 0, pf_walk = 0, pf_bcast = 0; int pf_rounds = 0, pf_iters = 0;
+#define PF_MARK(acc) do { const long long n__ = __builtin_readcyclecounter(); acc += n__ - pf_t; pf_t = n__; } while (0)
+#else
+#define PF_MARK(acc) do { } while (0)
+#endif
     while (__any(ok && v >= 0 && h >= 0)) {
         const bool live = ok && v >= 0 && h >= 0;
         // this lane's tile: column tile q0 - x, block row b0(x) or the one above
@@ -2881,22 +3021,29 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
         bool computed = false;
         int cl_b = -1;
         if (act) {
+            const int pos_v = k - G.prolog, s = Rb - pos_v;
+            // every load of the round in one go: the checkpoint and the carry words are fetched for the slot clamped into the
+            // group's range before the band-edge records say whether the slot was computed (one memory latency, not two)
+            const int se = min(max(s, 0), gns - 1);
             const int cf_a = cf[(int64_t)(k + 1) * 64], cf_b = cf[(int64_t)k * 64];
             cl_b = cl[(int64_t)k * 64];
+            const uint4 c0 = cp[(int64_t)q * cps + (int64_t)se * 64];
+            const uint4 w0 = hw[((int64_t)k * gns + se) * 64];
             load_planes_ab(tp, t0 + 64 * k, T0, T1);
             load_planes_ab(pp, p0 + 64 * Rb, pa, pb);
-            const int pos_v = k - G.prolog, s = Rb - pos_v;
             // a step at column h reads Pv of stored column h + 1: inside the band of THAT column's chunk or 0 (oracle header)
             inb_same = (u32)((s >= 0) & (s >= cf_b) & (s <= cl_b));
             inb_7 = ((q & (64 / TW - 1)) == 64 / TW - 1) ? (u32)((s >= 1) & (s - 1 >= cf_a) & (s - 1 <= cl_b)) : inb_same;
             computed = s >= cf_b && s <= min(cl_b, nw - 1 - pos_v);
             if (computed) {
-                const uint4 c0 = cp[(int64_t)q * cps + (int64_t)s * 64];
-                const uint4 w0 = hw[((int64_t)k * gns + s) * 64];
                 hinP = mk64(w0.x, w0.y); hinM = mk64(w0.z, w0.w);
                 P = mk64(c0.x, c0.y); M = mk64(c0.z, c0.w);
             }
         }
+#ifdef QE_TBS_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PF_MARK(pf_load); ++pf_rounds;
+#endif
         {   // TW block steps from the checkpoint: the fill's arithmetic, so its bits
             const int c_first = (TW * max(q, 0)) & 63;
             const u32 alo = lo32(pa), ahi = hi32(pa), blo = lo32(pb), bhi = hi32(pb);
@@ -2919,19 +3066,35 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
             // the row the band bookkeeping creates at the end of a chunk: Pv = ~0, Mv = 0 (bpm_banded.c:910)
             if (act && (Rb - (k - G.prolog)) == cl_b + 1 && (q & (64 / TW - 1)) == 64 / TW - 1) tP[TW - 1] = QE_ONES;
         }
-        // 16 lanes per leaf (four walkers per wave): where the walker's cell is anything but a plain match
-        u64 tX[TW];
+        if (LG == 4) {
+            // 16 lanes per leaf (four walkers per wave): the tiles' cells laid out along the diagonals near the walker's, and the
+            // walk over the round's 128 columns in all lanes at once (walk_round_diag)
+            u32 X8[8], P8[8], M8[8];
+            const int d0 = v - h;
+            diag_words<TW>(tP, tM, tE, inb_same, inb_7, d0 + TW * q - 64 * Rb, X8, P8, M8);
+            if (!act) {
 #pragma unroll
-        for (int c = 0; c < TW; ++c) tX[c] = (LG == 4) ? ((((c == TW - 1) ? inb_7 : inb_same) ? (tP[c] | tM[c]) : (u64)0) | ~tE[c]) : (u64)0;
+                for (int c = 0; c < 8; ++c) X8[c] = ~0u;
+            }
+            PF_MARK(pf_comp);
+            walk_round_diag<TW>(tP, tM, X8, P8, M8, live, act, x, Rb, d0 + TW * q - 64 * Rb, d0, TW * (h / TW) + TW - 1, inb_same, inb_7, j == 0,
+                                v, h, steps, nmatch, R);
+            PF_MARK(pf_walk);
+            continue;
+        }
         // the walk, tile by tile in path order
         bool first_phase = true;
+        PF_MARK(pf_comp);
         while (true) {
             const bool mine = act && live && v >= 0 && h >= 0 && (h / TW) == q && (v >> 6) == Rb;
             const u64 bal = __ballot(mine);
             const u32 grp = (u32)(bal >> gl) & ((1u << GL) - 1u);
             if (!__any(grp != 0)) break;
-            if (LG == 4) walk_tile_fast<TW>(tP, tM, tE, tX, mine, inb_same, inb_7, Rb, v, h, steps, nmatch, R);
-            else walk_tile_lean<TW>(tP, tM, tE, mine, inb_same, inb_7, Rb, v, h, steps, nmatch, R);
+            PF_MARK(pf_bcast);
+            walk_tile_lean<TW>(tP, tM, tE, mine, inb_same, inb_7, Rb, v, h, steps, nmatch, R);
+#ifdef QE_TBS_PROF
+            PF_MARK(pf_walk); ++pf_iters;
+#endif
             if (grp != 0) {                                         // (uniform over the lanes of a group)
                 const int own = gl | (__ffs((int)grp) - 1);
                 v = __shfl(v, own); h = __shfl(h, own); steps = (u32)__shfl((int)steps, own); nmatch = __shfl(nmatch, own);
@@ -2940,7 +3103,11 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
             first_phase = false;
         }
         (void)first_phase;
+        PF_MARK(pf_bcast);
     }
+#ifdef QE_TBS_PROF
+    if (wv == 0 && lane == 0) printf("k_traceback_sys<%d>: %d rounds, %d tile walks; cycles: loads %lld, recompute %lld, walks %lld, hand-over %lld\n", LG, pf_rounds, pf_iters, pf_load, pf_comp, pf_walk, pf_bcast);
+#endif
     if (!ok || j != 0) return;
     R.nops = (int)steps; R.edits = (int)steps - nmatch;
     R.push_n(OP_I, h + 1);
@@ -3477,6 +3644,7 @@ __device__ __forceinline__ void window_walk_tile_lean(const u64 (&tP)[8], const 
 }
 
 __global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
+    if (A.prio) __builtin_amdgcn_s_setprio(3);          // few waves, each a serial chain: first in line at the SIMD's issue arbiter
     const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & 3;
     const int t = wv * 16 + (lane >> 2);
     if (wv * 16 >= A.T.ntasks) return;
@@ -3625,6 +3793,7 @@ __global__ __launch_bounds__(256) void k_windowed_quad(WindowArgs A) {
 // flagged (o_abort) and left to it.
 // ===========================================================================
 __global__ __launch_bounds__(256) void k_windowed_sys(WindowArgs A) {
+    if (A.prio) __builtin_amdgcn_s_setprio(3);          // few waves, each a serial chain: first in line at the SIMD's issue arbiter
     const int wv = QE_GROUP_INDEX(), lane = threadIdx.x & 63, j = lane & 15, gl = lane & ~15;
     const int t = wv * 4 + (lane >> 4);
     if (wv * 4 >= A.T.ntasks) return;

@@ -17,6 +17,11 @@ namespace qe {
 // kernels and streams they come from.  A second kernel on another stream then fills exactly the SIMD
 // slots the first one left empty, at no cost to either.
 // ---------------------------------------------------------------------------
+// The cooperative forms are launches of few waves, each a serial chain; next to a chip-filling launch of another run a lone
+// wave gets a third of its SIMD's issue slots.  s_setprio 3 in those kernels (QE_WAVE_PRIO=0: off) puts them first in line.
+static int wave_prio() { static int v = -1; if (v < 0) { const char* e = getenv("QE_WAVE_PRIO"); v = e ? atoi(e) : 1; } return v; }
+template <class Args> static Args with_prio(Args a) { a.prio = wave_prio(); return a; }
+
 template <typename Kernel, typename Args>
 static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ngroups, int max_waves, size_t lds_per_wave, bool chain = false,
                           size_t pin_override = 0) {
@@ -466,10 +471,10 @@ static ScoreLaunch launch_banded_sys(quicked_batch& B, Context& C, const TaskLis
     a.lane_rel = env_int("QE_LANE_REL", 1);
     auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-    if (lg == 4) launch_groups(C, k_banded_sys<4, false>, a, S.nt / 4, 4, 0, false, (size_t)40 * 1024);
-    else launch_groups(C, k_banded_sys<6, false>, a, S.nt, 4, 0, false, (size_t)40 * 1024);
+    if (lg == 4) launch_groups(C, k_banded_sys<4, false>, with_prio(a), S.nt / 4, 4, 0, false, (size_t)40 * 1024);
+    else launch_groups(C, k_banded_sys<6, false>, with_prio(a), S.nt, 4, 0, false, (size_t)40 * 1024);
     a.only_if = S.O.hew;
-    if (lg == 6 && max_nsl > 63) launch_groups(C, k_banded_sys2<false>, a, S.nt, 4, 0, false, (size_t)40 * 1024);      // bands of 64 .. 127 slots
+    if (lg == 6 && max_nsl > 63) launch_groups(C, k_banded_sys2<false>, with_prio(a), S.nt, 4, 0, false, (size_t)40 * 1024);      // bands of 64 .. 127 slots
     launch_groups(C, k_banded<false>, a, L.ngroups(), 8, 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
@@ -515,7 +520,7 @@ static bool stage3_on_device(quicked_batch& B, Context& C, const TaskList& L, st
     a.mat = nullptr; a.g_mat_off = nullptr;
     a.o_score = O.score; a.o_first = O.first; a.o_last = O.last; a.o_posv = O.posv; a.o_adv = O.adv; a.o_maxrow = O.len;
     a.only_if = nullptr; a.o_abort = O.hew; a.doubling = 1; a.o_cutoff = d_cut;
-    launch_groups(C, k_banded_sys<6, false>, a, nt, 4, 0, false, (size_t)40 * 1024);
+    launch_groups(C, k_banded_sys<6, false>, with_prio(a), nt, 4, 0, false, (size_t)40 * 1024);
     d2h(score, O.score, nt, C.stream); d2h(adv, O.adv, nt, C.stream); d2h(flagged, O.hew, nt, C.stream); d2h(cutoff, d_cut, nt, C.stream);
     HIP_CHECK(hipStreamSynchronize(C.stream));
     return true;
@@ -668,7 +673,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
         const size_t waves = (size_t)ng * 4 * (size_t)std::max(1, fetch ? 1 : C.in_flight);
         if (score_only && (quad == 1 || (quad != 0 && waves <= 2048))) {
             a.state = C.scratch_p->take<int32_t>(5 * nt);
-            launch_groups(C, k_windowed_quad, a, nt / 16, 4, (size_t)QE_WQ_LDS_PER_WAVE, /* chain */ true);
+            launch_groups(C, k_windowed_quad, with_prio(a), nt / 16, 4, (size_t)QE_WQ_LDS_PER_WAVE, /* chain */ true);
         }
         launch_groups(C, k_windowed, a, (size_t)ng, 8, 8192, /* chain */ true);
     } else {
@@ -679,7 +684,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
         const size_t waves = (size_t)ng * 16 * (size_t)std::max(1, fetch ? 1 : C.in_flight);
         if (score_only && W <= 15 && a.cp_path != 0 && (wsys == 1 || (wsys != 0 && waves <= 4096))) {
             a.o_abort = C.scratch_p->take<int32_t>(nt);
-            launch_groups(C, k_windowed_sys, a, nt / 4, 4, 0, /* chain */ false, (size_t)40 * 1024);
+            launch_groups(C, k_windowed_sys, with_prio(a), nt / 4, 4, 0, /* chain */ false, (size_t)40 * 1024);
             a.only_if = a.o_abort;
         }
         launch_groups(C, k_windowed_cp, a, (size_t)ng, 8, 8192, /* chain */ true);
@@ -1017,13 +1022,13 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             int maxns = 0;
             for (int g = g0; g < g1; ++g) maxns = std::max(maxns, (int)lay.nslots[g]);
             a.o_abort = O.hew + o;
-            launch_groups(C, k_banded_sys<4, true>, a, (size_t)(g1 - g0) * 16, 4, 0, false, sys_pin);
+            launch_groups(C, k_banded_sys<4, true>, with_prio(a), (size_t)(g1 - g0) * 16, 4, 0, false, sys_pin);
             a.only_if = O.hew + o;
             // what it flagged for its height: one wave per leaf while the sub-batch is small enough for that
             if (maxns > 15 && (sys_env == 1 || (size_t)(g1 - g0) * 64 * in_fl <= 4096)) {
-                launch_groups(C, k_banded_sys<6, true>, a, (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
+                launch_groups(C, k_banded_sys<6, true>, with_prio(a), (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
                 // ... and what THAT flagged for its height (64 .. 127 slots): two rows per lane, two sweeps per chunk
-                if (maxns > 63) launch_groups(C, k_banded_sys2<true>, a, (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
+                if (maxns > 63) launch_groups(C, k_banded_sys2<true>, with_prio(a), (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
             }
         }
         a.fill_multi = env_int("QE_FILL_MULTI", 1);
@@ -1049,9 +1054,9 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         if (tlg) {
             tr.o_abort = C.scratch_p->take<int32_t>((size_t)(g1 - g0) * 64);
             const size_t nwv = (size_t)(g1 - g0) << tlg;
-            if (tlg == 4) launch_groups(C, k_traceback_sys<4>, tr, nwv, 4, 0, false, sys_pin);
-            else if (tlg == 3) launch_groups(C, k_traceback_sys<3>, tr, nwv, 4, 0, false, sys_pin);
-            else launch_groups(C, k_traceback_sys<2>, tr, nwv, 4, 0, false, sys_pin);
+            if (tlg == 4) launch_groups(C, k_traceback_sys<4>, with_prio(tr), nwv, 4, 0, false, sys_pin);
+            else if (tlg == 3) launch_groups(C, k_traceback_sys<3>, with_prio(tr), nwv, 4, 0, false, sys_pin);
+            else launch_groups(C, k_traceback_sys<2>, with_prio(tr), nwv, 4, 0, false, sys_pin);
             tr.only_if = tr.o_abort;
         }
         launch_groups(C, k_traceback, tr, (size_t)(g1 - g0), 8, 0);

@@ -86,6 +86,7 @@ struct BandedArgs {
     int32_t* o_abort = nullptr;   // k_banded_sys: 1 where a task is left to k_banded<true> (N in the pair, a band of more than 15 slots)
     int32_t doubling = 0;         // k_banded_sys<.., false>: QuickEd's stage-3 band doubling in the launch (quicked.c:248-278)
     int32_t* o_cutoff = nullptr;  // ... the cutoff of every task's last pass (or, flagged, of the pass it was handed back before)
+    int32_t prio = 0;             // the cooperative forms: s_setprio 3 (few waves on a serial chain, next to chip-filling launches)
 };
 
 // BandEd score-only, G lanes per alignment (cooperative form of k_banded<false>)
@@ -126,6 +127,7 @@ struct TraceArgs {
                              // (the wave-per-alignment formatter reads it sequentially; [idx][lane] rows cost it a 256-byte row per run)
     const int32_t* only_if = nullptr;   // k_traceback: walk only tasks whose flag is non-zero (what k_traceback_sys left)
     int32_t* o_abort = nullptr;         // k_traceback_sys: 1 where a task is left to k_traceback (N / non-canonical symbols)
+    int32_t prio = 0;                   // k_traceback_sys: s_setprio 3
 };
 
 // WindowEd chain (bpm_windowed.c:563-628)
@@ -146,6 +148,7 @@ struct WindowArgs {
     // k_windowed_sys (16 lanes per alignment, any window shape of up to 15 blocks, score only) flags what it leaves to
     // k_windowed_cp -- N / non-canonical symbols -- in o_abort; k_windowed_cp then runs only the tasks whose flag is set
     int32_t* o_abort = nullptr;  const int32_t* only_if = nullptr;
+    int32_t prio = 0;      // k_windowed_quad / k_windowed_sys: s_setprio 3
 };
 // k_windowed_quad: LDS per wave = {Pv after, Mv before} of the traceback's 64 columns, [slot][lane] x 8 B, 65 slots
 // (the lanes of a quad run one column apart)
