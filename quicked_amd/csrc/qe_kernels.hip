@@ -659,6 +659,20 @@ __device__ __forceinline__ void load_planes_ab(const u64* __restrict__ base, int
     b = (b0 >> sh) | ((b1 << 1) << (63 - sh));
 }
 
+// load_planes_ab in two halves: the loads (raw words), and the shifts where the planes are needed
+__device__ __forceinline__ void planes_ab_raw(const u64* __restrict__ base, int bit, u64 (&w)[4]) {
+    const int o = (bit & 63) ? 3 : 0;
+    const u64* q = base + 3 * (int64_t)(bit >> 6);
+    w[0] = q[0]; w[1] = q[1]; w[2] = q[o]; w[3] = q[o + 1];
+}
+__device__ __forceinline__ void planes_ab_finish(const u64 (&w)[4], int bit, u64& a, u64& b) {
+    const int sh = bit & 63;
+    a = (w[0] >> sh) | ((w[2] << 1) << (63 - sh));
+    b = (w[1] >> sh) | ((w[3] << 1) << (63 - sh));
+}
+// what a tile of k_traceback_sys needs from memory (band-edge records, checkpoint, carry words, planes as raw words)
+struct TbsFetch { int q, Rb, cf_a, cf_b, cl_b; uint4 c0, w0; u64 t[4], p[4]; };
+
 // base code (0..3, 4 = not ACGT) at position `pos` of a packed sequence
 __device__ __forceinline__ int plane_code(const u64* __restrict__ base, int pos) {
     const u64* q = base + 3 * (int64_t)(pos >> 6);
@@ -2799,10 +2813,12 @@ __device__ __forceinline__ void transpose16x2(u32 (&r)[16]) {        // r[i] bit
     transpose16x2_stage<8>(r); transpose16x2_stage<4>(r); transpose16x2_stage<2>(r); transpose16x2_stage<1>(r);
 }
 
-// 16 bits of `w` from bit sc on (sc may be negative or beyond the word); what comes from outside the word is 0
-__device__ __forceinline__ u32 window16(u64 w, int sc) {
-    const u32 t = (sc >= 0) ? (u32)(w >> min(sc, 63)) : ((u32)w << min(-sc, 31));
-    return ((sc > 63) ? 0u : t) & 0xFFFFu;
+// 16 bits of `w` from bit sc on (sc may be negative or beyond the word); what comes from outside the word is 0.  Both shifts
+// are always made -- one of them by 0 -- so that a column's three windows cost no branch: sr = clamp(sc, 0, 63),
+// sl = clamp(-sc, 0, 31), live = sc <= 63
+__device__ __forceinline__ u32 window16(u64 w, int sr, int sl, bool live) {
+    const u32 t = (u32)(w >> sr) << sl;
+    return (live ? t : 0u) & 0xFFFFu;
 }
 
 template <int TW>
@@ -2813,11 +2829,13 @@ __device__ __forceinline__ void diag_words(const u64 (&tP)[TW], const u64 (&tM)[
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int sc = base + c - 7;                               // the window's first bit in the column's words
+        const int sr = min(max(sc, 0), 63), sl = min(max(-sc, 0), 31);
+        const bool live = sc <= 63;
         const bool inb = ((c == TW - 1) ? inb_7 : inb_same) != 0;
         const u64 Pc = inb ? tP[c] : (u64)0, Mc = inb ? tM[c] : (u64)0;
-        const u32 wx = ~window16(~((Pc | Mc) | ~tE[c]), sc) & 0xFFFFu;      // outside the word: 1
-        r1[15 - c] = wx | (window16(Pc, sc) << 16);
-        r2[15 - c] = window16(Mc, sc);
+        const u32 wx = ~window16(~((Pc | Mc) | ~tE[c]), sr, sl, live) & 0xFFFFu;      // outside the word: 1
+        r1[15 - c] = wx | (window16(Pc, sr, sl, live) << 16);
+        r2[15 - c] = window16(Mc, sr, sl, live);
     }
     transpose16x2(r1); transpose16x2(r2);
 #pragma unroll
@@ -3004,6 +3022,23 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
 #else
 #define PF_MARK(acc) do { } while (0)
 #endif
+    // every load of a tile in one go: the checkpoint and the carry words are fetched for the slot clamped into the group's
+    // range before the band-edge records say whether the slot was computed (one memory latency, not two); planes as raw words
+    auto tbs_fetch = [&](int q, int Rb) {
+        TbsFetch F;
+        const int k = q / (64 / TW), se = min(max(Rb - (k - G.prolog), 0), gns - 1);
+        F.q = q; F.Rb = Rb;
+        F.cf_a = cf[(int64_t)(k + 1) * 64]; F.cf_b = cf[(int64_t)k * 64]; F.cl_b = cl[(int64_t)k * 64];
+        F.c0 = cp[(int64_t)q * cps + (int64_t)se * 64];
+        F.w0 = hw[((int64_t)k * gns + se) * 64];
+        planes_ab_raw(tp, t0 + 64 * k, F.t);
+        planes_ab_raw(pp, p0 + 64 * Rb, F.p);
+        return F;
+    };
+    TbsFetch pre;
+    pre.q = -1; pre.Rb = -1; pre.cf_a = 0; pre.cf_b = 0; pre.cl_b = -1; pre.c0 = make_uint4(0, 0, 0, 0); pre.w0 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pre.t[c] = 0; pre.p[c] = 0; }
     while (__any(ok && v >= 0 && h >= 0)) {
         const bool live = ok && v >= 0 && h >= 0;
         // this lane's tile: column tile q0 - x, block row b0(x) or the one above
@@ -3020,17 +3055,17 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
         u64 P = 0, M = 0, T0 = 0, T1 = 0, hinP = 0, hinM = 0, pa = 0, pb = 0;
         bool computed = false;
         int cl_b = -1;
+        // what the tile needs from memory: fetched a round ahead for the tile the walker is expected in next (pre), here only if
+        // that guess was wrong (the first round, a walker that ended the round off its diagonal's block row)
+        TbsFetch F = pre;
+        if (act && !(pre.q == q && pre.Rb == Rb)) F = tbs_fetch(q, Rb);
         if (act) {
             const int pos_v = k - G.prolog, s = Rb - pos_v;
-            // every load of the round in one go: the checkpoint and the carry words are fetched for the slot clamped into the
-            // group's range before the band-edge records say whether the slot was computed (one memory latency, not two)
-            const int se = min(max(s, 0), gns - 1);
-            const int cf_a = cf[(int64_t)(k + 1) * 64], cf_b = cf[(int64_t)k * 64];
-            cl_b = cl[(int64_t)k * 64];
-            const uint4 c0 = cp[(int64_t)q * cps + (int64_t)se * 64];
-            const uint4 w0 = hw[((int64_t)k * gns + se) * 64];
-            load_planes_ab(tp, t0 + 64 * k, T0, T1);
-            load_planes_ab(pp, p0 + 64 * Rb, pa, pb);
+            const int cf_a = F.cf_a, cf_b = F.cf_b;
+            cl_b = F.cl_b;
+            const uint4 c0 = F.c0, w0 = F.w0;
+            planes_ab_finish(F.t, t0 + 64 * k, T0, T1);
+            planes_ab_finish(F.p, p0 + 64 * Rb, pa, pb);
             // a step at column h reads Pv of stored column h + 1: inside the band of THAT column's chunk or 0 (oracle header)
             inb_same = (u32)((s >= 0) & (s >= cf_b) & (s <= cl_b));
             inb_7 = ((q & (64 / TW - 1)) == 64 / TW - 1) ? (u32)((s >= 1) & (s - 1 >= cf_a) & (s - 1 <= cl_b)) : inb_same;
@@ -3065,6 +3100,12 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
             for (int c = 0; c < TW; ++c) { tP[c] = 0; tM[c] = 0; }
             // the row the band bookkeeping creates at the end of a chunk: Pv = ~0, Mv = 0 (bpm_banded.c:910)
             if (act && (Rb - (k - G.prolog)) == cl_b + 1 && (q & (64 / TW - 1)) == 64 / TW - 1) tP[TW - 1] = QE_ONES;
+        }
+        {   // the next round's tile, if the walker keeps to its diagonal: GL / 2 column tiles to the left, 16 rows up per column tile
+            const int qn = q - GL / 2, vn = v_in - TW * (GL / 2);
+            const int Rbn = (max(vn, 0) >> 6) - (j & 1);
+            pre.q = -1; pre.Rb = -1;
+            if (live && qn >= 0 && vn >= 0 && Rbn >= 0) pre = tbs_fetch(qn, Rbn);
         }
         if (LG == 4) {
             // 16 lanes per leaf (four walkers per wave): the tiles' cells laid out along the diagonals near the walker's, and the

@@ -550,17 +550,17 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
     }
 }
 
-// few alignments with many runs each (long reads): one wave per alignment; else one lane per alignment.  Decided before the
-// traceback runs: the wave form wants every task's runs in a stretch of their own (TraceArgs::runs_by_task)
+// One wave per alignment wherever the strings are more than a few runs long, else one lane per alignment.  Decided before the
+// traceback runs: the wave form wants every task's runs in a stretch of their own (TraceArgs::runs_by_task).  Round 5: the
+// wave form used to be kept for few alignments or very long reads; measured per read length and batch size
+// (tools/probe_format_wave.sh) it is never behind -- streams of 12.5 k pairs of 10 kb 5.1 -> 5.8 M alignments/s, one such
+// batch alone 9.8 -> 8.8 ms, 100 k pairs 6.7 -> 6.95 M, 100 k pairs of 3 kb 19.1 -> 21.9 M, of 300 bases 20.2 -> 21.8 M
 static bool wave_formatter_wanted(const quicked_batch& B, const SegList& SL, bool want_strings) {
     const size_t nr = SL.root_pair.size(), nseg = SL.kind.size();
     size_t pool_bytes = 0;
     if (want_strings) for (size_t b : SL.bound) pool_bytes += b;
     const int wave_env = env_int("QE_FORMAT_WAVE", -1);      // tests force either form
-    // ... and a launch so small that every alignment's wave is resident at once (a single pair, a few hundred): one lane's
-    // chain over ~1 000 runs is 0.75 ms there, a wave's a tenth of it
-    const bool few = nr <= 2048 && nseg > 0 && pool_bytes / nr >= 2048;
-    return B.cigar_style != 2 && nr > 0 && (wave_env >= 0 ? wave_env != 0 : (few || (nr <= 32768 && nseg > 0 && pool_bytes / nr >= 16384)));
+    return B.cigar_style != 2 && nr > 0 && (wave_env >= 0 ? wave_env != 0 : (nseg > 0 && pool_bytes / nr >= 512));
 }
 
 static AlignOut format_segments(const quicked_batch& B, Context& C, const SegList& SL, const u32* runs, const int64_t* g_runs_off,
@@ -1045,12 +1045,13 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         // a launch of few waves: sixteen lanes per leaf rebuild the tiles along the path's diagonal together and hand the
         // walk from tile to tile (k_traceback_sys); what it flags (N, non-canonical symbols) stays with the one-lane kernel.
         // QE_TRACE_SYS = 0 / 1: never / always (tests)
-        // lanes per leaf: 16 while the launch stays under ~one wave per SIMD, 8 / 4 up to ~1 600 waves (12.5 k / 25 k leaves)
+        // lanes per leaf: 16 up to ~three waves per SIMD (one batch of 12.5 k leaves alone: 9.7 ms against 10.3 with 8 lanes
+        // since the walk runs in all 16 lanes at once), 8 / 4 up to ~1 600 waves
         const int tsys = env_int("QE_TRACE_SYS", -1);
         const size_t gw = (size_t)(g1 - g0) * (size_t)std::max(1, fetch ? 1 : C.in_flight);      // one-lane waves in flight
         int tlg = 0;
         if (tsys > 1) tlg = tsys == 4 ? 2 : (tsys == 8 ? 3 : 4);
-        else if (tsys != 0) tlg = (gw * 16 <= 1100 || tsys == 1) ? 4 : (gw * 8 <= 1700 ? 3 : (gw * 4 <= 1700 ? 2 : 0));
+        else if (tsys != 0) tlg = (gw * 16 <= 3300 || tsys == 1) ? 4 : (gw * 8 <= 1700 ? 3 : (gw * 4 <= 1700 ? 2 : 0));
         if (tlg) {
             tr.o_abort = C.scratch_p->take<int32_t>((size_t)(g1 - g0) * 64);
             const size_t nwv = (size_t)(g1 - g0) << tlg;
