@@ -44,8 +44,32 @@ namespace qe {
 
 
 // one in-stream copy as a kernel (see k_copy_multi); both buffers are padded to 16 bytes (pool / arena / stage allocations are)
+// CopyBatch: the small uploads of one place in the code (the tables of a launch: 5 - 10 vectors) go in ONE launch -- every
+// copy_kernel() on the batch's stream between its construction and its destruction is an entry of its table (a launch costs
+// ~7 us of host time and ~5 us of the stream's whatever it moves: 15 of them per single-pair QuickEd call).  The scope ends
+// before the first kernel that reads what was uploaded is queued.
+struct CopyBatch;
+static thread_local CopyBatch* tl_copy_batch = nullptr;
+struct CopyBatch {
+    CopyTable T; int64_t most = 1; hipStream_t s; CopyBatch* outer;
+    explicit CopyBatch(hipStream_t stream) : s(stream), outer(tl_copy_batch) { T.n = 0; tl_copy_batch = this; }
+    void flush() {
+        if (T.n == 0) return;
+        hipLaunchKernelGGL(k_copy_multi, dim3((unsigned)std::min<int64_t>(64, (most + 255) / 256), (unsigned)T.n), dim3(256), 0, s, T);
+        T.n = 0; most = 1;
+    }
+    void add(void* dst, const void* src, size_t bytes) {
+        T.dst[T.n] = (uint4*)dst; T.src[T.n] = (const uint4*)src; T.n_u4[T.n] = (int64_t)((bytes + 15) >> 4);
+        most = std::max(most, T.n_u4[T.n]);
+        if (++T.n == CopyTable::MAX) flush();
+    }
+    ~CopyBatch() { flush(); tl_copy_batch = outer; }
+    CopyBatch(const CopyBatch&) = delete;
+    CopyBatch& operator=(const CopyBatch&) = delete;
+};
 static void copy_kernel(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
+    if (tl_copy_batch && tl_copy_batch->s == s) { tl_copy_batch->add(dst, src, bytes); return; }
     CopyTable T;
     T.n = 1; T.dst[0] = (uint4*)dst; T.src[0] = (const uint4*)src; T.n_u4[0] = (int64_t)((bytes + 15) >> 4);
     const unsigned blocks = (unsigned)std::min<int64_t>(256, (T.n_u4[0] + 255) / 256);
@@ -974,10 +998,13 @@ static void merged_finish(std::vector<MergeItem>& items, size_t ni, Context& C) 
     V->unpack_pending = false; V->unpack_event_set = false;
     V->cigar_style = items[0].B->cigar_style; V->check = false;
     V->est_bound = 0; V->pending = false; V->pending_fetch.reset();
-    h2d(V->d_p_off, V->p_off, C.stream); h2d(V->d_t_off, V->t_off, C.stream);
-    h2d(V->d_plp_off, V->plp_off, C.stream); h2d(V->d_plt_off, V->plt_off, C.stream);
-    h2d(V->d_p_len, V->p_len, C.stream); h2d(V->d_t_len, V->t_len, C.stream);
-    h2d(d_fl, flags, C.stream); h2d(d_gsrc, g_src, C.stream); h2d(d_gdst, g_dst, C.stream); h2d(d_gnw, g_nw, C.stream);
+    {
+        CopyBatch cb(C.stream);
+        h2d(V->d_p_off, V->p_off, C.stream); h2d(V->d_t_off, V->t_off, C.stream);
+        h2d(V->d_plp_off, V->plp_off, C.stream); h2d(V->d_plt_off, V->plt_off, C.stream);
+        h2d(V->d_p_len, V->p_len, C.stream); h2d(V->d_t_len, V->t_len, C.stream);
+        h2d(d_fl, flags, C.stream); h2d(d_gsrc, g_src, C.stream); h2d(d_gdst, g_dst, C.stream); h2d(d_gnw, g_nw, C.stream);
+    }
     hipLaunchKernelGGL(k_gather_words, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, C.stream, (int)(2 * n), d_gsrc, d_gdst, d_gnw, planes);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(C.stream));
@@ -1361,9 +1388,12 @@ void batch_load(quicked_batch* B, Context& C, int64_t n,
     };
     send(B->d_asc_p, pattern_pool, pattern_off, pattern_len, B->p_off, p_dense, p_lo, p_bytes);
     send(B->d_asc_t, text_pool, text_off, text_len, B->t_off, t_dense, t_lo, t_bytes);
-    h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
-    h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
-    h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
+    {
+        CopyBatch cb(C.stream);
+        h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
+        h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
+        h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
+    }
     HIP_CHECK(hipStreamSynchronize(C.stream));
 }
 
@@ -1431,10 +1461,13 @@ void batch_load_packed(quicked_batch* B, Context& C, int64_t n, int wire,
     if (pw_total) upload_span((uint8_t*)d_pw, (const uint8_t*)(pattern_words + p_lo), pw_total * 8, C.device);
     if (tw_total) upload_span((uint8_t*)d_tw, (const uint8_t*)(text_words + t_lo), tw_total * 8, C.device);
     QE_TRACE_POINT("load_packed: word upload");
-    h2d(d_pwo, pwo, C.stream); h2d(d_two, two, C.stream);
-    h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
-    h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
-    h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
+    {
+        CopyBatch cb(C.stream);
+        h2d(d_pwo, pwo, C.stream); h2d(d_two, two, C.stream);
+        h2d(B->d_p_off, B->p_off, C.stream); h2d(B->d_t_off, B->t_off, C.stream);
+        h2d(B->d_plp_off, B->plp_off, C.stream); h2d(B->d_plt_off, B->plt_off, C.stream);
+        h2d(B->d_p_len, B->p_len, C.stream); h2d(B->d_t_len, B->t_len, C.stream);
+    }
     HIP_CHECK(hipStreamSynchronize(C.stream));
     QE_TRACE_POINT("load_packed: arrays");
     B->d_wire_p = d_pw; B->d_wire_t = d_tw; B->d_wire_p_off = d_pwo; B->d_wire_t_off = d_two;

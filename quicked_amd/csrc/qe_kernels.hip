@@ -2026,6 +2026,8 @@ __device__ __forceinline__ int row_ror_n(int x) { return __builtin_amdgcn_update
 // pass (bpm_banded.c:791-964: its own narrower band and stop rule) for whole texts -- QuickEd's stage-3 doubling rounds, a
 // BandEd score-only call on few pairs; a pass that stops early (a Hirschberg half pass exports its band) is flagged.
 template <int LG, bool FILL>
+// (occupancy is not what bounds a launch of many waves here: 12.5 k leaves at 16 lanes each put three to four waves on a SIMD,
+// every one adds ~0.6 ms to the 1.3 ms of a lone wave -- 3.1 ms; forcing <= 128 VGPRs changed nothing)
 __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
     if (A.prio) __builtin_amdgcn_s_setprio(3);          // few waves, each a serial chain: first in line at the SIMD's issue arbiter
     constexpr int GL = 1 << LG, NT = 64 >> LG, GM = GL - 1;

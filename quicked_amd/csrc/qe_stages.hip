@@ -323,7 +323,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     uint8_t* ws = C.scratch_p->take<uint8_t>(ws_bytes + 256);
     int64_t* d_off = C.scratch_p->take<int64_t>(nwaves); int32_t* d_ns = C.scratch_p->take<int32_t>(nwaves);
     int32_t* d_nr = C.scratch_p->take<int32_t>(nwaves); int32_t* d_nch = C.scratch_p->take<int32_t>(nwaves);
-    h2d(d_off, w_off, C.stream); h2d(d_ns, w_ns, C.stream); h2d(d_nr, w_nr, C.stream); h2d(d_nch, w_nch, C.stream);
+    { CopyBatch cb(C.stream); h2d(d_off, w_off, C.stream); h2d(d_ns, w_ns, C.stream); h2d(d_nr, w_nr, C.stream); h2d(d_nch, w_nch, C.stream); }
     S.G = G; S.cws = ws; S.c_off = d_off; S.c_ns = d_ns; S.c_nr = d_nr; S.c_nch = d_nch;
     CoopArgs a;
     a.P = pair_view(B, reversed); a.T = S.T.v; a.G = G;
@@ -572,8 +572,11 @@ static AlignOut format_segments(const quicked_batch& B, Context& C, const SegLis
     int32_t* d_kind = C.scratch_p->take<int32_t>(nseg + 1); int32_t* d_a = C.scratch_p->take<int32_t>(nseg + 1);
     int32_t* d_b = C.scratch_p->take<int32_t>(nseg + 1);
     int32_t* d_rootpair = C.scratch_p->take<int32_t>(nr + 1);
-    h2d(d_off, SL.off, C.stream); h2d(d_kind, SL.kind, C.stream); h2d(d_a, SL.a, C.stream); h2d(d_b, SL.b, C.stream);
-    h2d(d_rootpair, SL.root_pair, C.stream);
+    {
+        CopyBatch cb(C.stream);
+        h2d(d_off, SL.off, C.stream); h2d(d_kind, SL.kind, C.stream); h2d(d_a, SL.a, C.stream); h2d(d_b, SL.b, C.stream);
+        h2d(d_rootpair, SL.root_pair, C.stream);
+    }
     A.len = C.scratch_p->take<int32_t>(nr + 1); A.edits = C.scratch_p->take<int32_t>(nr + 1); A.nops = C.scratch_p->take<int32_t>(nr + 1);
     A.str_off = C.scratch_p->take<int64_t>(nr + 1); A.total = C.scratch_p->take<int64_t>(1);
     size_t pool_bytes = 0;
@@ -798,7 +801,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         JoinArgs J;
         J.nnodes = (int32_t)ns;
         int32_t* dm = C.scratch_p->take<int32_t>(ns); int32_t* dn1 = C.scratch_p->take<int32_t>(ns); int32_t* dn2 = C.scratch_p->take<int32_t>(ns);
-        h2d(dm, hm, C.stream); h2d(dn1, hn1, C.stream); h2d(dn2, hn2, C.stream);
+        { CopyBatch cb(C.stream); h2d(dm, hm, C.stream); h2d(dn1, hn1, C.stream); h2d(dn2, hn2, C.stream); }
         J.m = dm; J.n1 = dn1; J.n2 = dn2;
         J.Ffb = band_state(SF); J.Rfb = band_state(SV);
         J.F = (Gf >= 2) ? coop_state(SF) : J.Ffb; J.R = (Gf >= 2) ? coop_state(SV) : J.Rfb;
@@ -921,9 +924,12 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     int64_t* d_runs_off = C.scratch_p->take<int64_t>(ng + 1);
     int32_t* d_nslots = C.scratch_p->take<int32_t>(ng + 1); int32_t* d_nrows = C.scratch_p->take<int32_t>(ng + 1);
     int32_t* d_nch = C.scratch_p->take<int32_t>(ng + 1); int32_t* d_runs_cap = C.scratch_p->take<int32_t>(ng + 1);
-    h2d(d_ws_off, ws_off, C.stream); h2d(d_mat_off, mat_off, C.stream); h2d(d_runs_off, lay.runs_off, C.stream);
-    h2d(d_nslots, lay.nslots, C.stream); h2d(d_nrows, lay.nrows, C.stream); h2d(d_nch, lay.nch, C.stream);
-    h2d(d_runs_cap, lay.runs_cap, C.stream);
+    {
+        CopyBatch cb(C.stream);
+        h2d(d_ws_off, ws_off, C.stream); h2d(d_mat_off, mat_off, C.stream); h2d(d_runs_off, lay.runs_off, C.stream);
+        h2d(d_nslots, lay.nslots, C.stream); h2d(d_nrows, lay.nrows, C.stream); h2d(d_nch, lay.nch, C.stream);
+        h2d(d_runs_cap, lay.runs_cap, C.stream);
+    }
     u32* d_runs = C.scratch_p->take<u32>(lay.runs_u32 + 64);
     const bool wave_fmt = wave_formatter_wanted(B, SL, want_cigar);       // also the layout the traceback leaves its runs in
     // Lanes per leaf for the fill: 1 where the leaves fill the chip -- and wherever the cutoff is a tight bound of the distance
