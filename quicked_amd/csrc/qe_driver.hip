@@ -1379,6 +1379,38 @@ void batch_load(quicked_batch* B, Context& C, int64_t n,
         B->d_flags[q] = A.take<u32>((size_t)n);
         if (!B->ev_done[q]) HIP_CHECK(hipEventCreateWithFlags(&B->ev_done[q], hipEventDisableTiming));
     }
+    // a small batch (single quicked_align calls): strings and tables through the context's pinned block, one copy launch
+    const size_t small_total = p_bytes + t_bytes + (size_t)n * 40 + 8 * 64;
+    if (small_total <= ((size_t)512 << 10)) {
+        uint8_t* st = C.small_pinned(small_total + 256);
+        size_t top = 0;
+        CopyBatch cb(C.stream);
+        auto put = [&](void* dst, const void* src, size_t bytes) {
+            if (bytes == 0) return;
+            memcpy(st + top, src, bytes);
+            copy_kernel(dst, st + top, bytes, C.stream);
+            top += (bytes + 63) & ~(size_t)63;
+        };
+        auto put_pool = [&](uint8_t* dst, const char* pool, const int64_t* off, const int32_t* len, const std::vector<int64_t>& doff,
+                            bool dense, int64_t lo, size_t bytes) {
+            if (bytes == 0) return;
+            if (dense) { put(dst, pool + lo, bytes); return; }
+            uint8_t* h = st + top;
+            memset(h, 0, bytes);
+            for (int64_t i = 0; i < n; ++i) if (len[i]) memcpy(h + doff[(size_t)i], pool + off[i], (size_t)len[i]);
+            copy_kernel(dst, h, bytes, C.stream);
+            top += (bytes + 63) & ~(size_t)63;
+        };
+        put_pool(B->d_asc_p, pattern_pool, pattern_off, pattern_len, B->p_off, p_dense, p_lo, p_bytes);
+        put_pool(B->d_asc_t, text_pool, text_off, text_len, B->t_off, t_dense, t_lo, t_bytes);
+        put(B->d_p_off, B->p_off.data(), (size_t)n * 8); put(B->d_t_off, B->t_off.data(), (size_t)n * 8);
+        put(B->d_plp_off, B->plp_off.data(), (size_t)n * 8); put(B->d_plt_off, B->plt_off.data(), (size_t)n * 8);
+        put(B->d_p_len, B->p_len.data(), (size_t)n * 4); put(B->d_t_len, B->t_len.data(), (size_t)n * 4);
+        cb.flush();
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        return;
+    }
     auto send = [&](uint8_t* dst, const char* pool, const int64_t* off, const int32_t* len, const std::vector<int64_t>& doff,
                     bool dense, int64_t lo, size_t bytes) {
         if (dense) { upload_span(dst, (const uint8_t*)pool + lo, bytes, C.device); return; }
