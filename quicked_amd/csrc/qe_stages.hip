@@ -611,19 +611,53 @@ static AlignOut format_segments(const quicked_batch& B, Context& C, const SegLis
 static void fetch_alignments(quicked_batch& B, Context& C, const SegList& SL, const AlignOut& A, bool want_strings,
                              int32_t ok_status, const std::vector<int32_t>* root_status) {
     std::vector<int32_t> len, edits, nops; std::vector<int64_t> off;
-    d2h(len, A.len, A.nroots, C.stream); d2h(edits, A.edits, A.nroots, C.stream); d2h(nops, A.nops, A.nroots, C.stream);
-    if (want_strings) d2h(off, A.str_off, A.nroots, C.stream);
     std::vector<int32_t> okv;
-    if (A.ok) d2h(okv, A.ok, A.nroots, C.stream);
-    HIP_CHECK(hipStreamSynchronize(C.stream));
-    int64_t total = 0;
-    if (want_strings) for (size_t i = 0; i < A.nroots; ++i) total = std::max<int64_t>(total, off[i] + len[i] + 1);
+    const size_t nr = A.nroots;
+    const bool strings = want_strings && A.pool != nullptr && A.pool_bytes > 0;
+    const size_t small_bytes = 6 * (((nr * 8) + 63) & ~(size_t)63) + (strings ? A.pool_bytes + 64 : 0);
     const size_t base = B.wr->cigar_pool.size;
-    if (total) {
-        B.wr->cigar_pool.reserve(base + (size_t)total);
-        HIP_CHECK(hipMemcpyAsync(B.wr->cigar_pool.p + base, A.pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
+    if (small_bytes <= ((size_t)256 << 10)) {
+        // few alignments (a single quicked_align call): the per-root arrays and the string pool up to its bound arrive in the
+        // context's pinned block through ONE copy launch and ONE synchronisation (five copies, the strings' own round trip
+        // and two synchronisations otherwise: ~0.1 ms of a call)
+        uint8_t* st = C.small_pinned(small_bytes + 256);
+        size_t top = 0;
+        auto get = [&](const void* src, size_t bytes) { uint8_t* p = st + top; copy_kernel(p, src, bytes, C.stream); top += (bytes + 63) & ~(size_t)63; return p; };
+        const uint8_t *h_len, *h_edits, *h_nops, *h_off = nullptr, *h_ok = nullptr, *h_pool = nullptr;
+        {
+            CopyBatch cb(C.stream);
+            h_len = get(A.len, nr * 4); h_edits = get(A.edits, nr * 4); h_nops = get(A.nops, nr * 4);
+            if (want_strings) h_off = get(A.str_off, nr * 8);
+            if (A.ok) h_ok = get(A.ok, nr * 4);
+            if (strings) h_pool = get(A.pool, A.pool_bytes);
+        }
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(C.stream));
-        B.wr->cigar_pool.size = base + (size_t)total;
+        len.assign((const int32_t*)h_len, (const int32_t*)h_len + nr); edits.assign((const int32_t*)h_edits, (const int32_t*)h_edits + nr);
+        nops.assign((const int32_t*)h_nops, (const int32_t*)h_nops + nr);
+        if (h_off) off.assign((const int64_t*)h_off, (const int64_t*)h_off + nr);
+        if (h_ok) okv.assign((const int32_t*)h_ok, (const int32_t*)h_ok + nr);
+        int64_t total = 0;
+        if (want_strings) for (size_t i = 0; i < nr; ++i) total = std::max<int64_t>(total, off[i] + len[i] + 1);
+        if (total && h_pool) {
+            if ((size_t)total > A.pool_bytes) throw HipError{hipErrorUnknown, "CIGAR strings beyond their pool's bound", __LINE__};
+            B.wr->cigar_pool.reserve(base + (size_t)total);
+            memcpy(B.wr->cigar_pool.p + base, h_pool, (size_t)total);
+            B.wr->cigar_pool.size = base + (size_t)total;
+        }
+    } else {
+        d2h(len, A.len, A.nroots, C.stream); d2h(edits, A.edits, A.nroots, C.stream); d2h(nops, A.nops, A.nroots, C.stream);
+        if (want_strings) d2h(off, A.str_off, A.nroots, C.stream);
+        if (A.ok) d2h(okv, A.ok, A.nroots, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        int64_t total = 0;
+        if (want_strings) for (size_t i = 0; i < A.nroots; ++i) total = std::max<int64_t>(total, off[i] + len[i] + 1);
+        if (total) {
+            B.wr->cigar_pool.reserve(base + (size_t)total);
+            HIP_CHECK(hipMemcpyAsync(B.wr->cigar_pool.p + base, A.pool, (size_t)total, hipMemcpyDeviceToHost, C.stream));
+            HIP_CHECK(hipStreamSynchronize(C.stream));
+            B.wr->cigar_pool.size = base + (size_t)total;
+        }
     }
     for (size_t i = 0; i < A.nroots; ++i) {
         const int pr = SL.root_pair[i];
