@@ -88,6 +88,36 @@ static void h2d(T* dst, const std::vector<T>& src, hipStream_t s) {
     }
     HIP_CHECK(hipMemcpyAsync(dst, src.data(), bytes, hipMemcpyHostToDevice, s));
 }
+// FetchBatch: the small device arrays one place in the code reads back (two to five vectors and then a stream synchronisation)
+// arrive in the context's pinned block through ONE copy launch; above 256 KB in total, plain asynchronous copies as before.
+//   FetchBatch fb(C); fb.add(v1, d1, n); fb.add(v2, d2, n); fb.sync();      // = d2h x 2 + hipStreamSynchronize(C.stream)
+struct FetchBatch {
+    struct Item { void* dst; const void* src; size_t bytes, off; };
+    Context& C; std::vector<Item> items; size_t top = 0;
+    explicit FetchBatch(Context& c) : C(c) {}
+    template <typename T> void add(std::vector<T>& dst, const T* src, size_t n) {
+        dst.resize(n);
+        if (n == 0) return;
+        items.push_back(Item{dst.data(), src, n * sizeof(T), top});
+        top += (n * sizeof(T) + 63) & ~(size_t)63;
+    }
+    void sync() {
+        if (top <= ((size_t)256 << 10)) {
+            uint8_t* st = top ? C.small_pinned(top + 256) : nullptr;
+            {
+                CopyBatch cb(C.stream);
+                for (const Item& it : items) copy_kernel(st + it.off, it.src, it.bytes, C.stream);
+            }
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(C.stream));
+            for (const Item& it : items) memcpy(it.dst, st + it.off, it.bytes);
+        } else {
+            for (const Item& it : items) HIP_CHECK(hipMemcpyAsync(it.dst, it.src, it.bytes, hipMemcpyDeviceToHost, C.stream));
+            HIP_CHECK(hipStreamSynchronize(C.stream));
+        }
+        items.clear(); top = 0;
+    }
+};
 template <typename T>
 static void d2h(std::vector<T>& dst, const T* src, size_t n, hipStream_t s) {
     dst.resize(n);
@@ -406,8 +436,7 @@ static bool fast_finish_collect(quicked_batch& B, Context& C, const TaskList& L,
                                 const u32* d_steps, FastLeft& W) {
     const size_t nt = L.pair.size();
     std::vector<int32_t> cut, skip; std::vector<u32> steps;
-    d2h(cut, d_cut, nt, C.stream); d2h(skip, d_skip, nt, C.stream); d2h(steps, d_steps, nt, C.stream);
-    HIP_CHECK(hipStreamSynchronize(C.stream));
+    { FetchBatch fb(C); fb.add(cut, d_cut, nt); fb.add(skip, d_skip, nt); fb.add(steps, d_steps, nt); fb.sync(); }
     std::vector<int32_t> stage1_bounds;
     for (size_t t = 0; t < nt; ++t) {
         if (L.pair[t] < 0) continue;
@@ -865,10 +894,13 @@ static quicked_status_t fetch_pending(quicked_batch& B, FastLeft* left = nullptr
     if (F.kind == 1) {
         const size_t nt = F.task_pair.size();
         std::vector<int32_t> sc, ab; std::vector<u32> w;
-        d2h(sc, F.d_score, nt, C.stream);
-        if (F.d_adv) d2h(w, F.d_adv, nt, C.stream); else if (F.d_steps) d2h(w, F.d_steps, nt, C.stream);
-        if (F.d_abort) d2h(ab, F.d_abort, nt, C.stream);
-        HIP_CHECK(hipStreamSynchronize(C.stream));
+        {
+            FetchBatch fb(C);
+            fb.add(sc, F.d_score, nt);
+            if (F.d_adv) fb.add(w, F.d_adv, nt); else if (F.d_steps) fb.add(w, F.d_steps, nt);
+            if (F.d_abort) fb.add(ab, F.d_abort, nt);
+            fb.sync();
+        }
         for (size_t t = 0; t < nt; ++t) {
             const int pr = F.task_pair[t];
             if (pr < 0) continue;

@@ -544,9 +544,10 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
         pf->d_abort = (G >= 2) ? S.O.hew : nullptr;
     }
     if (fetch && R) {
-        if (G >= 2) d2h(R->hew, S.O.hew, S.nt, C.stream);       // abort flags (diagnostics)
-        d2h(R->score, S.O.score, S.nt, C.stream); d2h(R->adv, S.O.adv, S.nt, C.stream);
-        HIP_CHECK(hipStreamSynchronize(C.stream));
+        FetchBatch fb(C);
+        if (G >= 2) fb.add(R->hew, S.O.hew, S.nt);              // abort flags (diagnostics)
+        fb.add(R->score, S.O.score, S.nt); fb.add(R->adv, S.O.adv, S.nt);
+        fb.sync();
     }
 }
 
@@ -748,8 +749,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
         return;
     }
     if (fetch && R) {
-        d2h(R->score, O.score, nt, C.stream); d2h(R->hew, O.hew, nt, C.stream); d2h(R->steps, O.steps, nt, C.stream);
-        HIP_CHECK(hipStreamSynchronize(C.stream));
+        { FetchBatch fb(C); fb.add(R->score, O.score, nt); fb.add(R->hew, O.hew, nt); fb.add(R->steps, O.steps, nt); fb.sync(); }
         if (!score_only) fetch_alignments(B, C, SL, AO, want_cigar, QUICKED_WIP, nullptr);
     }
 }
@@ -1117,8 +1117,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     if (fetch) {
         if (stats) {
             std::vector<u32> adv, steps;
-            d2h(adv, O.adv, nt, C.stream); d2h(steps, O.steps, nt, C.stream);
-            HIP_CHECK(hipStreamSynchronize(C.stream));
+            { FetchBatch fb(C); fb.add(adv, O.adv, nt); fb.add(steps, O.steps, nt); fb.sync(); }
             for (size_t t = 0; t < nt; ++t) if (LL.pair[t] >= 0) { stats->fill_adv += adv[t]; stats->tb_steps += steps[t]; B.note_pair(LL.pair[t], 1, adv[t]); B.note_pair(LL.pair[t], 3, steps[t]); }
         }
         fetch_alignments(B, C, SL, AO, want_cigar, ok_status, &root_status);
