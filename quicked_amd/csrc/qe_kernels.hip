@@ -2020,6 +2020,18 @@ __device__ __forceinline__ u32 grp_ror1(u32 x) {            // lane G g + j <- l
 }
 template <int N>
 __device__ __forceinline__ int row_ror_n(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x120 + N, 0xf, 0xf, false); }
+// inclusive prefix sum over the 64 lanes of a wave in lane order, DPP only: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (six DPP moves: a chain of six ds_bpermute round trips
+// -- ~100 cycles each for a lone wave -- is what the per-chunk bookkeeping of a wave-per-task kernel used to wait for)
+__device__ __forceinline__ int wave_scan_add(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 
 // LG = 4: sixteen lanes per task, four tasks per wave (bands of <= 15 slots: QuickEd's tight bounds); LG = 6: one task per
 // wave (bands of <= 63 slots: the bounds of pairs with large indels, a user bandwidth).  FILL = false is the score-only
@@ -2123,7 +2135,11 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
         u64 qa = 0, qb = 0;
         const int new_row = last + pos_v + 1;
         if (on && ncols == 64 && ((new_row & GM) == j) && new_row < nw) load_planes_ab(pp, p0 + 64 * new_row, qa, qb);
-        const int Hm = __builtin_amdgcn_readfirstlane(wave_max(on ? rhi - first + 1 : 0));
+        // (a wave per task: every lane holds the same band; four tasks per wave: the tallest of the four)
+        const int hm_own = on ? rhi - first + 1 : 0;
+        const int Hm = (LG == 6) ? __builtin_amdgcn_readfirstlane(hm_own)
+                                 : max(max(__builtin_amdgcn_readlane(hm_own, 0), __builtin_amdgcn_readlane(hm_own, 16)),
+                                       max(__builtin_amdgcn_readlane(hm_own, 32), __builtin_amdgcn_readlane(hm_own, 48)));
         // bit s of these is the text's column s - i (mod 64)
         const int ri = i & 63;
         const u64 R0 = ri ? ((T0 << ri) | (T0 >> (64 - ri))) : T0, R1 = ri ? ((T1 << ri) | (T1 >> (64 - ri))) : T1;
@@ -2194,16 +2210,28 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
                 y = row_ror_n<4>(x); if (i >= 4) x += y;
                 y = row_ror_n<8>(x); if (i >= 8) x += y;
             } else {
-#pragma unroll
-                for (int d = 1; d < GL; d <<= 1) { y = __shfl(x, gl | ((j - d) & GM)); if (i >= d) x += y; }
+                // band order is lane order rotated by the top row's lane: the lane-order scan, less what precedes the top row,
+                // plus the wave's total for the lanes the band wraps around to
+                const int rf = __builtin_amdgcn_readfirstlane(r_first & GM);
+                const int S = wave_scan_add(x);
+                const int tot = __builtin_amdgcn_readlane(S, 63), before = __builtin_amdgcn_readlane(S, (rf + GM) & GM);
+                x = S - (rf ? before : 0) + ((j < rf) ? tot : 0);
+                (void)y;
             }
             if (inband) sc += ncols + x;
         }
         {
             // every-64-columns bookkeeping (bpm_banded.c:264-301 / 889-922), the same for all lanes of a group
-            const int s_top1 = __shfl(sc, gl | ((r_first + 1) & GM));
-            const int s_bot = __shfl(sc, gl | ((last + pos_v) & GM));
-            const int s_bot1 = __shfl(sc, gl | ((last + pos_v - 1) & GM));
+            int s_top1, s_bot, s_bot1;
+            if (LG == 6) {                                          // one task per wave: the rows' lanes are the same in all lanes
+                s_top1 = __builtin_amdgcn_readlane(sc, __builtin_amdgcn_readfirstlane((r_first + 1) & GM));
+                s_bot = __builtin_amdgcn_readlane(sc, __builtin_amdgcn_readfirstlane((last + pos_v) & GM));
+                s_bot1 = __builtin_amdgcn_readlane(sc, __builtin_amdgcn_readfirstlane((last + pos_v - 1) & GM));
+            } else {
+                s_top1 = __shfl(sc, gl | ((r_first + 1) & GM));
+                s_bot = __shfl(sc, gl | ((last + pos_v) & GM));
+                s_bot1 = __shfl(sc, gl | ((last + pos_v - 1) & GM));
+            }
             if (on && ncols == 64) {
                 const bool c1 = (first + 2 < last) && (G.fin > 64 * (first + 1));
                 const bool cut_lo = c1 && (s_top1 + (G.fin - 64 * (first + 1)) > G.cutoff);
