@@ -200,11 +200,11 @@ static TaskOut take_out(Context& C, size_t nt) {
     o.score = C.scratch_p->take<int32_t>(nt); o.first = C.scratch_p->take<int32_t>(nt); o.last = C.scratch_p->take<int32_t>(nt);
     o.posv = C.scratch_p->take<int32_t>(nt); o.hew = C.scratch_p->take<int32_t>(nt); o.nruns = C.scratch_p->take<int32_t>(nt);
     o.nops = C.scratch_p->take<int32_t>(nt); o.edits = C.scratch_p->take<int32_t>(nt); o.len = C.scratch_p->take<int32_t>(nt);
-    o.adv = C.scratch_p->take<u32>(nt); o.steps = C.scratch_p->take<u32>(nt);
+    const size_t ntp = (nt + 63) & ~(size_t)63;
+    o.adv = C.scratch_p->take<u32>(2 * ntp); o.steps = o.adv + ntp;         // one block: one memset
     o.str_off = C.scratch_p->take<int64_t>(nt + 1);
     // the work counters are summed over every slot of the list: padding slots (and tasks a kernel skips) count 0
-    HIP_CHECK(hipMemsetAsync(o.adv, 0, nt * sizeof(u32), C.stream));
-    HIP_CHECK(hipMemsetAsync(o.steps, 0, nt * sizeof(u32), C.stream));
+    HIP_CHECK(hipMemsetAsync(o.adv, 0, 2 * ntp * sizeof(u32), C.stream));
     return o;
 }
 
