@@ -26,6 +26,7 @@
 // windows on chip), k_join (Hirschberg midpoint), k_format_segs / k_scan_offsets
 // (CIGAR strings, three styles), k_check_segs / k_check_strings (CIGAR validator).
 // No MFMA (bit manipulation, not a contraction), no CUDA-compat paths.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "qe_types.h"
 
@@ -2159,10 +2160,14 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
         for (int blk = 0; blk < (LG == 4 ? 3 : 4); ++blk) {
             if (32 * blk >= nsteps) break;
             const u32 w0 = (blk & 1) ? hi32(R0) : lo32(R0), w1 = (blk & 1) ? hi32(R1) : lo32(R1);
+            // 32 steps; `whole`: all of them are inside the chunk's 64 + H - 1 (the first two blocks always), so no step asks --
+            // three scalar instructions per step of a lone wave's chain, 5 % of the kernel
+            auto steps32 = [&](auto whole_tag) {
+            constexpr bool whole = decltype(whole_tag)::value;
 #pragma unroll
             for (int sb = 0; sb < 32; ++sb) {
                 const int s = 32 * blk + sb;
-                if (s >= nsteps) continue;                         // (uniform; a break would keep the loop rolled)
+                if (!whole && s >= nsteps) continue;               // (uniform; a break would keep the loop rolled)
                 const u32 inP = grp_ror1<LG>(oP), inM = grp_ror1<LG>(oM);
                 const u32 c = (u32)(s - i);
                 if (c < len) {
@@ -2188,6 +2193,8 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
                     if (inband && 16 * q - 1 < ncols) cpk[(int64_t)q * cps] = make_uint4(cPlo, cPhi, cMlo, cMhi);
                 }
             }
+            };
+            if (32 * blk + 32 <= nsteps) steps32(std::true_type{}); else steps32(std::false_type{});
         }
         if (FILL && inband && ncols == 64 && si > 0) cpk[(int64_t)QE_CPC * cps - 64] = make_uint4(Plo, Phi, Mlo, Mhi);
         if (inband) {
