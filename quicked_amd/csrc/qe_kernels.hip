@@ -2153,6 +2153,9 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
         u32 cPlo = Plo, cPhi = Phi, cMlo = Mlo, cMhi = Mhi;        // G = 16: the checkpoint this row passed last
         const u32 len = inband ? (u32)ncols : 0u;
         const int nsteps = 64 + Hm - 1;
+        // (not in the fill of tall bands: its per-step checkpoint stores in one straight block cost 60 registers more;
+        // lane_rel = 2: tests switch the steady blocks off)
+        const bool steady_ok = !(FILL && LG == 6) && !__any(on && ncols != 64) && A.lane_rel != 2;
         // where this row's checkpoints go: q = 1 .. 3 in this chunk's slot numbering, q = 4 = the next chunk's checkpoint 0
         // one slot up (the band shift, bpm_banded.c:279-287; slot -1 does not exist and is never read)
         uint4* const cpk = FILL ? cp + (int64_t)(QE_CPC * k) * cps + (int64_t)si * 64 : nullptr;
@@ -2160,17 +2163,24 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
         for (int blk = 0; blk < (LG == 4 ? 3 : 4); ++blk) {
             if (32 * blk >= nsteps) break;
             const u32 w0 = (blk & 1) ? hi32(R0) : lo32(R0), w1 = (blk & 1) ? hi32(R1) : lo32(R1);
-            // 32 steps; `whole`: all of them are inside the chunk's 64 + H - 1 (the first two blocks always), so no step asks --
-            // three scalar instructions per step of a lone wave's chain, 5 % of the kernel
-            auto steps32 = [&](auto whole_tag) {
-            constexpr bool whole = decltype(whole_tag)::value;
+            // 16 steps (half a block); `whole`: all of them are inside the chunk's 64 + H - 1, so no step asks -- three scalar
+            // instructions per step of a lone wave's chain, 5 % of the kernel
+            // `steady`: sixteen steps from H - 1 on and before 64, in a chunk whose columns are all there -- every row of every
+            // band is at work in every one of them, so the block runs under ONE mask (the rows in their bands) and
+            // no step asks whether its lane is inside its row's columns (two vector and four scalar instructions per step).
+            // The carries come by DPP as ever; the top row's source -- the idle lane above it -- is masked out there, a DPP
+            // move leaves such a lane's destination as it was, and that is made the boundary carry (1, 0)
+            auto steps16 = [&](auto whole_tag, auto steady_tag, auto half_tag) {
+            constexpr bool whole = decltype(whole_tag)::value, steady = decltype(steady_tag)::value;
+            constexpr int half = decltype(half_tag)::value;
 #pragma unroll
-            for (int sb = 0; sb < 32; ++sb) {
+            for (int sb = 16 * half; sb < 16 * half + 16; ++sb) {
                 const int s = 32 * blk + sb;
                 if (!whole && s >= nsteps) continue;               // (uniform; a break would keep the loop rolled)
-                const u32 inP = grp_ror1<LG>(oP), inM = grp_ror1<LG>(oM);
+                const u32 inP = steady ? (u32)__builtin_amdgcn_update_dpp(1, (int)oP, LG == 4 ? 0x121 : 0x13C, 0xf, 0xf, false) : grp_ror1<LG>(oP);
+                const u32 inM = steady ? (u32)__builtin_amdgcn_update_dpp(0, (int)oM, LG == 4 ? 0x121 : 0x13C, 0xf, 0xf, false) : grp_ror1<LG>(oM);
                 const u32 c = (u32)(s - i);
-                if (c < len) {
+                if (steady || c < len) {
                     const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)w0, sb, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)w1, sb, 1);
                     const u32 elo = bitop3<0x90>(~(alo ^ m0), blo, m1), ehi = bitop3<0x90>(~(ahi ^ m0), bhi, m1);
                     u32 phhi, mhhi;
@@ -2194,7 +2204,16 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
                 }
             }
             };
-            if (32 * blk + 32 <= nsteps) steps32(std::true_type{}); else steps32(std::false_type{});
+            {   // the block's two halves, each in the cheapest form it qualifies for
+                const int s0 = 32 * blk;
+                if (steady_ok && s0 >= Hm - 1 && s0 + 16 <= 64) { if (inband) steps16(std::true_type{}, std::true_type{}, std::integral_constant<int, 0>{}); }
+                else if (s0 + 16 <= nsteps) steps16(std::true_type{}, std::false_type{}, std::integral_constant<int, 0>{});
+                else steps16(std::false_type{}, std::false_type{}, std::integral_constant<int, 0>{});
+                const int s1 = s0 + 16;
+                if (steady_ok && s1 >= Hm - 1 && s1 + 16 <= 64) { if (inband) steps16(std::true_type{}, std::true_type{}, std::integral_constant<int, 1>{}); }
+                else if (s1 + 16 <= nsteps) steps16(std::true_type{}, std::false_type{}, std::integral_constant<int, 1>{});
+                else if (s1 < nsteps) steps16(std::false_type{}, std::false_type{}, std::integral_constant<int, 1>{});
+            }
         }
         if (FILL && inband && ncols == 64 && si > 0) cpk[(int64_t)QE_CPC * cps - 64] = make_uint4(Plo, Phi, Mlo, Mhi);
         if (inband) {

@@ -705,6 +705,38 @@ def test_traceback_systolic_forced(tsys, golden, monkeypatch):
     assert cnt[1] == sum(x["fill_block_advances"] for x in tr)
 
 
+@pytest.mark.parametrize("rel", ["1", "2"])
+def test_systolic_steady_blocks_switch(rel, monkeypatch):
+    """k_banded_sys runs the sixteen-step units in which every row of every band is at work under ONE mask, the top row's
+    boundary carry coming from a DPP move that leaves a masked-out source's destination as it was (QE_LANE_REL = 1, the
+    default) or asks every step (2): same scores, CIGAR bytes and block-advance counts as the oracle either way, the
+    systolic fill and score-only forms forced, tight QuickEd bands, a user bandwidth, ragged and N input."""
+    monkeypatch.setenv("QE_LANE_REL", rel)
+    monkeypatch.setenv("QE_FILL_SYS", "1")
+    monkeypatch.setenv("QE_SCORE_SYS", "1")
+    pairs = mixed_batch()
+    rng = np.random.default_rng(41)
+    for i in range(40):
+        L = int(rng.choice([64, 65, 128, 700, 1000, 2500, 6000, 10000]))
+        e = float(rng.choice([0.0, 0.02, 0.05, 0.2]))
+        b = datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=4100 + i,
+                             indels_num=int(rng.integers(0, 3)) if L >= 2500 else 0, indels_len=150)
+        p, t = next(b.pairs())
+        if rng.random() < 0.3:
+            t = t[: max(1, len(t) - int(rng.integers(0, max(1, len(t) // 3))))]
+        pairs.append((p, t))
+    for kw in (dict(algo=0), dict(algo=2, only_score=True, bandwidth=15), dict(algo=2, bandwidth=20), dict(algo=2, only_score=True, bandwidth=40)):
+        al = capi.QuickedAligner()
+        for k, v in kw.items():
+            setattr(al._params, k, v)
+        st, out = al.alignBatch(pairs)
+        for i, (p, t) in enumerate(pairs):
+            want = oracle_cached(p, t, **kw)
+            in_domain = kw["algo"] == 0 or len(p) == 0 or len(t) == 0 or exact_cached(p, t) <= max(len(p), len(t)) * kw["bandwidth"] // 100
+            if in_domain:
+                assert out[i] == want, (rel, kw, i, len(p), len(t))
+
+
 @pytest.mark.parametrize("ssys", ["1", "0"])
 def test_score_systolic_forced(ssys, golden, monkeypatch):
     """BandEd score-only over whole texts with the band's rows as a systolic array (k_banded_sys<.., false>: sixteen lanes
