@@ -303,6 +303,7 @@ QE_API quicked_status_t quicked_pool_trim(void) {
     try {
         Context& C = ctx();
         (void)C.release_pools(nullptr, true);
+        C.release_small_pinned();                           // the pinned block of small loads and read-backs (1 MB; comes back on demand)
         { std::lock_guard<std::mutex> lk(g_ctx_mu); C.planned = 0; C.wanted = 0; }
         (void)release_unleased(C.device);                  // what threads that have ended left behind: pools ...
         retire_idle_streams(C.device);                      // ... and streams nobody is using

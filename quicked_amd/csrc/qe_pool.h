@@ -301,6 +301,9 @@ struct Context {
         }
         return small_pin;
     }
+    void release_small_pinned() {          // (its users end with a stream synchronisation: nothing of it is in flight between calls)
+        if (small_pin) { (void)hipHostFree(small_pin); small_pin = nullptr; small_pin_cap = 0; }
+    }
     void* merge_batch = nullptr;             // the stand-in object of merged early finishes (qe_driver.hip: merged_finish)
     bool util_pinned = false;                // the utility pool holds live data of the call in progress (merged_finish): not to be reclaimed
 
