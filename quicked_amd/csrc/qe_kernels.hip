@@ -2837,7 +2837,8 @@ __global__ __launch_bounds__(512) void k_traceback(TraceArgs A) {
 }
 
 // ---------------------------------------------------------------------------
-// The walk of k_traceback_sys<4> (walk_round_diag): a path is mostly plain matches along a diagonal, so the walker does not
+// The walk of k_traceback_sys<3 / 4> (walk_round_diag; described for 16 lanes and a round of 128 columns -- with 8 lanes a
+// round is 64 columns and the reductions run over half a DPP row): a path is mostly plain matches along a diagonal, so the walker does not
 // visit them column by column, and it is not handed from lane to lane either: its state (v, h, the run under construction,
 // the counters) is kept THE SAME IN ALL 16 LANES of its group, every lane runs the same code, and what a lane contributes
 // is what its own tile says.  When a round's tiles are rebuilt, every lane lays three bit planes of its tile out ALONG THE
@@ -2920,18 +2921,31 @@ __device__ __forceinline__ u64 sel_col(const u64 (&t)[TW], u32 c) {  // t[c], c 
     return c1 ? d1 : d0;
 }
 __device__ __forceinline__ u32 pair_swap(u32 x) { return (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, false); }     // quad_perm:[1,0,3,2]
-__device__ __forceinline__ u32 row_min(u32 x) {                      // the minimum over the 16 lanes of a row, in all of them
-    x = min(x, (u32)row_ror_n<1>((int)x)); x = min(x, (u32)row_ror_n<2>((int)x));
-    x = min(x, (u32)row_ror_n<4>((int)x)); return min(x, (u32)row_ror_n<8>((int)x));
+template <int LG>
+__device__ __forceinline__ u32 grp_min(u32 x) {                      // the minimum over the 16 / 8 lanes of a group, in all of them
+    if (LG == 4) {
+        x = min(x, (u32)row_ror_n<1>((int)x)); x = min(x, (u32)row_ror_n<2>((int)x));
+        x = min(x, (u32)row_ror_n<4>((int)x)); return min(x, (u32)row_ror_n<8>((int)x));
+    }
+    // eight lanes = half a DPP row: the quad's neighbour, the quad's other pair, the half row's mirror image
+    x = min(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+    x = min(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+    return min(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
 }
-__device__ __forceinline__ u32 row_max(u32 x) {
-    x = max(x, (u32)row_ror_n<1>((int)x)); x = max(x, (u32)row_ror_n<2>((int)x));
-    x = max(x, (u32)row_ror_n<4>((int)x)); return max(x, (u32)row_ror_n<8>((int)x));
+template <int LG>
+__device__ __forceinline__ u32 grp_max(u32 x) {
+    if (LG == 4) {
+        x = max(x, (u32)row_ror_n<1>((int)x)); x = max(x, (u32)row_ror_n<2>((int)x));
+        x = max(x, (u32)row_ror_n<4>((int)x)); return max(x, (u32)row_ror_n<8>((int)x));
+    }
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+    return max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
 }
 
 // one round's walk.  act / q / Rb / base: this lane's tile (base = d0 + 16 q - 64 Rb); x = the tile's place in the round
 // (0 = the walker's column tile at the round's start, 7 = the leftmost); col_r = the round's rightmost column (u = 0)
-template <int TW>
+template <int TW, int LG>
 __device__ __forceinline__ void walk_round_diag(const u64 (&tP)[TW], const u64 (&tM)[TW], const u32 (&X8)[8], const u32 (&P8)[8], const u32 (&M8)[8],
                                                 bool live, bool act, int x, int Rb, int base, int d0, int col_r, u32 inb_same, u32 inb_7, bool writer,
                                                 int& v, int& h, u32& steps, int& nmatch, RunSink& R) {
@@ -2950,7 +2964,7 @@ __device__ __forceinline__ void walk_round_diag(const u64 (&tP)[TW], const u64 (
         const u32 o = (u32)((v - h) - d0 + 7);
         const bool step = going && o <= 15u;          // (else: drifted off the diagonals the words cover -- the next round re-centres)
         const u32 oc = o & 15u;
-        const int u0 = col_r - h;                     // the walker's place in the round's columns, 0 .. 127
+        const int u0 = col_r - h;                     // the walker's place in the round's columns, 0 .. SPAN - 1
         // the first cell at or after the walker's that is not a plain match, with its class bits
         const int lo = u0 - u_base;
         const u32 keep = (lo <= 0) ? 0xFFFFu : ((lo > 15) ? 0u : ((0xFFFFu << lo) & 0xFFFFu));
@@ -2958,18 +2972,19 @@ __device__ __forceinline__ void walk_round_diag(const u64 (&tP)[TW], const u64 (
         wx &= pair_swap(wx);                          // the pair's two block rows: the cell is in one of them, the other says 1
         const u32 wm = wx & keep;
         const u32 cu = wm ? (u32)__builtin_ctz(wm) : 0u;
-        const u32 pcell = wm ? (u32)u_base + cu : 128u;
+        constexpr int SPAN = 8 << LG;                 // the round's columns: 16 per column tile, half as many tiles as lanes
+        const u32 pcell = wm ? (u32)u_base + cu : (u32)SPAN;
         const int bitpos = base + (15 - (int)cu) + (int)o - 7;
         const bool inr = act && wm != 0 && (u32)bitpos < 64u;       // the cell is in THIS lane's block row
         const u32 pb = inr ? ((sel16(P8, oc) >> cu) & 1u) : 0u, mb = inr ? ((sel16(M8, oc) >> cu) & 1u) : 0u;
         u32 pay = (pcell << 3) | (inr ? 4u : 0u) | (pb << 1) | mb;
         pay |= pair_swap(pay) & 7u;
-        pay = row_min(pay);
+        pay = grp_min<LG>(pay);
         const int ub = (int)(pay >> 3);
         const u32 cls = pay & 7u;
         const int r = step ? ub - u0 : 0;             // plain matches up the diagonal
         if (r > 0) { switch_op((int)OP_M); R.cur_len += r; nmatch += r; steps += (u32)r; v -= r; h -= r; }
-        const bool cont = step && v >= 0 && h >= 0 && ub < 128 && (cls & 4u) != 0;       // (no owner: the path left the predicted tiles)
+        const bool cont = step && v >= 0 && h >= 0 && ub < SPAN && (cls & 4u) != 0;       // (no owner: the path left the predicted tiles)
         const bool isD = cont && (cls & 2u) != 0, isI = cont && !isD && (cls & 1u) != 0, isX = cont && !isD && !isI;
         const bool owner = inr && (int)pcell == ub;
         if (isX) { switch_op((int)OP_X); R.cur_len += 1; steps += 1u; v -= 1; h -= 1; }
@@ -2980,7 +2995,7 @@ __device__ __forceinline__ void walk_round_diag(const u64 (&tP)[TW], const u64 (
                 const u64 Pw = sel_col<TW>(tP, 15u - cu);
                 rd = (u32)min(__clzll((long long)~(Pw << (63 - bit))), bit + 1);
             }
-            rd = row_max(rd);
+            rd = grp_max<LG>(rd);
             if (isD) { switch_op((int)OP_D); R.cur_len += (int)rd; steps += rd; v -= (int)rd; }
         }
         if (__any(isI)) {
@@ -2990,7 +3005,7 @@ __device__ __forceinline__ void walk_round_diag(const u64 (&tP)[TW], const u64 (
                 const u32 o1 = o + 1u;
                 more = ((sel16(M8, o1) >> (cu + 1u)) & 1u) & ~((sel16(P8, o1) >> (cu + 1u)) & 1u);
             }
-            more = row_max(more);
+            more = grp_max<LG>(more);
             int ri = 1;
             if (__any(isI && more != 0)) {
                 const int bit = v & 63;
@@ -3009,8 +3024,8 @@ __device__ __forceinline__ void walk_round_diag(const u64 (&tP)[TW], const u64 (
                 pi = min(pi, pair_swap(pi));
                 // no tile of this column pair is in the walker's row: the run's data ends at the pair's right edge
                 if (pi == 2000u) pi = (u_base + 15 < un) ? 1000u : (u32)max(u_base, un + 1);
-                pi = row_min(pi);
-                ri = (more != 0) ? (int)min(pi, 128u) - un : 1;
+                pi = grp_min<LG>(pi);
+                ri = (more != 0) ? (int)min(pi, (u32)SPAN) - un : 1;
             }
             if (isI) { switch_op((int)OP_I); R.cur_len += ri; steps += (u32)ri; h -= ri; }
         }
@@ -3163,8 +3178,8 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
             pre.q = -1; pre.Rb = -1;
             if (live && qn >= 0 && vn >= 0 && Rbn >= 0) pre = tbs_fetch(qn, Rbn);
         }
-        if (LG == 4) {
-            // 16 lanes per leaf (four walkers per wave): the tiles' cells laid out along the diagonals near the walker's, and the
+        if (LG >= 3) {
+            // 16 / 8 lanes per leaf (four / eight walkers per wave): the tiles' cells laid out along the diagonals near the walker's, and the
             // walk over the round's 128 columns in all lanes at once (walk_round_diag)
             u32 X8[8], P8[8], M8[8];
             const int d0 = v - h;
@@ -3174,7 +3189,7 @@ __global__ __launch_bounds__(256) void k_traceback_sys(TraceArgs A) {
                 for (int c = 0; c < 8; ++c) X8[c] = ~0u;
             }
             PF_MARK(pf_comp);
-            walk_round_diag<TW>(tP, tM, X8, P8, M8, live, act, x, Rb, d0 + TW * q - 64 * Rb, d0, TW * (h / TW) + TW - 1, inb_same, inb_7, j == 0,
+            walk_round_diag<TW, LG>(tP, tM, X8, P8, M8, live, act, x, Rb, d0 + TW * q - 64 * Rb, d0, TW * (h / TW) + TW - 1, inb_same, inb_7, j == 0,
                                 v, h, steps, nmatch, R);
             PF_MARK(pf_walk);
             continue;

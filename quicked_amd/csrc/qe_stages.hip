@@ -1085,13 +1085,14 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         // a launch of few waves: sixteen lanes per leaf rebuild the tiles along the path's diagonal together and hand the
         // walk from tile to tile (k_traceback_sys); what it flags (N, non-canonical symbols) stays with the one-lane kernel.
         // QE_TRACE_SYS = 0 / 1: never / always (tests)
-        // lanes per leaf: 16 up to ~three waves per SIMD (one batch of 12.5 k leaves alone: 9.7 ms against 10.3 with 8 lanes
-        // since the walk runs in all 16 lanes at once), 8 / 4 up to ~1 600 waves
+        // lanes per leaf: 16 while the launch is one round of waves (two per SIMD at 246 VGPRs: ~8 k leaves), 8 up to ~3 300
+        // waves (the walk runs in all lanes of a group at once in both: one batch of 12.5 k leaves alone 8.1 ms with 8 lanes,
+        // 8.6 with 16, 10.3 with the tile-by-tile walk of the round's first half), 4 up to ~1 700 waves
         const int tsys = env_int("QE_TRACE_SYS", -1);
         const size_t gw = (size_t)(g1 - g0) * (size_t)std::max(1, fetch ? 1 : C.in_flight);      // one-lane waves in flight
         int tlg = 0;
         if (tsys > 1) tlg = tsys == 4 ? 2 : (tsys == 8 ? 3 : 4);
-        else if (tsys != 0) tlg = (gw * 16 <= 3300 || tsys == 1) ? 4 : (gw * 8 <= 1700 ? 3 : (gw * 4 <= 1700 ? 2 : 0));
+        else if (tsys != 0) tlg = (gw * 16 <= 2100 || tsys == 1) ? 4 : (gw * 8 <= 3300 ? 3 : (gw * 4 <= 1700 ? 2 : 0));
         if (tlg) {
             tr.o_abort = C.scratch_p->take<int32_t>((size_t)(g1 - g0) * 64);
             const size_t nwv = (size_t)(g1 - g0) << tlg;
