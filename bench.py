@@ -66,6 +66,7 @@ ISSUE_CYCLES_PER_BLOCK_COLUMN = 61.0     # (2 766 x 2 + 570 x 4) / 128 block-col
 CPU_ANCHOR_PER_CORE = {"banded_score": 2463.0, "quicked": 1680.0}
 FILL_BYTES_PER_BLOCK_COLUMN = 1.25       # 16 B of {Pv, Mv} per 16 columns + 16 B of carry words per 64 (qe_types.h: QE_CP_COLS)
 STRONG_SHARE_PAIRS = 12500       # 100 k pairs over 8 GPUs (BASELINE.json north_star)
+CFG5_MAX_PER_GPU = 250000        # configs[4] is 1 M pairs over 8 GPUs = 125 k per GPU; a rank never takes more than this
 
 
 def visible_gpus():
@@ -562,7 +563,7 @@ class Bench:
                 flow["stage2_pairs"], flow["stage3_pairs"] = int(wc[6]), int(wc[7])
                 flow["deferred_pairs"] = rb.deferred_pairs()
                 if flow["stage2_pairs"] or flow["deferred_pairs"]:
-                    os.environ["QE_QUICKED_FAST"] = "0"
+                    os.environ["QE_QUICKED_FAST"] = "0"; capi.reload_env()
                     flow["timed_flow"] = "classic (host-driven stages): pairs leave stage 1 on this data"
                 else:
                     flow["timed_flow"] = ("stage-1 rule on the device, align step queued with it, where no pair may split (else host-driven "
@@ -583,7 +584,7 @@ class Bench:
             latency = time.perf_counter() - tl0
             if quick and os.environ.get("QE_QUICKED_FAST") != "0" and rb.deferred_pairs():
                 # ... and to catch what the warm-up runs could not: pairs deferred to a fetch the timed loop never made
-                os.environ["QE_QUICKED_FAST"] = "0"
+                os.environ["QE_QUICKED_FAST"] = "0"; capi.reload_env()
                 flow["timed_flow"] = "classic (host-driven stages): the fast flow deferred pairs to the fetch on this data (re-timed)"
                 flow["deferred_pairs"] = rb.deferred_pairs()
                 run_checked(True)
@@ -609,6 +610,7 @@ class Bench:
                 os.environ.pop("QE_QUICKED_FAST", None)
             else:
                 os.environ["QE_QUICKED_FAST"] = saved_fast
+            capi.reload_env()
             rb.close()
         return dict(batch=batch, scores=scores, counters=counters, elapsed=elapsed, kern_ms=kern_ms, kern_n=kern_n,
                     solo_ms=solo_ms, solo_n=solo_n, cigar_bytes=cig, flow=flow, sets=sets, latency_s=latency, params=params)
@@ -780,8 +782,12 @@ def main():
                     help="pairs of the indel-heavy QuickEd leg (4 x 800-base indels per 10 kb pair: stages 2 / 3 and band doubling, "
                          "SURVEY's own trigger set); 0: no such leg")
     ap.add_argument("--cfg4-pairs", type=int, default=10000,
-                    help="pairs of the long-read leg (BASELINE.json configs[3]: 100 kb at 10 % error, QuickEd + Hirschberg CIGAR; "
+                    help="pairs of the long-read leg (BASELINE.json configs[3]: 100 kb at 10 %% error, QuickEd + Hirschberg CIGAR; "
                          "workloads.cfg4, N = 1); 0: no such leg")
+    ap.add_argument("--cfg5-pairs", type=int, default=None,
+                    help="pairs IN TOTAL of BASELINE.json configs[4] (QuickEd score + CIGAR, 10 kb at 5 %%, sharded over the GPUs; "
+                         "workloads.cfg5 at N > 1, the 1/8 shard as workloads.cfg5_shard at N = 1); 0: no such leg; default: 1 000 000 on "
+                         "10 kb reads")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="profiling aid: no overlap between consecutive runs, so per-kernel durations are those of a kernel alone")
     ap.add_argument("--seed", type=int, default=0x51CED)
@@ -822,6 +828,8 @@ def main():
         else:
             dist.init_process_group(backend)                    # reductions on host tensors (device = None)
 
+    collective = {"backend": "none" if dist is None else backend, "tensors": "device" if device is not None else "host",
+                  "world_size": world} if dist is not None else {"backend": "none"}
     B = Bench(args, rank, world, local_rank, dist, torch, device, share)
     ranks_seen = shard.count_ranks(dist, torch, device)
 
@@ -868,6 +876,27 @@ def main():
         except Exception as e:          # noqa: BLE001  (a leg of its own: the line survives it)
             others["cfg4"] = {"error": repr(e)}
         args.length, args.error, args.cpu_budget = saved
+        B._cache = None
+        B.capi.pool_trim()
+    if args.cfg5_pairs is None:                       # the default: configs[4]'s own size on its own kind of data
+        args.cfg5_pairs = 1000000 if args.length == 10000 else 0
+    if default_shape and args.cfg5_pairs > 0 and args.indels_num == 0:
+        # BASELINE.json configs[4]: QuickEd score + CIGAR, 1 M pairs of 10 kb at 5 % sharded over the GPUs of the node
+        # (align_benchmark.c:246-284: disjoint pair ranges, one aligner each; here contiguous ranges of the seeded dataset per
+        # rank, no data-path collective, the totals through one all-reduce).  N > 1: the whole job, `cfg5_pairs` in total
+        # (125 k pairs per GPU at 8; at most CFG5_MAX_PER_GPU per GPU, so N = 2 / 3 run a smaller total and say so).  N = 1: the
+        # shard one GPU of eight gets, as `cfg5_shard`.
+        per_gpu = min(args.cfg5_pairs // max(world, 8 if world == 1 else 1), CFG5_MAX_PER_GPU)
+        total = per_gpu * world
+        B._cache = None
+        B.capi.pool_trim()
+        o = B.workload_object("quicked", per_gpu, min(args.steps, 10), 2, with_e2e=False, with_cpu=False)
+        name = "cfg5" if world > 1 else "cfg5_shard"
+        others[name] = {k: o[k] for k in ("value", "unit", "ms_per_step", "gcups", "band_gcups", "pairs_per_gpu", "total_pairs", "steps",
+                                          "runs_in_flight", "single_batch_latency_ms", "single_batch_value", "quicked_flow",
+                                          "score_checksum", "cigar_bytes_per_step") if k in o}
+        others[name]["data"] = (f"BASELINE.json configs[4]: QuickEd score + CIGAR, {total} pairs of {args.length} bp at {args.error:g} error in total over {world} GPU(s), "
+                                f"{per_gpu} per GPU and step" + ("" if world > 1 else f" (the share of one GPU of 8 of {args.cfg5_pairs} pairs)"))
         B._cache = None
         B.capi.pool_trim()
     # ---- strong scaling: `pairs` pairs in total (BASELINE.json's "100 k pairs at 8 GPUs"); at N = 1 the per-GPU share of it
@@ -939,7 +968,7 @@ def main():
         line = {
             "metric": f"alignments/sec + GCUPS, {label}",
             "value": head["value"], "unit": "alignments/s", "gcups": head["gcups"], "band_gcups": head["band_gcups"],
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": ranks_seen,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": ranks_seen, "collective": collective,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.workload}, DEVICE-RESIDENT inputs: {args.pairs} pairs/GPU x {args.length} bp @ {args.error:g} error, "

@@ -165,6 +165,11 @@ int64_t quicked_batch_deferred_pairs(quicked_batch_t* batch);
  * objects per flow; 1 = never merge. */
 quicked_status_t quicked_early_finish_stats(int64_t stats_out[4]);
 
+/* The library reads its QE_* environment switches (test hooks that force kernel forms, traces; production
+ * needs none) ONCE, at their first use, into a table; this parses the environment again.  For in-process test suites that
+ * change a switch between runs -- not to be called while other threads are inside the library. */
+quicked_status_t quicked_debug_reload_env(void);
+
 /* The device-pool planner's view of the calling thread (replaces mm_allocator, quicked_utils/src/mm_allocator.c:141-426):
  *   [0] bytes its pools hold   [1] allocations that had to take memory from this thread's other pools or from other threads
  *   (process-wide; the planner is there to keep this 0)   [2] pool sets in rotation in the last run   [3] fill sub-batches of

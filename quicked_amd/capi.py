@@ -58,7 +58,8 @@ EXPORTS = ["quicked_check_error", "quicked_status_msg", "quicked_default_params"
            "quicked_batch_configure", "quicked_batch_check_results", "quicked_batch_validate",
            "quicked_wire_words", "quicked_wire_pack", "quicked_batch_create_packed",
            "quicked_batch_reload", "quicked_batch_reload_packed", "quicked_batch_fetch", "quicked_pool_stats", "quicked_batch_cigar_view",
-           "quicked_batch_deferred_pairs", "quicked_wire_pack_pool", "quicked_wire_offsets", "quicked_wire_pack_isa", "quicked_pool_trim", "quicked_early_finish_stats"]
+           "quicked_batch_deferred_pairs", "quicked_wire_pack_pool", "quicked_wire_offsets", "quicked_wire_pack_isa", "quicked_pool_trim", "quicked_early_finish_stats",
+           "quicked_debug_reload_env"]
 
 _LIB = None
 
@@ -135,6 +136,14 @@ def lib():
     L.quicked_host_free.restype = None
     _LIB = L
     return L
+
+
+def reload_env():
+    """The library parses its QE_* switches once (qe_pool.h: SwitchTable); code that changes one in os.environ while the
+    library is loaded -- the in-process parity tests that force a kernel form, bench.py's classic-flow leg -- calls this to
+    have it parsed again.  No-op while the library is not loaded (its first use parses the environment as it is then)."""
+    if _LIB is not None and hasattr(_LIB, "quicked_debug_reload_env"):
+        _LIB.quicked_debug_reload_env()
 
 
 def pool_trim():

@@ -169,7 +169,7 @@ inline void qe_timer_stop(profiler_timer_t* t) {
 }
 
 inline double now_ms() { return mono_ms(); }
-inline bool trace_on() { static int v = -1; if (v < 0) v = getenv("QE_TRACE") ? 1 : 0; return v == 1; }
+inline bool trace_on() { return env_set("QE_TRACE"); }
 #define QE_TRACE_POINT(name) do { if (qe::trace_on()) { double t__ = qe::now_ms(); fprintf(stderr, "[qe t%03d @%.1f] %-22s +%.3f ms\n", (int)(syscall(SYS_gettid) % 1000), t__, name, t__ - tr_last); tr_last = t__; } } while (0)
 
 // ---- the device side (qe_driver.hip)

@@ -314,6 +314,11 @@ QE_API quicked_status_t quicked_pool_trim(void) {
     }
 }
 
+QE_API quicked_status_t quicked_debug_reload_env(void) {
+    qe::switches_reload();
+    return QUICKED_OK;
+}
+
 QE_API quicked_status_t quicked_early_finish_stats(int64_t stats_out[4]) {
     qe::early_finish_stats(stats_out);
     return QUICKED_OK;

@@ -1097,7 +1097,7 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
     // other queued jobs whose runs are over too: the same flow serves their pairs (merged_finish)
-    static const int merge_max = std::max(1, env_int("QE_FINISH_MERGE", 4));
+    const int merge_max = std::max(1, env_int("QE_FINISH_MERGE", 4));
     std::vector<FinishJob> group{job};
     {
         std::lock_guard<std::mutex> lk(g_fin_mu);
@@ -1164,7 +1164,7 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
             // number of pairs (12.5 k-pair batches with 1 % hard pairs: 0.54 -> 1.08 M alignments/s) -- a flow of its own
             // for a batch that left thousands (20 k indel-heavy pairs each: merged, three of them ran 5 x slower than apart)
             std::sort(items.begin(), items.end(), [](const MergeItem& a, const MergeItem& b) { return a.W.Ls.pair.size() < b.W.Ls.pair.size(); });
-            static const size_t merge_pairs = (size_t)std::max(0, env_int("QE_FINISH_MERGE_PAIRS", 8192));
+            const size_t merge_pairs = (size_t)std::max(0, env_int("QE_FINISH_MERGE_PAIRS", 8192));
             size_t nm = 0, pairs = 0;
             while (nm < items.size() && pairs + items[nm].W.Ls.pair.size() <= merge_pairs) pairs += items[nm++].W.Ls.pair.size();
             if (nm < 2) nm = 0;
@@ -1205,7 +1205,16 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
 }
 
 static int g_fin_limit = 3;                          // threads that may take work now (QE_FINISHERS at the last submit; under g_fin_mu)
+static int g_fin_exited = 0, g_fin_exited_joined = 0;   // threads that have left finisher_loop / of those, joined by a retire (under g_fin_mu)
+static std::condition_variable& g_fin_exit_cv = *new std::condition_variable;
+static void finisher_loop(int index);
 static void finisher_main(int index) {
+    finisher_loop(index);
+    std::lock_guard<std::mutex> lk(g_fin_mu);
+    ++g_fin_exited;
+    g_fin_exit_cv.notify_all();
+}
+static void finisher_loop(int index) {
     for (;;) {
         FinishJob job;
         {
@@ -1225,8 +1234,7 @@ static void finisher_main(int index) {
             (void)hipGetLastError();
         }
         catch (const std::exception& e) { fprintf(stderr, "[quicked_hip] early finish: %s\n", e.what()); }
-        --g_fin_busy;
-        if (g_fin_stop.load()) return;               // exiting: the batch objects may be gone
+        if (g_fin_stop.load()) { --g_fin_busy; return; }      // exiting: the batch objects may be gone
         taken.push_back(job);
         for (const FinishJob& j : taken) {
             // notified under the lock: quicked_batch_destroy, which waits for fin_jobs == 0 under fin_mu, must not be able to
@@ -1235,6 +1243,10 @@ static void finisher_main(int index) {
             --j.B->fin_jobs;
             j.B->fin_cv.notify_all();
         }
+        // busy until the bookkeeping above is done: it takes batches' fin_mu, and a caller that holds one of those may be
+        // waiting for g_fin_pool_mu in finisher_submit -- finisher_retire, which joins this thread with that mutex held, must
+        // therefore not start while this thread can still block on a fin_mu (it backs off while anything is busy)
+        --g_fin_busy;
     }
 }
 // at process exit (this library's destructors run before the HIP runtime's, which it depends on): no new early-finish work,
@@ -1243,12 +1255,21 @@ static void finisher_main(int index) {
 // destructors run before the HIP runtime's, which it depends on) no new work is taken, a job in progress notices the stop
 // flag at its next poll, and every thread is joined.
 __attribute__((destructor)) static void finisher_shutdown() {
-    std::lock_guard<std::mutex> pl(g_fin_pool_mu);
     g_fin_stop.store(true);
+    // the pool is taken out under its mutex and joined without it (a caller blocked in finisher_submit behind a join would
+    // keep a batch's fin_mu from a thread that is being joined); a thread that does not come back within 5 s -- stuck in a
+    // runtime that is itself shutting down -- is detached rather than waited for
+    std::vector<std::thread> pool;
+    { std::lock_guard<std::mutex> pl(g_fin_pool_mu); pool.swap(g_fin_pool); }
     { std::lock_guard<std::mutex> lk(g_fin_mu); g_fin_q.clear(); }
     g_fin_cv.notify_all();
-    for (std::thread& t : g_fin_pool) if (t.joinable()) t.join();
-    g_fin_pool.clear();
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(5);
+    {
+        std::unique_lock<std::mutex> lk(g_fin_mu);
+        g_fin_exit_cv.wait_until(lk, t_end, [&] { return g_fin_exited >= (int)pool.size() + g_fin_exited_joined; });
+    }
+    const bool all_out = [&] { std::lock_guard<std::mutex> lk(g_fin_mu); return g_fin_exited >= (int)pool.size() + g_fin_exited_joined; }();
+    for (std::thread& t : pool) { if (!t.joinable()) continue; if (all_out) t.join(); else t.detach(); }
 }
 // quicked_pool_trim(): a process that is done with its batches gives the threads back too -- only while none of them has
 // work (they start again on demand)
@@ -1260,10 +1281,13 @@ void finisher_retire() {
         g_fin_retire = true;
     }
     g_fin_cv.notify_all();
+    // every thread is idle or on its way out (nothing queued, nothing busy -- and busy covers a thread's fin_mu bookkeeping):
+    // none of them can be waiting for a mutex a caller behind g_fin_pool_mu holds, so joining here cannot cycle
+    const int joined = (int)g_fin_pool.size();
     for (std::thread& t : g_fin_pool) if (t.joinable()) t.join();
     g_fin_pool.clear();
     std::lock_guard<std::mutex> lk(g_fin_mu);
-    g_fin_retire = false; g_fin_threads = 0; g_fin_idle = 0;
+    g_fin_retire = false; g_fin_threads = 0; g_fin_idle = 0; g_fin_exited_joined += joined;
 }
 
 // called by run_batch with B.fin_mu held

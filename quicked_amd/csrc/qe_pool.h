@@ -55,8 +55,51 @@ struct HipError { hipError_t e; const char* what; int line; };
         if (e__ != hipSuccess) throw qe::HipError{e__, #expr, __LINE__};            \
     } while (0)
 
-inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-inline bool pool_trace() { static int v = -1; if (v < 0) v = getenv("QE_TRACE_POOL") ? 1 : 0; return v == 1; }
+// ---------------------------------------------------------------------------
+// The library's switches.  Every QE_* environment variable it knows is read ONCE, the first time any of them is asked
+// for, into one immutable table; the launch path only ever looks names up in that table (no getenv per stage call,
+// nothing that races an embedding application's setenv).  Production needs none of them: they force kernel forms for the
+// parity tests, lower thresholds so that small inputs reach deep paths, and switch traces on.  A name that is not in
+// the list is a programming error.  quicked_debug_reload_env() (tests: the in-process suites change switches between
+// runs) parses the environment again; it must not run concurrently with other calls into the library.
+// ---------------------------------------------------------------------------
+struct SwitchTable {
+    static constexpr int N = 28;
+    static constexpr const char* names[N] = {
+        "QE_QUICKED_FAST", "QE_QUICKED_EST", "QE_FINISH_MERGE", "QE_FINISH_MERGE_PAIRS", "QE_FINISHERS", "QE_WAVE_PRIO", "QE_LANE_REL",
+        "QE_COOP_G", "QE_COOP_FILL_G", "QE_COOP_LDS", "QE_WAVE", "QE_SCORE_SYS", "QE_STAGE3_DEVICE", "QE_FORMAT_WAVE", "QE_WINDOWED_CP",
+        "QE_WINDOWED_QUAD", "QE_WINDOWED_SYS", "QE_SPLIT_BYTES", "QE_FILL_SYS", "QE_COOP_TALL_FILL", "QE_FILL_MULTI", "QE_TRACE_SYS",
+        "QE_TRACE", "QE_TRACE_POOL", "QE_OOM_WAIT_MS", "QE_SCORE_STRIP", "QE_SCORE_WAVES", "QE_LONE_SPLIT"};
+    bool set[N];
+    long long value[N];
+    SwitchTable() {
+        for (int i = 0; i < N; ++i) {
+            const char* e = getenv(names[i]);
+            set[i] = e != nullptr;
+            value[i] = e ? strtoll(e, nullptr, 10) : 0;
+        }
+    }
+};
+inline std::atomic<const SwitchTable*> g_switches{nullptr};
+inline const SwitchTable& switches() {
+    const SwitchTable* t = g_switches.load(std::memory_order_acquire);
+    if (!t) {
+        const SwitchTable* fresh = new SwitchTable();
+        if (g_switches.compare_exchange_strong(t, fresh, std::memory_order_acq_rel)) t = fresh;
+        else delete fresh;
+    }
+    return *t;
+}
+inline void switches_reload() { g_switches.store(new SwitchTable(), std::memory_order_release); }     // the old table stays (a reader may hold it): a few hundred bytes per reload, tests only
+inline int switch_index(const char* name) {
+    for (int i = 0; i < SwitchTable::N; ++i) if (strcmp(SwitchTable::names[i], name) == 0) return i;
+    fprintf(stderr, "[quicked_hip] internal error: unknown switch %s\n", name);
+    abort();
+}
+inline bool env_set(const char* name) { return switches().set[switch_index(name)]; }
+inline long long env_ll(const char* name, long long dflt) { const SwitchTable& t = switches(); const int i = switch_index(name); return t.set[i] ? t.value[i] : dflt; }
+inline int env_int(const char* name, int dflt) { return (int)env_ll(name, dflt); }
+inline bool pool_trace() { return env_set("QE_TRACE_POOL"); }
 inline double mono_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 // ---------------------------------------------------------------------------
@@ -90,7 +133,7 @@ inline void device_malloc(void** p, size_t bytes, int device, DevicePool* keep, 
         // other threads are in the middle of runs: ask them to shrink, and take what comes free
         (void)hipGetLastError();
         ++bk.pressure;
-        static const int wait_ms = env_int("QE_OOM_WAIT_MS", 10000);
+        const int wait_ms = env_int("QE_OOM_WAIT_MS", 10000);
         const double t_end = mono_ms() + wait_ms;
         if (pool_trace()) fprintf(stderr, "[qe-pool] out of memory for %.2f GB: waiting up to %d ms for other threads\n", bytes / 1e9, wait_ms);
         while (e == hipErrorOutOfMemory && mono_ms() < t_end) {
@@ -292,17 +335,20 @@ struct Context {
     // batch_load returns (it ends with a stream synchronisation)
     uint8_t* small_pin = nullptr;
     size_t small_pin_cap = 0;
+    std::atomic<bool> small_pin_set{false};      // readable without `busy`: a reclaim pass asks whether there is anything to free
     uint8_t* small_pinned(size_t bytes) {
         if (small_pin_cap < bytes) {
             if (small_pin) { (void)hipHostFree(small_pin); small_pin = nullptr; small_pin_cap = 0; }
             const size_t cap = std::max(bytes, (size_t)1 << 20);
             HIP_CHECK(hipHostMalloc((void**)&small_pin, cap, hipHostMallocDefault));
             small_pin_cap = cap;
+            small_pin_set = true;
         }
         return small_pin;
     }
     void release_small_pinned() {          // (its users end with a stream synchronisation: nothing of it is in flight between calls)
         if (small_pin) { (void)hipHostFree(small_pin); small_pin = nullptr; small_pin_cap = 0; }
+        small_pin_set = false;
     }
     void* merge_batch = nullptr;             // the stand-in object of merged early finishes (qe_driver.hip: merged_finish)
     bool util_pinned = false;                // the utility pool holds live data of the call in progress (merged_finish): not to be reclaimed
@@ -519,6 +565,7 @@ inline Context* lease_context(int device) {
 // the calling thread's context on tl_device, `busy` held until the outermost ApiScope closes
 inline Context& ctx() {
     if (tl_api_depth <= 0) { fprintf(stderr, "[quicked_hip] internal error: ctx() outside an API scope\n"); abort(); }
+    bool fresh_lease = false;
     if (!tl_ctx || tl_ctx->device != tl_device) {
         tl_ctx = nullptr;
         for (Context* c : tl_leases.v) if (c->device == tl_device) tl_ctx = c;
@@ -526,10 +573,7 @@ inline Context& ctx() {
             if (tl_device < 0 || tl_device >= QE_MAX_DEVICES) throw HipError{hipErrorInvalidDevice, "device index", __LINE__};
             tl_ctx = lease_context(tl_device);
             tl_leases.v.push_back(tl_ctx);
-            // what the previous lessee left: its plan and its degraded mode are not this thread's
-            tl_ctx->memory_tight = false; tl_ctx->tight_left = 0; tl_ctx->tight_spell = 16;
-            tl_ctx->kev_used = 0; tl_ctx->seen_total = 0; tl_ctx->seen_epoch = ~(uint64_t)0;
-            tl_ctx->pressure_seen = g_book[tl_device].pressure.load();
+            fresh_lease = true;
         }
     }
     Context* C = tl_ctx;
@@ -537,6 +581,15 @@ inline Context& ctx() {
         C->busy.lock();              // a reclaiming thread may hold it for the time it takes to drain and free this context's pools
         C->in_call = true;
         tl_locked.push_back(C);
+    }
+    if (fresh_lease) {
+        // what the previous lessee left: its plan and its degraded mode are not this thread's.  Only with `busy` held: a
+        // reclaiming or stream-retiring thread that try_lock'ed this context while it had no lessee may still be writing
+        // the same fields (retire_streams resets kev_used) -- a fresh lease always reaches this point with tl_locked not
+        // yet holding C, so the lock above has just been taken.
+        C->memory_tight = false; C->tight_left = 0; C->tight_spell = 16;
+        C->kev_used = 0; C->seen_total = 0; C->seen_epoch = ~(uint64_t)0;
+        C->pressure_seen = g_book[tl_device].pressure.load();
     }
     if (tl_bound_device != tl_device) { HIP_CHECK(hipSetDevice(tl_device)); tl_bound_device = tl_device; }
     C->init();
@@ -600,7 +653,8 @@ inline bool reclaim(int device, int level, DevicePool* keep) {
     { std::lock_guard<std::mutex> lk(g_ctx_mu); list = g_ctx_all; }
     bool freed = false;
     for (Context* c : list) {
-        if (c == me || c->device != device || c->held.load() == 0) continue;
+        const bool pinned_left = !c->leased.load() && c->small_pin_set.load();      // an ended thread's pinned block (>= 1 MB) goes with its pools
+        if (c == me || c->device != device || (c->held.load() == 0 && !pinned_left)) continue;
         if (level == 1 && c->leased.load()) continue;
         std::unique_lock<std::mutex> lk(c->busy, std::try_to_lock);
         if (!lk.owns_lock()) continue;
@@ -608,6 +662,7 @@ inline bool reclaim(int device, int level, DevicePool* keep) {
         if (pool_trace()) fprintf(stderr, "[qe-pool] reclaim level %d: context %p (%s) gives %.2f GB back\n", level, (void*)c, c->leased.load() ? "idle thread" : "no lease", c->held.load() / 1e9);
         freed |= c->release_pools(nullptr, true);
         if (!c->leased.load()) {
+            c->release_small_pinned();         // under `busy`; nothing of it is in flight between calls
             std::unique_lock<std::shared_mutex> life(g_stream_life, std::try_to_lock);
             if (life.owns_lock()) c->retire_streams(true);
         }

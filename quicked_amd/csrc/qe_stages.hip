@@ -19,7 +19,7 @@ namespace qe {
 // ---------------------------------------------------------------------------
 // The cooperative forms are launches of few waves, each a serial chain; next to a chip-filling launch of another run a lone
 // wave gets a third of its SIMD's issue slots.  s_setprio 3 in those kernels (QE_WAVE_PRIO=0: off) puts them first in line.
-static int wave_prio() { static int v = -1; if (v < 0) { const char* e = getenv("QE_WAVE_PRIO"); v = e ? atoi(e) : 1; } return v; }
+static int wave_prio() { return env_int("QE_WAVE_PRIO", 1); }
 template <class Args> static Args with_prio(Args a) { a.prio = wave_prio(); return a; }
 
 template <typename Kernel, typename Args>
@@ -265,7 +265,8 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
 // lanes per alignment for the cooperative score-only kernel: enough waves to fill the chip
 // (>= ~4 per SIMD) while every lane keeps >= 2 band slots; QE_COOP_G overrides (0 / 1 = off)
 static int coop_lanes(const TaskList& L, int in_flight = 1, bool fill = false) {
-    const char* e = getenv(fill ? "QE_COOP_FILL_G" : "QE_COOP_G");
+    const char* const e_name = fill ? "QE_COOP_FILL_G" : "QE_COOP_G";
+    const bool e = env_set(e_name);
     int min_nsl = 1 << 30, n_max = 1;
     size_t live = 0;
     for (size_t t = 0; t < L.pair.size(); ++t) {
@@ -281,7 +282,7 @@ static int coop_lanes(const TaskList& L, int in_flight = 1, bool fill = false) {
     // 8 k / 16 k pairs are best at G = 4, 32 k at G = 2, 50 k and up at G = 1), more for longer reads, whose one-lane
     // latency grows with their length (100 kb half passes: 526 -> 430 ms from G = 8 to 32)
     const size_t target = std::min<size_t>(4096, (size_t)700 * (size_t)std::max(1, n_max / 10000));
-    if (e) G = atoi(e);
+    if (e) G = env_int(e_name, 1);
     else
         while (G < 64 && ((live * G) / 64) * (size_t)std::max(1, in_flight) < target) G *= 2;      // runs in flight fill the chip together
     // the band-height test first + 2 < last must stay decidable G-2 chunks early: keep the band >= 3 G + 4 slots
@@ -530,7 +531,7 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
                              bool fetch, int32_t** d_score_out, PendingFetch* pf = nullptr) {
     // one wavefront per alignment only where the cooperative on-chip form has no room (a band of fewer than 8 slots): with
     // G = 8 lanes per alignment and 4-slot passes that form does a 10 kb pair in 2.7 ms, the wave form in 4.3
-    const bool forced = getenv("QE_COOP_G") != nullptr || env_int("QE_WAVE", -1) == 1;      // tests of the other forms
+    const bool forced = env_set("QE_COOP_G") || env_int("QE_WAVE", -1) == 1;      // tests of the other forms
     const int lg = forced ? 0 : sys_score_lanes(L, fetch ? 1 : C.in_flight);
     const int G0 = lg ? 1 : coop_lanes(L, fetch ? 1 : C.in_flight);
     const bool wave = !lg && wave_form_wanted(L) && (G0 < 2 || env_int("QE_WAVE", -1) == 1);
@@ -720,7 +721,10 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
         // QE_WINDOWED_SYS = 0 / 1: never / wherever eligible (tests)
         const int wsys = env_int("QE_WINDOWED_SYS", -1);
         const size_t waves = (size_t)ng * 16 * (size_t)std::max(1, fetch ? 1 : C.in_flight);
-        if (score_only && W <= 15 && a.cp_path != 0 && (wsys == 1 || (wsys != 0 && waves <= 4096))) {
+        // not for W == 2 with the x86 SSE semantics (bpm_windowed.c:577: the SSE window kernel runs whenever window_size == 2
+        // and force_scalar is off, whatever the overlap): k_windowed_sys computes the scalar kernel's windows, the one-lane
+        // kernel's history path has the SSE boundary pattern
+        if (score_only && W <= 15 && !(sse && W == 2) && a.cp_path != 0 && (wsys == 1 || (wsys != 0 && waves <= 4096))) {
             a.o_abort = C.scratch_p->take<int32_t>(nt);
             launch_groups(C, k_windowed_sys, with_prio(a), nt / 4, 4, 0, /* chain */ false, (size_t)40 * 1024);
             a.only_if = a.o_abort;
@@ -763,8 +767,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
 // ---------------------------------------------------------------------------
 // BUFFER_SIZE_16M of bpm_hirschberg.c:65; QE_SPLIT_BYTES lowers it so tests can force many split levels on small inputs
 static uint64_t split_threshold() {
-    const char* e = getenv("QE_SPLIT_BYTES");
-    return e ? (uint64_t)strtoull(e, nullptr, 10) : ((uint64_t)1 << 24);
+    return (uint64_t)env_ll("QE_SPLIT_BYTES", (long long)1 << 24);
 }
 static void reset_host_results(quicked_batch& B) {
     B.wr->score.assign((size_t)B.n, -1);
@@ -971,7 +974,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     // (first + 2 < last) cannot be decided chunks ahead, and the cooperative protocol hands most leaves back to the
     // one-lane kernel (config 4's leaves: both kernels ran, 45 + 36 ms instead of 38).  A user bandwidth leaves the band
     // tall: few long BandEd alignments with CIGAR fill with G lanes each.  QE_COOP_FILL_G forces a width (tests).
-    const bool fill_forced = getenv("QE_COOP_FILL_G") != nullptr;
+    const bool fill_forced = env_set("QE_COOP_FILL_G");
     int Gfill = (env_int("QE_COOP_LDS", 1) == 0 || (tight_runs && !fill_forced)) ? 1 : coop_lanes(LL, fetch ? 1 : C.in_flight, true);
     // Round 4: ... except where the bound is LARGE.  A pair with large indels has a bound of thousands, its band is 40-60
     // slots tall for most of its length (the edge pruning only bites as the score nears the cutoff), and a launch of such

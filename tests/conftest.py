@@ -18,3 +18,25 @@ def golden():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, with one addition: libquicked_hip.so parses its QE_* switches once (qe_pool.h: SwitchTable), so a
+    test that sets or removes one while the library is loaded has it parsed again (quicked_debug_reload_env) -- and once
+    more when the test's changes are undone."""
+    from quicked_amd import capi
+    set_, del_ = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, prepend=None):
+        set_(name, value, prepend)
+        capi.reload_env()
+
+    def delenv(name, raising=True):
+        del_(name, raising)
+        capi.reload_env()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield monkeypatch
+    monkeypatch.undo()
+    capi.reload_env()

@@ -8,7 +8,9 @@ import test_gpu_parity as T
 
 
 class _MP:
-    def setenv(self, k, v): os.environ[k] = v
+    def setenv(self, k, v):
+        os.environ[k] = v
+        T.capi.reload_env()          # the library parses its switches once (qe_pool.h: SwitchTable)
 
 
 first, count = int(sys.argv[1]), int(sys.argv[2])

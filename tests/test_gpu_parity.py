@@ -40,6 +40,16 @@ def exact_cached(p, t):
     return _EXACT_MEMO[key]
 
 
+def oracle_many(pairs, threads=None, **kw):
+    """oracle_cached over many pairs on the host's cores (ctypes releases the GIL inside the C oracle): the strided
+    samples of the full-size tests are >= 1 000 pairs of 10 kb"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or max(1, min(32, len(os.sched_getaffinity(0))))
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(lambda pt: oracle_cached(pt[0], pt[1], **kw), pairs))
+
+
 def gpu_batch(batch, **kw):
     """-> (scores, statuses, cigars or None, counters) through quicked_batch_*"""
     rb = capi.ResidentBatch(batch)
@@ -267,15 +277,82 @@ def test_configs_2_and_3_at_full_size():
     finally:
         rb.close()
         capi.pool_trim()                  # 100 k-pair QuickEd pools (five sets): not this test's to leave to the ones after it
-    pairs = whole.pairs()
-    for i, (p, t) in enumerate(pairs):
-        if i % 1999:
-            continue
-        want = oracle_cached(p, t, algo=0)
-        assert (capi.QUICKED_WIP, int(s_q[i]), cig[i]) == want, i
-        assert oracle_cached(p, t, algo=2, only_score=True, bandwidth=15)[1] == s_b[i], i
-        if O.have_ref():
-            assert O.ref_align(p, t, algo=0) == want, i
+    idx = list(range(0, N, 97))                                              # 1 031 pairs: status, score and CIGAR bytes
+    sample = [(whole.pattern(i), whole.text(i)) for i in idx]
+    want_q = oracle_many(sample, algo=0)
+    want_b = oracle_many(sample, algo=2, only_score=True, bandwidth=15)
+    for i, wq, wb in zip(idx, want_q, want_b):
+        assert (capi.QUICKED_WIP, int(s_q[i]), sha(cig[i])) == (wq[0], wq[1], sha(wq[2])), i
+        assert wb[1] == s_b[i], i
+    if O.have_ref():
+        for i, (p, t), wq in list(zip(idx, sample, want_q))[::20]:
+            assert O.ref_align(p, t, algo=0) == wq, i
+
+
+def test_config_5_shard_at_full_size():
+    """BASELINE configs[4] (1 M pairs of 10 kb at 5 %, QuickEd score + CIGAR over 8 GPUs) at the size ONE GPU of the eight
+    sees: shard 3 of 8 = pairs [375 000, 500 000) of the seeded dataset (quicked_amd/shard.py; align_benchmark.c:246-284 hands
+    its threads disjoint pair ranges the same way).  Every CIGAR passes the device-side validator and carries its score as
+    edit count; status, score and CIGAR bytes equal the oracle's on every 250th pair; and a shard generated on its own is
+    the same data as that range of a larger one (what makes the ranks independent)."""
+    from quicked_amd import shard
+    first, count, total = shard.plan(1000000, 3, 8, "strong")
+    assert (first, count, total) == (375000, 125000, 1000000)
+    part = datagen.generate(count, 10000, 0.05, seed=0x51CED, first=first)
+    probe = datagen.generate(3, 10000, 0.05, seed=0x51CED, first=first + 1000)
+    assert [part.pattern(1000 + k) for k in range(3)] == [probe.pattern(k) for k in range(3)]
+    rb = capi.ResidentBatch(part)
+    try:
+        rb.configure(check=True)
+        assert rb.run(capi.make_params(algo=0), sync=True) == capi.QUICKED_WIP
+        s_q, st_q = rb.scores()
+        assert (st_q == capi.QUICKED_WIP).all()
+        assert 430 < int(s_q.min()) and int(s_q.max()) < 530
+        assert bool(rb.check_results().all())                    # validity + edit count == score, on the device, all 125 k
+        cig = rb.cigars()
+        # the stream form the bench times (queued runs, nothing fetched in between) leaves the same results
+        for _ in range(3):
+            assert rb.run(capi.make_params(algo=0), sync=False) >= 0
+        assert rb.fetch() >= 0
+        s2, st2 = rb.scores()
+        assert (s2 == s_q).all() and (st2 == st_q).all() and rb.deferred_pairs() == 0
+    finally:
+        rb.close()
+        capi.pool_trim()
+    idx = list(range(0, count, 250))
+    want = oracle_many([(part.pattern(i), part.text(i)) for i in idx], algo=0)
+    for i, w in zip(idx, want):
+        assert (capi.QUICKED_WIP, int(s_q[i]), sha(cig[i])) == (w[0], w[1], sha(w[2])), i
+
+
+def test_config_4_at_full_size():
+    """BASELINE configs[3] at its own size: 10 k pairs of 100 kb at 10 %, QuickEd + Hirschberg CIGAR (every pair splits,
+    bpm_hirschberg.c:63-65).  The device-side validator passes every CIGAR (valid + edit count == score), the score
+    equals BandEd score-only's at bandwidth 15 on every pair (two different kernels, the same exact distance), and status,
+    score and CIGAR bytes equal the oracle's on every 400th pair."""
+    N = 10000
+    whole = datagen.generate(N, 100000, 0.10, seed=0x51CED)
+    rb = capi.ResidentBatch(whole)
+    try:
+        rb.configure(check=True)
+        assert rb.run(capi.make_params(algo=0), sync=True) == capi.QUICKED_WIP
+        s_q, st_q = rb.scores()
+        s_q = s_q.copy()
+        assert (st_q == capi.QUICKED_WIP).all()
+        assert bool(rb.check_results().all())
+        cig = rb.cigars()
+        capi.pool_trim()
+        assert rb.run(capi.make_params(algo=2, only_score=True, bandwidth=15), sync=True) == capi.QUICKED_WIP
+        s_b, st_b = rb.scores()
+        assert (st_b == capi.QUICKED_WIP).all() and (s_b == s_q).all()
+        assert 8500 < int(s_q.min()) and int(s_q.max()) < 9900            # SURVEY 8(d): ~9.2 k on this generator
+    finally:
+        rb.close()
+        capi.pool_trim()
+    idx = list(range(0, N, 400))
+    want = oracle_many([(whole.pattern(i), whole.text(i)) for i in idx], algo=0)
+    for i, w in zip(idx, want):
+        assert (capi.QUICKED_WIP, int(s_q[i]), sha(cig[i])) == (w[0], w[1], sha(w[2])), i
 
 
 def test_hirschberg_forced_deep_splits(monkeypatch):
@@ -324,12 +401,42 @@ def test_align_benchmark_harness(tmp_path):
         assert "INACCURATE SCORE" not in r.stderr or algo == "edit-windowed"      # WindowEd is a bound, not exact
         assert "Alignments.Correct     100/100" in r.stderr
     # --verbose: the stage-timer report of align_benchmark.c:116-128 (two batches of 64 / 36 pairs -> two laps)
-    r = subprocess.run([exe, "-a", "quicked", "-i", str(seq), "--batch-size", "64", "--verbose"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
-    for name in ("Windowed Small", "Windowed Large", "Banded", "Align"):
-        assert f"=> Time.{name}" in r.stderr
-    assert [l for l in r.stderr.splitlines() if "Time.Windowed Small" in l][0].rstrip().endswith("(2 calls)")
-    assert [l for l in r.stderr.splitlines() if "Time.Align " in l][0].rstrip().endswith("(2 calls)")
+    # the long option takes the level, -v is level 1 (align_benchmark_params.c:126-127, 241-250)
+    for flags in (["--verbose", "2"], ["-v"], ["--verbose=1"]):
+        r = subprocess.run([exe, "-a", "quicked", "-i", str(seq), "--batch-size", "64"] + flags, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        for name in ("Windowed Small", "Windowed Large", "Banded", "Align"):
+            assert f"=> Time.{name}" in r.stderr
+        assert [l for l in r.stderr.splitlines() if "Time.Windowed Small" in l][0].rstrip().endswith("(2 calls)")
+        assert [l for l in r.stderr.splitlines() if "Time.Align " in l][0].rstrip().endswith("(2 calls)")
+        assert f"Total.reads              {len(pairs)}" in r.stderr
+    r = subprocess.run([exe, "-a", "quicked", "-i", str(seq), "--verbose", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "must be in {0,1,2,3,4}" in r.stderr
+
+
+def test_align_benchmark_totals_through_rccl_on_one_device(tmp_path):
+    """tools/align_benchmark --force-rccl: the multi-device totals path (dlopen librccl, ncclCommInitAll, a grouped
+    ncclAllReduce on device buffers, ncclCommDestroy: align_benchmark.c:246-284's reduction mapped to devices) executed with the
+    ONE device this box has -- a one-rank communicator -- and checked by the tool itself against the host-summed totals; the
+    printed figures must equal the plain run's."""
+    import re
+    import subprocess
+    from quicked_amd import build
+    exe = build.build_harness()
+    batch = datagen.generate(count=300, length=1200, error=0.06, seed=81)
+    seq = tmp_path / "in.seq"
+    with open(seq, "wb") as f:
+        for p, t in batch.pairs():
+            f.write(b">" + p + b"\n<" + t + b"\n")
+    got = {}
+    for tag, extra in (("plain", []), ("rccl", ["--force-rccl"]), ("rccl_t3", ["--force-rccl", "-t", "3", "--devices", "1"])):
+        r = subprocess.run([exe, "-a", "quicked", "-i", str(seq), "-c", "correct", "--batch-size", "128"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        got[tag] = (re.search(r"Total\.reads\s+(\d+)", r.stderr).group(1), re.search(r"Score\.sum (-?\d+)", r.stderr).group(1),
+                    re.search(r"Alignments\.Correct\s+(\d+/\d+)", r.stderr).group(1))
+        assert ("Totals.by ncclAllReduce" in r.stderr) == (tag != "plain"), r.stderr
+    assert got["plain"] == got["rccl"] == got["rccl_t3"] and got["plain"][0] == "300", got
 
 
 def test_align_benchmark_worker_threads_write_the_same_file(tmp_path):
@@ -393,7 +500,7 @@ def test_randomised_shapes_and_params(seed, monkeypatch):
                   force_scalar=bool(rng.integers(0, 2)))
         if algo in (0, 1):
             W = int(rng.choice([2, 3, 5, 9]))
-            kw.update(window_size=W, overlap_size=int(rng.integers(1, W)))
+            kw.update(window_size=W, overlap_size=int(rng.integers(0, W)))
         if algo == 0:
             kw.update(hew_threshold=(int(rng.choice([10, 40])),) * 2, hew_percentage=(int(rng.choice([1, 15])),) * 2)
         al = capi.QuickedAligner()
@@ -534,6 +641,11 @@ def test_windowed_systolic_forced(wsys, golden, monkeypatch):
     for kw in (dict(algo=1, only_score=True), dict(algo=1, only_score=True, window_size=3, overlap_size=1),
                dict(algo=1, only_score=True, window_size=4, overlap_size=2), dict(algo=1, only_score=True, window_size=7, overlap_size=5),
                dict(algo=1, only_score=True, window_size=15, overlap_size=1),
+               # W == 2 away from the on-chip (2, 1) shape: the reference runs its SSE window kernel there whenever force_scalar
+               # is off, whatever the overlap (bpm_windowed.c:577) -- scores differ from the scalar kernel's on most pairs
+               dict(algo=1, only_score=True, window_size=2, overlap_size=0),
+               dict(algo=1, only_score=True, window_size=2, overlap_size=0, force_scalar=True),
+               dict(algo=0, window_size=2, overlap_size=0, hew_threshold=(10, 10), hew_percentage=(1, 1)),
                dict(algo=0, hew_threshold=(10, 10), hew_percentage=(1, 1)),
                dict(algo=0, window_size=5, overlap_size=2, hew_threshold=(10, 40), hew_percentage=(1, 15))):
         al = capi.QuickedAligner()
@@ -1597,7 +1709,7 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     n = 3000
-    common = ["--steps", "2", "--warmup", "1", "--length", "2000", "--no-cpu-baseline", "--e2e-batches", "3"]
+    common = ["--steps", "2", "--warmup", "1", "--length", "2000", "--no-cpu-baseline", "--e2e-batches", "3", "--cfg5-pairs", "5000"]
     env = dict(os.environ, QE_BENCH_SHARE_GPU="1", QE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "2", "--pairs", str(n)] + common,
@@ -1614,6 +1726,47 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     assert two["strong"]["total_pairs"] == n and two["strong"]["pairs_per_gpu"] == n // 2 and two["strong"]["value"] > 0
     assert two["e2e"]["2bit_pinned"]["value"] > 0 and two["e2e"]["ascii_pinned"]["value"] > 0
     assert "cpu_baseline" not in two
+    # config 5's leg: QuickEd + CIGAR, --cfg5-pairs IN TOTAL split over the ranks; the two shards add up to the whole
+    c5 = two["workloads"]["cfg5"]
+    assert c5["total_pairs"] == 5000 and c5["pairs_per_gpu"] == 2500 and c5["value"] > 0 and "5000 pairs" in c5["data"]
+    rq = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "quicked", "--pairs", "5000", "--no-e2e",
+                         "--no-strong", "--steps", "2", "--warmup", "1", "--length", "2000", "--no-cpu-baseline"],
+                        capture_output=True, text=True, timeout=900)
+    assert rq.returncode == 0, rq.stderr[-3000:]
+    assert c5["score_checksum"] == json.loads([l for l in rq.stdout.splitlines() if l.startswith("{")][-1])["score_checksum"]
+
+
+def test_bench_reduces_through_rccl_on_one_gpu():
+    """The RCCL path itself, executed: bench.py as ONE rank under torch.distributed.run with QE_FORCE_DIST=1 and the default
+    backend -- init_process_group("nccl", device_id=...), the all-reduces of shard.reduce_totals / count_ranks on DEVICE
+    tensors, barrier + synchronize around the timed loop, destroy_process_group -- exactly what every rank of the driver's
+    N > 1 runs does, on the one GPU this box has (a one-rank communicator).  The line must say so (collective.backend ==
+    "nccl", device tensors), ranks_seen == 1, and the figures must equal the plain run's; config 5's leg runs in both."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--pairs", "3000", "--length", "2000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e",
+              "--indel-pairs", "0", "--cfg4-pairs", "0", "--mixed-share", "0", "--cfg5-pairs", "8000"]
+    env = dict(os.environ, QE_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    env.pop("QE_BENCH_BACKEND", None)
+    env.pop("QE_BENCH_SHARE_GPU", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", os.path.join(root, "bench.py")] + common, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    forced = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    plain = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert forced["collective"] == {"backend": "nccl", "tensors": "device", "world_size": 1} and plain["collective"]["backend"] == "none"
+    assert forced["ranks_seen"] == 1 and forced["n_gpus"] == 1 and forced["value"] > 0
+    assert forced["score_checksum"] == plain["score_checksum"]
+    assert forced["workloads"]["quicked"]["score_checksum"] == plain["workloads"]["quicked"]["score_checksum"]
+    for line in (forced, plain):
+        c5 = line["workloads"]["cfg5_shard"]
+        assert c5["pairs_per_gpu"] == 1000 and c5["total_pairs"] == 1000 and c5["value"] > 0 and "configs[4]" in c5["data"]
+    assert forced["workloads"]["cfg5_shard"]["score_checksum"] == plain["workloads"]["cfg5_shard"]["score_checksum"]
 
 
 def test_bench_eight_ranks_dry_run_on_one_gpu():

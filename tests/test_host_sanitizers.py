@@ -35,9 +35,27 @@ def run(exe, env_extra, timeout=600):
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
 def test_host_layer_under_thread_sanitizer(tmp_path):
     exe = build(tmp_path, "tsan", ["-fsanitize=thread"])
-    r = run(exe, {"TSAN_OPTIONS": "halt_on_error=1 second_deadlock_stack=1", "QE_STUB_HBM_BYTES": str(8 << 30)})
+    env = {"TSAN_OPTIONS": "halt_on_error=1 second_deadlock_stack=1", "QE_STUB_HBM_BYTES": str(8 << 30)}
+    r = run(exe, env)
     assert r.returncode == 0 and "host_scenarios ok" in r.stdout, (r.stdout + r.stderr)[-6000:]
     assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    # A race shows up under load, not alone: round 5's lease race (qe::ctx() reset a context's fields before it held the
+    # context's `busy` mutex while a reclaiming thread could still be writing them) was silent in 15 of 15 lone runs and
+    # reported in 7 of 30 when six copies of the binary shared the machine.  So: rounds of six copies side by side, >= 50
+    # runs in all, none of which may report anything (QE_TSAN_ROUNDS: more rounds for a soak, 0 to skip).
+    rounds = int(os.environ.get("QE_TSAN_ROUNDS", "9"))
+    full = dict(os.environ, QE_FINISHERS="3", **env)
+    for rnd in range(rounds):
+        procs = [subprocess.Popen([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=full) for _ in range(6)]
+        for k, p in enumerate(procs):
+            try:
+                out, err = p.communicate(timeout=600)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise AssertionError(f"round {rnd}, copy {k}: the host scenarios did not finish (a deadlock?)")
+            assert p.returncode == 0 and "host_scenarios ok" in out, (rnd, k, (out + err)[-6000:])
+            assert "WARNING: ThreadSanitizer" not in err, (rnd, k, err[-6000:])
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")

@@ -18,7 +18,9 @@
 //           next jobs, aligning and writing the finished ones (in input order: the output file is byte-identical to
 //           -t 1's) overlap.  --devices D limits the devices in use (default: all the node has, at most N).
 //           The totals the tool prints (reads, score sum, correct alignments) are reduced over the devices with
-//           ncclAllReduce (RCCL over xGMI; librccl is loaded when more than one device is in use, never for one).
+//           ncclAllReduce (RCCL over xGMI; librccl is loaded when more than one device is in use; with one device only
+//           when --force-rccl / QE_FORCE_RCCL=1 asks for it: ncclCommInitAll over that one device, the same grouped
+//           all-reduce, checked against the host-summed totals -- how the path is exercised on a one-GPU box).
 // Instead of the reference's loop over quicked_align calls every job goes through one quicked_align_batch call.
 //
 //   g++ -O2 -std=c++17 -pthread tools/align_benchmark.cpp -Iinclude -Lquicked_amd -lquicked_hip -ldl -Wl,-rpath,$PWD/quicked_amd
@@ -47,8 +49,9 @@ static void usage() {
             "  --input|i PATH   --output|o PATH   --output-full PATH\n"
             "  --bandwidth INT  --window-size INT  --overlap-size INT  --hew-threshold INT  --hew-percentage INT\n"
             "  --force-scalar   --only-score\n"
-            "  --check|c score|alignment|correct   --batch-size INT   --progress|P INT   --verbose|v   --help|h\n"
-            "  --num-threads|t INT (worker threads, one aligner each)   --device INT (first device)   --devices INT (devices in use)\n");
+            "  --check|c score|alignment|correct   --batch-size INT   --progress|P INT   --verbose INT | -v   --quiet|q   --help|h\n"
+            "  --num-threads|t INT (worker threads, one aligner each)   --device INT (first device)   --devices INT (devices in use)\n"
+            "  --force-rccl (reduce the totals through ncclAllReduce with ONE device in use too)\n");
 }
 
 static int encode(char c) {
@@ -165,7 +168,8 @@ int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "20", 0);
     std::string algo_name, input, output, output_full, check;
     quicked_params_t params = quicked_default_params();
-    bool bandwidth_set = false, verbose = false;
+    bool bandwidth_set = false, force_rccl = getenv("QE_FORCE_RCCL") != nullptr && atoi(getenv("QE_FORCE_RCCL")) != 0;
+    int verbose = 0;                              // align_benchmark_params.c:60, 241-252: -v is level 1, --verbose takes the level
     long batch_size = 65536, progress = 100000;
     int device = 0, num_threads = 1, devices_wanted = 0;
     static struct option opts[] = {
@@ -176,7 +180,8 @@ int main(int argc, char** argv) {
         {"force-scalar", no_argument, 0, 2005}, {"only-score", no_argument, 0, 2006}, {"check", required_argument, 0, 'c'},
         {"num-threads", required_argument, 0, 't'}, {"batch-size", required_argument, 0, 4000}, {"device", required_argument, 0, 4002},
         {"devices", required_argument, 0, 4003},
-        {"progress", required_argument, 0, 'P'}, {"verbose", no_argument, 0, 'v'}, {"quiet", no_argument, 0, 'q'},
+        {"progress", required_argument, 0, 'P'}, {"verbose", required_argument, 0, 4001}, {"verbose1", no_argument, 0, 'v'},
+        {"quiet", no_argument, 0, 'q'}, {"force-rccl", no_argument, 0, 4004},
         {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
     if (argc <= 1) { usage(); return 0; }
     int c, idx;
@@ -199,8 +204,13 @@ int main(int argc, char** argv) {
             case 4002: device = atoi(optarg); break;
             case 4003: devices_wanted = atoi(optarg); break;
             case 'P': progress = atol(optarg); break;
-            case 'v': verbose = true; break;
-            case 'q': progress = 0; break;
+            case 'v': verbose = 1; break;
+            case 4001:                                                  // align_benchmark_params.c:244-250
+                verbose = atoi(optarg);
+                if (verbose < 0 || verbose > 4) { fprintf(stderr, "Option '--verbose' must be in {0,1,2,3,4}\n"); return 1; }
+                break;
+            case 4004: force_rccl = true; break;
+            case 'q': progress = 0; verbose = -1; break;                // align_benchmark_params.c:251-253
             case 'h': usage(); return 0;
             default: fprintf(stderr, "Option not recognized\n"); return 1;
         }
@@ -390,9 +400,13 @@ int main(int argc, char** argv) {
     // ---- totals: over the devices in use through RCCL, over one device on the host
     DeviceTotals tot{{0, 0, 0, 0, 0}};
     const char* how = "host";
-    if (ndev > 1) {
+    if (ndev > 1 || force_rccl) {
         if (!reduce_over_devices(per_dev, devs, &tot)) { fprintf(stderr, "the RCCL reduction over %d devices failed\n", ndev); return 1; }
         how = "ncclAllReduce";
+        // the host's own sum of the same figures: what the collective must return
+        DeviceTotals host{{0, 0, 0, 0, 0}};
+        for (const DeviceTotals& d : per_dev) for (int k = 0; k < 5; ++k) host.v[k] += d.v[k];
+        if (memcmp(&host, &tot, sizeof(tot)) != 0) { fprintf(stderr, "the RCCL reduction disagrees with the host-summed totals\n"); return 1; }
     } else tot = per_dev[0];
     const long total = (long)tot.v[0], ok_cigar = (long)tot.v[2], ok_score = (long)tot.v[3];
     const long checked = (long)tot.v[4];
@@ -401,7 +415,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "[Benchmark]\n=> Total.reads              %ld\n=> Time.Benchmark           %.3f s\n  => Time.Alignment         %.3f s (%.1f seq/s)\n",
             total, wall, busiest, busiest > 0 ? total / busiest : 0.0);
     fprintf(stderr, "=> Threads %d  Devices %d  Totals.by %s  Score.sum %lld\n", W, ndev, how, tot.v[1]);
-    if (params.algo == QUICKED && verbose) {
+    if (params.algo == QUICKED && verbose > 0) {
         // the stage timers of the aligners, as align_benchmark.c:116-128 prints them with --verbose (a job is one lap of
         // each stage timer: calls = jobs that went through the stage), summed over the workers
         auto line = [&](const char* name, int which) {
