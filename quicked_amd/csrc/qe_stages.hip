@@ -257,7 +257,8 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     a.lane_rel = env_int("QE_LANE_REL", 1);
     auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;       // timed = kind + 1 (Context::kernel_events)
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
-    launch_groups(C, k_banded<false>, a, L.ngroups(), 8, 0);
+    // QE_SCORE_WAVES = 3: a 52 KB pin, three workgroups per CU = three waves per SIMD (the kernel's 158 VGPRs allow it)
+    launch_groups(C, k_banded<false>, a, L.ngroups(), 8, 0, false, env_int("QE_SCORE_WAVES", 2) == 3 ? (size_t)52 * 1024 : 0);
     if (ke) HIP_CHECK(hipEventRecord(ke->second, C.stream));
     return S;
 }
