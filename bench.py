@@ -62,6 +62,7 @@ SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9
 INSTR_PER_BLOCK_COLUMN = 26.1
 INSTR_PER_BLOCK_COLUMN_COOP = 33.4       # k_banded_coop_lds<false>, per LIVE block-column (profiles/r03_g_cfg4_sq_counters.txt)
 ISSUE_CYCLES_PER_BLOCK_COLUMN = 61.0     # (2 766 x 2 + 570 x 4) / 128 block-columns of the unrolled 4-slot loop
+MEASURED_LOOP_BLOCK_COLUMNS_PER_S = 1.70e12  # run64_skew<4> on registers at two waves per SIMD: 91 cycles per block-column (profiles/r06_b_skew_asm_bench.txt)
 # reference anchors of BASELINE.md section 2 (one core of the survey container's 2.1 GHz Xeon, AVX2 build)
 CPU_ANCHOR_PER_CORE = {"banded_score": 2463.0, "quicked": 1680.0}
 FILL_BYTES_PER_BLOCK_COLUMN = 1.25       # 16 B of {Pv, Mv} per 16 columns + 16 B of carry words per 64 (qe_types.h: QE_CP_COLS)
@@ -684,6 +685,11 @@ class Bench:
                 "issue_cycles_per_block_column": ISSUE_CYCLES_PER_BLOCK_COLUMN,
                 "instruction_mix_bound_block_columns_per_s": SIMDS * PEAK_CLOCK_HZ * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN,
                 "aggregate_block_columns_per_s": work_blocks / step_s,
+                # what the pass's own instruction stream does on registers, no memory, two waves per SIMD (the occupancy the
+                # kernel runs at): profiles/r06_b_skew_asm_bench.txt / r06_b_issue_classes.md -- a quarter-rate instruction costs
+                # ~6.8 cycles in a mixed stream, not the nominal 4, so this, not instruction_mix_bound, is the loop's real bound
+                "measured_loop_block_columns_per_s": MEASURED_LOOP_BLOCK_COLUMNS_PER_S,
+                "aggregate_frac_of_measured_loop": work_blocks / step_s / MEASURED_LOOP_BLOCK_COLUMNS_PER_S,
                 "note": "aggregate = per-step work / step time; peak assumes the 2.4 GHz peak clock (the chip holds less under this "
                         "load: DESIGN.md 4.1)"}
         return roof, valu, work_blocks
