@@ -563,8 +563,8 @@ static void stash_results(quicked_batch& B, Context& C, PendingFetch& F) {
 
 // sets of {streams, pools, planes} that rotate for a batch of n pairs: enough runs in flight for ~2048 waves (two per SIMD)
 static int rotation_depth(int64_t n, int floor_sets = 5) {
-    const int64_t groups = std::max<int64_t>(1, (n + 63) / 64);
-    return (int)std::max<int64_t>(floor_sets, std::min<int64_t>(Context::NA, (2048 + groups - 1) / groups));
+    const int64_t groups = std::max<int64_t>(1, (n + 63) / 64), slots = (int64_t)chip(tl_device).slots2();
+    return (int)std::max<int64_t>(floor_sets, std::min<int64_t>(Context::NA, (slots + groups - 1) / groups));
 }
 
 static void finisher_submit(quicked_batch& B, const std::shared_ptr<void>& pf);

@@ -56,6 +56,30 @@ struct HipError { hipError_t e; const char* what; int line; };
     } while (0)
 
 // ---------------------------------------------------------------------------
+// The chip, as the launch-shape rules see it: compute units and SIMDs of a device, read from the runtime once per device.
+// Every "how many waves fill the chip" threshold of qe_stages.hip / qe_driver.hip is a multiple of these -- a launch is "one
+// round of waves" while it has at most two waves per SIMD (the occupancy of the 158-246-VGPR alignment kernels) -- instead of
+// a wave count that happens to fit the 256 CUs of one MI355X in SPX mode (a CPX partition has 32, other parts other counts).
+// ---------------------------------------------------------------------------
+struct Chip {
+    int cus = 256, simds = 1024;
+    size_t slots2() const { return (size_t)simds * 2; }       // wave slots at two waves per SIMD
+    size_t frac2(double f) const { return (size_t)((double)simds * 2.0 * f); }
+};
+inline const Chip& chip(int device) {
+    static Chip table[16];
+    static std::atomic<int> known[16];
+    const int d = (device >= 0 && device < 16) ? device : 0;
+    if (!known[d].load(std::memory_order_acquire)) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && cus > 0) { table[d].cus = cus; table[d].simds = cus * 4; }
+        else (void)hipGetLastError();
+        known[d].store(1, std::memory_order_release);
+    }
+    return table[d];
+}
+
+// ---------------------------------------------------------------------------
 // The library's switches.  Every QE_* environment variable it knows is read ONCE, the first time any of them is asked
 // for, into one immutable table; the launch path only ever looks names up in that table (no getenv per stage call,
 // nothing that races an embedding application's setenv).  Production needs none of them: they force kernel forms for the

@@ -31,11 +31,12 @@ static void launch_groups(Context& C, Kernel kernel, const Args& args, size_t ng
     // 54 KB: 3 x 54 KB > 160 KB >= 2 x 54 KB, two workgroups per CU.  When the launches in flight have fewer workgroups than
     // the chip has CUs, 84 KB (one per CU): the dispatcher packs the workgroups of CONCURRENT small kernels two to a CU
     // while other CUs idle (three 49-workgroup launches in flight: 16.5 ms each at 54 KB, 11.7 ms at 84 KB, 11.4 ms alone)
-    size_t pin = ((size_t)blocks * (size_t)std::max(1, C.in_flight) > 256) ? (size_t)54 * 1024 : (size_t)84 * 1024;
+    const Chip& chp = chip(C.device);
+    size_t pin = ((size_t)blocks * (size_t)std::max(1, C.in_flight) > (size_t)chp.cus) ? (size_t)54 * 1024 : (size_t)84 * 1024;
     // chain: a launch of few waves whose duration is one wave's serial chain (WindowEd on a few thousand long reads: 157
     // waves of 1563 windows each).  108 KB: no 54 KB workgroup fits beside it, so its waves have their SIMDs to themselves
     // instead of sharing them with the fill of the run before (config 4: the stage took 59 ms beside that fill, 36 alone)
-    if (chain && (size_t)blocks * (size_t)std::max(1, C.in_flight) <= 128) pin = (size_t)108 * 1024;
+    if (chain && (size_t)blocks * (size_t)std::max(1, C.in_flight) <= (size_t)chp.cus / 2) pin = (size_t)108 * 1024;
     if (pin_override) pin = pin_override;
     const size_t lds = std::max(pin, lds_per_wave * (size_t)wpb);
     static thread_local std::vector<std::pair<const void*, int>> configured;      // per host thread and device
@@ -282,7 +283,8 @@ static int coop_lanes(const TaskList& L, int in_flight = 1, bool fill = false) {
     // Waves to aim for: ~700 for 10 kb reads (measured with the multi-slot one-lane kernel and overlapped runs:
     // 8 k / 16 k pairs are best at G = 4, 32 k at G = 2, 50 k and up at G = 1), more for longer reads, whose one-lane
     // latency grows with their length (100 kb half passes: 526 -> 430 ms from G = 8 to 32)
-    const size_t target = std::min<size_t>(4096, (size_t)700 * (size_t)std::max(1, n_max / 10000));
+    const Chip& chp = chip(tl_device);
+    const size_t target = std::min<size_t>(2 * chp.slots2(), chp.frac2(0.34) * (size_t)std::max(1, n_max / 10000));      // ~700 waves of 2 048 slots per 10 kb of read
     if (e) G = env_int(e_name, 1);
     else
         while (G < 64 && ((live * G) / 64) * (size_t)std::max(1, in_flight) < target) G *= 2;      // runs in flight fill the chip together
@@ -292,7 +294,7 @@ static int coop_lanes(const TaskList& L, int in_flight = 1, bool fill = false) {
     // kernel -- rare, and worth it where the launch is short of waves anyway (4 000 pairs of 10 kb: 4.2 -> 2.8 ms with G = 8)
     while (G > 1 && min_nsl < 3 * G + 4) G /= 2;
     if (!e)
-        while (G < 64 && min_nsl >= 2 * (2 * G) + 4 && ((live * G) / 64) * (size_t)std::max(1, in_flight) < 512) G *= 2;
+        while (G < 64 && min_nsl >= 2 * (2 * G) + 4 && ((live * G) / 64) * (size_t)std::max(1, in_flight) < chp.slots2() / 4) G *= 2;
     return G < 2 ? 1 : G;
 }
 
@@ -432,7 +434,7 @@ static bool wave_form_wanted(const TaskList& L) {
         n_max = std::max(n_max, L.n[t]);
         if (L.tfin[t] != L.n[t] || host_geometry(L.m[t], L.n[t], L.cutoff[t]).ebb_local > 62) return false;
     }
-    return live > 0 && (force == 1 || (live <= 1024 && n_max >= 4096));
+    return live > 0 && (force == 1 || (live <= (size_t)chip(tl_device).simds && n_max >= 4096));      // at most a wave per SIMD
 }
 
 static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int timed) {
@@ -496,8 +498,9 @@ static int sys_score_lanes(const TaskList& L, int in_flight) {
     }
     if (live == 0 || max_nsl > 127) return 0;
     const size_t nt = L.pair.size(), fl = (size_t)std::max(1, in_flight);
-    if (max_nsl <= 15) return (env == 1 || nt / 4 * fl <= 2048) ? 4 : 0;
-    return (env == 1 || nt * fl <= 1100) ? 6 : 0;
+    const Chip& chp = chip(tl_device);
+    if (max_nsl <= 15) return (env == 1 || nt / 4 * fl <= chp.slots2()) ? 4 : 0;      // one round of waves
+    return (env == 1 || nt * fl <= chp.frac2(0.54)) ? 6 : 0;                            // a wave per task: about a wave per SIMD
 }
 
 // QuickEd's stage 3 (quicked.c:248-278) in ONE launch: k_banded_sys<.., false> with the band doubling on the device.  Every
@@ -510,7 +513,7 @@ static bool stage3_on_device(quicked_batch& B, Context& C, const TaskList& L, st
     if (env == 0) return false;
     size_t live = 0;
     for (int32_t pr : L.pair) live += pr >= 0;
-    if (live == 0 || (env != 1 && L.pair.size() > 1100)) return false;
+    if (live == 0 || (env != 1 && L.pair.size() > chip(C.device).frac2(0.54))) return false;
     const size_t nt = L.pair.size();
     const DevTasks T = upload_tasks(L, C);
     const TaskOut O = take_out(C, nt);
@@ -711,7 +714,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
         // left.  Worth it while the launches in flight leave SIMDs idle; QE_WINDOWED_QUAD = 0 / 1: never / always (tests)
         const int quad = env_int("QE_WINDOWED_QUAD", -1);
         const size_t waves = (size_t)ng * 4 * (size_t)std::max(1, fetch ? 1 : C.in_flight);
-        if (score_only && (quad == 1 || (quad != 0 && waves <= 2048))) {
+        if (score_only && (quad == 1 || (quad != 0 && waves <= chip(C.device).slots2()))) {
             a.state = C.scratch_p->take<int32_t>(5 * nt);
             launch_groups(C, k_windowed_quad, with_prio(a), nt / 16, 4, (size_t)QE_WQ_LDS_PER_WAVE, /* chain */ true);
         }
@@ -725,7 +728,7 @@ static void run_windowed(quicked_batch& B, Context& C, const TaskList& L, bool r
         // not for W == 2 with the x86 SSE semantics (bpm_windowed.c:577: the SSE window kernel runs whenever window_size == 2
         // and force_scalar is off, whatever the overlap): k_windowed_sys computes the scalar kernel's windows, the one-lane
         // kernel's history path has the SSE boundary pattern
-        if (score_only && W <= 15 && !(sse && W == 2) && a.cp_path != 0 && (wsys == 1 || (wsys != 0 && waves <= 4096))) {
+        if (score_only && W <= 15 && !(sse && W == 2) && a.cp_path != 0 && (wsys == 1 || (wsys != 0 && waves <= 2 * chip(C.device).slots2()))) {
             a.o_abort = C.scratch_p->take<int32_t>(nt);
             launch_groups(C, k_windowed_sys, with_prio(a), nt / 4, 4, 0, /* chain */ false, (size_t)40 * 1024);
             a.only_if = a.o_abort;
@@ -990,7 +993,8 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
     // QE_FILL_SYS = 0 / 1: never / wherever the bound is tight (tests)
     const int sys_env = env_int("QE_FILL_SYS", -1);
     const size_t in_fl = (size_t)std::max(1, fetch ? 1 : C.in_flight);
-    const bool sys_fill = Gfill < 2 && tight_runs && (sys_env == 1 || (sys_env != 0 && (size_t)ng * 16 * in_fl <= 4096));
+    const Chip& chp = chip(C.device);
+    const bool sys_fill = Gfill < 2 && tight_runs && (sys_env == 1 || (sys_env != 0 && (size_t)ng * 16 * in_fl <= 2 * chp.slots2()));
     std::vector<int32_t> hew_init;
     if (!sys_fill && Gfill < 2 && tight_runs && !fill_forced && !d_cut && env_int("QE_COOP_LDS", 1) != 0 && env_int("QE_COOP_TALL_FILL", 1) != 0 &&
         (size_t)ng * (size_t)std::max(1, fetch ? 1 : C.in_flight) <= 64) {
@@ -1069,7 +1073,7 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
             launch_groups(C, k_banded_sys<4, true>, with_prio(a), (size_t)(g1 - g0) * 16, 4, 0, false, sys_pin);
             a.only_if = O.hew + o;
             // what it flagged for its height: one wave per leaf while the sub-batch is small enough for that
-            if (maxns > 15 && (sys_env == 1 || (size_t)(g1 - g0) * 64 * in_fl <= 4096)) {
+            if (maxns > 15 && (sys_env == 1 || (size_t)(g1 - g0) * 64 * in_fl <= 2 * chp.slots2())) {
                 launch_groups(C, k_banded_sys<6, true>, with_prio(a), (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
                 // ... and what THAT flagged for its height (64 .. 127 slots): two rows per lane, two sweeps per chunk
                 if (maxns > 63) launch_groups(C, k_banded_sys2<true>, with_prio(a), (size_t)(g1 - g0) * 64, 4, 0, false, sys_pin);
@@ -1096,7 +1100,8 @@ static void run_align(quicked_batch& B, Context& C, const TaskList& roots, bool 
         const size_t gw = (size_t)(g1 - g0) * (size_t)std::max(1, fetch ? 1 : C.in_flight);      // one-lane waves in flight
         int tlg = 0;
         if (tsys > 1) tlg = tsys == 4 ? 2 : (tsys == 8 ? 3 : 4);
-        else if (tsys != 0) tlg = (gw * 16 <= 2100 || tsys == 1) ? 4 : (gw * 8 <= 3300 ? 3 : (gw * 4 <= 1700 ? 2 : 0));
+        // (2 100 / 3 300 / 1 700 waves on the 1 024 SIMDs of an MI355X: one round at two waves per SIMD, 1.6 rounds, 0.8)
+        else if (tsys != 0) tlg = (gw * 16 <= chp.frac2(1.03) || tsys == 1) ? 4 : (gw * 8 <= chp.frac2(1.61) ? 3 : (gw * 4 <= chp.frac2(0.83) ? 2 : 0));
         if (tlg) {
             tr.o_abort = C.scratch_p->take<int32_t>((size_t)(g1 - g0) * 64);
             const size_t nwv = (size_t)(g1 - g0) << tlg;

@@ -62,6 +62,8 @@ static inline const char* hipGetErrorString(hipError_t e) {
 }
 static inline hipError_t hipGetLastError() { const hipError_t e = hipstub::tl_last; hipstub::tl_last = hipSuccess; return e; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { if (d != 0) return hipstub::fail(hipErrorInvalidDevice); hipstub::tl_dev = d; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 
