@@ -4299,20 +4299,21 @@ template __global__ void k_format_segs<false>(SegFormatArgs);
 template __global__ void k_format_segs<true>(SegFormatArgs);
 
 // ---------------------------------------------------------------------------
-// The same formatter with one WAVE per alignment (few, long alignments: a 100 kb pair has ~30 k runs, and one lane
-// walking them twice is a 15 ms launch).  The alignment's runs in string order are one sequence (segment after segment,
-// a leaf's runs back to front); lane l takes an equal slice of it.  Inside a leaf neighbouring runs differ, so runs only
-// merge across segment borders: a slice's leading runs that continue the previous slice's last run belong to that
-// slice's owner, who reads on past its end.  Styles 0 and 1 only (style 2 folds X into M, which merges inside leaves).
+// The same formatter with one WAVE per alignment (strings of more than a few runs: a 100 kb pair has ~30 k runs, and one
+// lane walking them twice is a 15 ms launch).  The alignment's runs in string order are one sequence (segment after
+// segment, a leaf's runs back to front); the wave takes it 64 consecutive runs at a time -- lane l run 64 j + l: with the
+// traceback's by-task layout one 256-byte row per step, every line of the run buffer read once (round 5's form gave every
+// lane a slice of its own to walk: 64 streams per wave, 20-27 x the run bytes fetched from HBM once the waves of a chip
+// together outgrew its L2) -- and merges equal neighbours with a segmented scan: inside a leaf neighbouring runs differ, so
+// groups of more than one run only form across segment borders, but any grouping is handled.  A group's text is written
+// by the lane that holds its last run; a group that is still open at the end of a step is carried into the next.
+// Styles 0 and 1 only (style 2 folds X into M, which regroups inside leaves).
 // ---------------------------------------------------------------------------
 struct SegCursor {
-    const SegFormatArgs* A; int64_t s0, s1;      // segments of this alignment
-    int64_t seg; int k;                          // current segment; index of the current run in it (string order)
-    // what the current segment is, loaded once on entering it (a walk used to re-read the segment arrays, the leaf's run
-    // count and its group's layout for every run: nine dependent loads per element, and those were the kernel's time)
+    const SegFormatArgs* A; int64_t s1;          // end of this alignment's segments
+    int64_t seg, first;                          // current segment; sequence index of its first run
     int n = 0, kind = 0, la = 0, lb = 0, nr = 0;
     RunView rv;
-    __device__ __forceinline__ int seg_runs(int64_t sg) const { return A->seg_kind[sg] == 1 ? (A->seg_b[sg] > 0 ? 1 : 0) : max(A->nruns[A->seg_a[sg]], 0); }
     __device__ __forceinline__ void load() {
         n = 0;
         if (seg >= s1) return;
@@ -4320,20 +4321,14 @@ struct SegCursor {
         if (kind == 1) { lb = A->seg_b[seg]; n = lb > 0 ? 1 : 0; }
         else { nr = max(A->nruns[la], 0); n = nr; rv = run_view(*A, la); }
     }
-    __device__ __forceinline__ void seek(int64_t idx) {      // position on run `idx` of the sequence (or past the end)
-        seg = s0; load();
-        while (seg < s1 && idx >= n) { idx -= n; ++seg; load(); }
-        k = (int)idx;
-    }
-    __device__ __forceinline__ bool valid() const { return seg < s1; }
-    __device__ __forceinline__ void get(int& op, int& len) const {
-        if (kind == 1) { op = la; len = lb; return; }
-        const u32 r = rv.at(nr - 1 - k);
+    // run `idx` of the sequence (idx only ever grows from call to call); false past the end
+    __device__ __forceinline__ bool get(int64_t idx, int& op, int& len) {
+        while (seg < s1 && idx >= first + n) { first += n; ++seg; load(); }
+        if (seg >= s1) return false;
+        if (kind == 1) { op = la; len = lb; return true; }
+        const u32 r = rv.at(nr - 1 - (idx - first));
         op = (int)(r & 3); len = (int)(r >> 2);
-    }
-    __device__ __forceinline__ void next() {
-        ++k;
-        while (seg < s1 && k >= n) { ++seg; k = 0; load(); }
+        return true;
     }
 };
 
@@ -4341,11 +4336,11 @@ template <bool WRITE>
 __global__ __launch_bounds__(64) void k_format_segs_wave(SegFormatArgs A) {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= A.npairs) return;
-    SegCursor C; C.A = &A; C.s0 = A.seg_off[i]; C.s1 = A.seg_off[i + 1];
+    const int64_t s0 = A.seg_off[i], s1 = A.seg_off[i + 1];
     int64_t total_runs = 0; bool bad = false;
-    for (int64_t sg = C.s0 + lane; sg < C.s1; sg += 64) {
-        if (A.seg_kind[sg] != 1 && A.nruns[A.seg_a[sg]] < 0) bad = true;
-        total_runs += C.seg_runs(sg);
+    for (int64_t sg = s0 + lane; sg < s1; sg += 64) {
+        if (A.seg_kind[sg] == 1) total_runs += A.seg_b[sg] > 0 ? 1 : 0;
+        else { const int nr = A.nruns[A.seg_a[sg]]; if (nr < 0) bad = true; total_runs += max(nr, 0); }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) total_runs += __shfl_xor(total_runs, o);
@@ -4353,50 +4348,61 @@ __global__ __launch_bounds__(64) void k_format_segs_wave(SegFormatArgs A) {
         if (lane == 0) { if (WRITE) A.pool[A.str_off[i]] = '\0'; else { A.o_len[i] = 0; A.o_edits[i] = -1; A.o_nops[i] = 0; } }
         return;
     }
-    const int64_t per = (total_runs + 63) / 64, lo = min((int64_t)lane * per, total_runs), hi = min(lo + per, total_runs);
-    // my groups: start at the first run of my slice that does not continue the run before it; end past my slice while the
-    // following runs still continue my last group
-    RunMerger Mg; Mg.style = A.style;
-    auto walk = [&](auto&& sink) {
-        if (lo >= hi) return;
-        C.seek(lo);
-        int64_t idx = lo;
-        int prev_op = -1;
-        if (lo > 0) { SegCursor P = C; P.seek(lo - 1); int l; P.get(prev_op, l); }
-        bool started = false;
-        int cur_op = -1;
-        while (C.valid()) {
-            int op, len; C.get(op, len);
-            if (!started) {
-                if (idx >= hi) break;
-                if (op == prev_op) { ++idx; C.next(); continue; }                     // belongs to the previous slice's last group
-                started = true;
-            } else if (idx >= hi && op != cur_op) break;                              // past my slice and no longer my group
-            sink(op, len);
-            cur_op = op;
-            ++idx; C.next();
-        }
-    };
-    // pass A: my string length
-    walk([&](int op, int len) { Mg.template push<false>(op, len); });
-    Mg.template emit<false>();
-    int mine = Mg.total, edits = Mg.edits, nops = Mg.nops;
-    int off = mine;                                                   // inclusive scan -> exclusive offset
+    SegCursor C; C.A = &A; C.s1 = s1; C.seg = s0; C.first = 0; C.load();
+    const u32 letters = (A.style == 1) ? 0x4449583Du : 0x4449584Du;      // "=XID" : "MXID"
+    char* const out = WRITE ? A.pool + A.str_off[i] : nullptr;
+    int64_t written = 0;                 // characters of the groups closed so far (the same in every lane)
+    int edits = 0, nops = 0;             // per lane; summed at the end
+    int carry_op = -1, carry_len = 0;    // the group that was still open at the end of the previous step (the same in every lane)
+    int nop = -1, nlen = 0;              // my run of the NEXT step (one step of look-ahead: lane 63 needs its right neighbour's op)
+    bool nvalid = C.get(lane, nop, nlen);
+    for (int64_t base = 0; base < total_runs; base += 64) {
+        const bool valid = nvalid;
+        const int op = valid ? nop : -1;
+        int x = valid ? nlen : 0;
+        nop = -1; nlen = 0;
+        nvalid = (base + 64 + lane < total_runs) && C.get(base + 64 + lane, nop, nlen);
+        const int right = __shfl_down(op, 1), first_next = __shfl(nvalid ? nop : -1, 0);
+        const int op_next = (lane == 63) ? first_next : right;
+        const int left = __shfl_up(op, 1);
+        const int op_prev = (lane == 0) ? carry_op : left;
+        bool flag = valid && op != op_prev;                              // my run opens a group
+        const bool tail = valid && op != op_next;                        // ... closes one
+        // segmented inclusive scan of the run lengths: x = length of my group up to and including my run
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(off, d); if (lane >= d) off += y; }
-    const int total = __shfl(off, 63);
-    off -= mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            const int f = __shfl_up((int)flag, d);
+            if (lane >= d && !flag) { x += y; flag = f != 0; }
+        }
+        if (valid && !flag) x += carry_len;                              // my group was opened in an earlier step
+        // what the step leaves open
+        const int last = (int)min((int64_t)63, total_runs - 1 - base);
+        const int l_tail = __shfl((int)tail, last), l_x = __shfl(x, last), l_op = __shfl(op, last);
+        carry_op = l_op; carry_len = l_tail ? 0 : l_x;
+        // the groups that close here: "<length><letter>"
+        const int digits = tail ? dec_digits((u32)x) : 0;
+        const int chars = tail ? digits + 1 : 0;
+        if (tail) { nops += x; if (op != (int)OP_M) edits += x; }
+        int off = chars;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(off, d); if (lane >= d) off += y; }
+        const int step_chars = __shfl(off, 63);
+        if (WRITE && tail) {
+            char* q = out + written + (off - chars);
+            u32 v = (u32)x;
+            for (int k = digits - 1; k >= 0; --k) { q[k] = (char)('0' + v % 10); v /= 10; }
+            q[digits] = (char)((letters >> (8 * (op & 3))) & 0xFFu);
+        }
+        written += step_chars;
+    }
     if (!WRITE) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { edits += __shfl_xor(edits, o); nops += __shfl_xor(nops, o); }
-        if (lane == 0) { A.o_len[i] = total; A.o_edits[i] = edits; A.o_nops[i] = nops; }
+        if (lane == 0) { A.o_len[i] = (int)written; A.o_edits[i] = edits; A.o_nops[i] = nops; }
         return;
     }
-    RunMerger Wr; Wr.style = A.style; Wr.out = A.pool + A.str_off[i] + off;
-    walk([&](int op, int len) { Wr.template push<true>(op, len); });
-    Wr.template emit<true>();
-    for (int k = 0; k < Wr.nb; ++k) Wr.out[k] = (char)(Wr.buf >> (8 * k));       // the waiting characters, no terminator
-    if (lane == 0) A.pool[A.str_off[i] + total] = '\0';
+    if (lane == 0) out[written] = '\0';
 }
 template __global__ void k_format_segs_wave<false>(SegFormatArgs);
 template __global__ void k_format_segs_wave<true>(SegFormatArgs);
