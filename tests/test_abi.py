@@ -182,8 +182,10 @@ def _newest_bench_line():
     import glob
     import json
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*_bench_line.json")),
-                   key=lambda f: re.match(r"(r\d+_[a-z]+)_bench_line", os.path.basename(f)).group(1))
+    def tag(f):      # (round, milestone): r05_z < r06_a < r06_b2 < r10_a; a name that does not parse sorts first instead of failing
+        m = re.match(r"r(\d+)_([A-Za-z]*)(\d*)_bench_line", os.path.basename(f))
+        return (int(m.group(1)), m.group(2).lower(), int(m.group(3) or 0)) if m else (-1, "", 0)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*_bench_line.json")), key=tag)
     assert files, "no committed bench line"
     f = files[-1]
     return f, json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])

@@ -4,7 +4,9 @@
 # kernel-trace/stats and every PMC counter set in separate passes, as MI355X_MICROARCH.md prescribes.
 tag=${1:-r03_x}; shift
 wls=${@:-banded_score quicked cfg4 share indels}
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}      # the repository's root on the GPU box (or wherever the script lies)
+cd /tmp && export TMPDIR=/tmp; cd "$R"
 out=gpurun_out/$tag; mkdir -p $out
 one="--no-workloads --no-strong --indel-pairs 0 --no-cpu-baseline --no-e2e"
 for wl in $wls; do
