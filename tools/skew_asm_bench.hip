@@ -100,6 +100,78 @@ __device__ __forceinline__ void skew4_asm(u64 (&P)[4], u64 (&M)[4], const u64 (&
     houtM = qe::mk64(o[2], o[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The block step on 32-ROW blocks, full-rate instructions only (profiles/r06_b_issue_classes.md: a quarter-rate instruction
+// costs ~6.8 cycles in a mixed stream at two waves per SIMD, a full-rate one 2.1-2.6).  The Myers step is exact for any
+// partition of a column into blocks (k_windowed_quad relies on it): a 64-row slot is two 32-row steps, the carry between
+// them the step's own PHout / MHout.  sum = v_add_u32, x << 1 = x + x (an asm v_add_u32: hipcc would select the quarter-rate
+// v_lshlrev_b32), the carry-in ORed into the consumers' truth tables.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 dbl(u32 x) { u32 r; asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ void step32(u32 e, u32& P, u32& M, u32 cP, u32 cM, u32& oP, u32& oM) {
+    const u32 xv = e | M;
+    const u32 ecl = e | cM;
+    const u32 t = ecl & P, q = ecl | P;
+    const u32 s = t + P;
+    const u32 ph = qe::bitop3<0xF1>(M, s, q);                 // M | ~(s | q)
+    const u32 mh = qe::bitop3<0xB0>(P, s, ecl);               // P & ((s ^ P) | Eqc)
+    oP = ph >> 31; oM = mh >> 31;
+    const u32 ph2 = dbl(ph), mh2 = dbl(mh);
+    const u32 xvc = xv | cP;
+    const u32 w = qe::bitop3<0xF1>(cM, xvc, ph2);             // MHin | ~(Xv | Phs)
+    P = mh2 | w;
+    M = qe::bitop3<0xA8>(ph2, cP, xv);                        // (ph2 | PHin) & Xv
+}
+template <int K>
+__device__ __forceinline__ void run64_skew32(u64 (&P)[K], u64 (&M)[K], const u64 (&a)[K], const u64 (&b)[K],
+                                             u64 T0, u64 T1, u64 hinP, u64 hinM, u64& houtP, u64& houtM) {
+    using namespace qe;
+    u32 alo[K], ahi[K], blo[K], bhi[K], Plo[K], Phi[K], Mlo[K], Mhi[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        alo[k] = lo32(a[k]); ahi[k] = hi32(a[k]); blo[k] = lo32(b[k]); bhi[k] = hi32(b[k]);
+        Plo[k] = lo32(P[k]); Phi[k] = hi32(P[k]); Mlo[k] = lo32(M[k]); Mhi[k] = hi32(M[k]);
+    }
+    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        // running bit-reversed words: bit 31 is the current column's
+        u32 t0 = __builtin_bitreverse32(half ? hi32(T0) : lo32(T0)), t1 = __builtin_bitreverse32(half ? hi32(T1) : lo32(T1));
+        u32 hp = __builtin_bitreverse32(half ? hi32(hinP) : lo32(hinP)), hm = __builtin_bitreverse32(half ? hi32(hinM) : lo32(hinM));
+        u32 gP = 0, gM = 0;
+        u32 m0[32], m1[32], cP[K], cM[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { cP[k] = 0; cM[k] = 0; }
+#pragma unroll
+        for (int s = 0; s < 32 + K - 1; ++s) {
+            if (s < 32) {
+                m0[s] = (u32)((int)t0 >> 31); m1[s] = (u32)((int)t1 >> 31);
+                t0 = dbl(t0); t1 = dbl(t1);
+            }
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                const int c = s - k;
+                if (c < 0 || c >= 32) continue;
+                u32 inP, inM;
+                if (k == 0) { inP = hp >> 31; inM = hm >> 31; hp = dbl(hp); hm = dbl(hm); }
+                else { inP = cP[k]; inM = cM[k]; }
+                const u32 elo = bitop3<0x90>(~(alo[k] ^ m0[c]), blo[k], m1[c]), ehi = bitop3<0x90>(~(ahi[k] ^ m0[c]), bhi[k], m1[c]);
+                u32 midP, midM, outP, outM;
+                step32(elo, Plo[k], Mlo[k], inP, inM, midP, midM);
+                step32(ehi, Phi[k], Mhi[k], midP, midM, outP, outM);
+                if (k + 1 < K) { cP[k + 1] = outP; cM[k + 1] = outM; }
+                else { gP = dbl(gP) | outP; gM = dbl(gM) | outM; }
+            }
+        }
+        const u32 rP = __builtin_bitreverse32(gP), rM = __builtin_bitreverse32(gM);
+        if (half) { o[1] = rP; o[3] = rM; } else { o[0] = rP; o[2] = rM; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { P[k] = mk64(Plo[k], Phi[k]); M[k] = mk64(Mlo[k], Mhi[k]); }
+    houtP = qe::mk64(o[0], o[1]);
+    houtM = qe::mk64(o[2], o[3]);
+}
+
 struct Stamp { uint64_t cyc, real; };
 
 // VAR 0: run64_skew<4> (hipcc's schedule), 1: asm scheduled dmin 8, 2: asm in program order, 3: asm scheduled dmin 32
@@ -118,6 +190,7 @@ __global__ __launch_bounds__(256) void k_step(u32* out, Stamp* stamps, int iters
     const uint64_t c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; ++i) {
         if (VAR == 0) run64_skew<4>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM);
+        else if (VAR == 10) run64_skew32<4>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM);
         else skew4_asm<VAR - 1>(P, M, a, b, T0, T1, hinP, hinM, houtP, houtM);
         T0 = T0 * 6364136223846793005ull + 1442695040888963407ull;
         T1 ^= T0 >> 7;
@@ -142,7 +215,8 @@ __global__ void k_verify(u32* bad) {
         const u64 T0 = rnd(), T1 = rnd(), h1 = rnd(), h2 = rnd(), hinP = h1 & ~h2, hinM = h2 & ~h1;
         u64 o1P, o1M, o2P, o2M;
         run64_multi<4>(P1, M1, a, b, T0, T1, hinP, hinM, o1P, o1M);
-        skew4_asm<V>(P2, M2, a, b, T0, T1, hinP, hinM, o2P, o2M);
+        if (V == 9) run64_skew32<4>(P2, M2, a, b, T0, T1, hinP, hinM, o2P, o2M);
+        else skew4_asm<(V == 9 ? 0 : V)>(P2, M2, a, b, T0, T1, hinP, hinM, o2P, o2M);
         bool ok = o1P == o2P && o1M == o2M;
         for (int k = 0; k < 4; ++k) ok = ok && P1[k] == P2[k] && M1[k] == M2[k];
         if (!ok) atomicAdd(bad, 1u);
@@ -197,8 +271,10 @@ int main() {
     hipLaunchKernelGGL((k_verify<6>), dim3(256), dim3(256), 0, 0, g_out + 6);
     hipLaunchKernelGGL((k_verify<7>), dim3(256), dim3(256), 0, 0, g_out + 7);
     hipLaunchKernelGGL((k_verify<8>), dim3(256), dim3(256), 0, 0, g_out + 8);
-    u32 bad[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
-    hipMemcpy(bad, g_out, 36, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL((k_verify<9>), dim3(256), dim3(256), 0, 0, g_out + 9);
+    u32 bad[10] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    hipMemcpy(bad, g_out, 40, hipMemcpyDeviceToHost);
+    printf("32-row blocks, full-rate instructions only (run64_skew32<4>, hipcc-scheduled) against run64_multi<4>: %u mismatches\n", bad[9]);
     printf("no-quarter-rate passes (scheduled / program order / all VOP3) against run64_multi<4>: %u / %u / %u mismatches\n", bad[6], bad[7], bad[8]);
     printf("asm passes (dmin 8 / program order / dmin 32 / all VOP3 / low registers / 8 columns rolled) against run64_multi<4> on %d random passes each: %u / %u / %u / %u / %u / %u mismatches\n",
            256 * 256 * 32, bad[0], bad[1], bad[2], bad[3], bad[4], bad[5]);
@@ -214,6 +290,7 @@ int main() {
         step_row<7>("asm2 no quarter-rate, dmin 4", w, it);
         step_row<8>("asm2 no quarter-rate, program order", w, it);
         step_row<9>("asm2 no quarter-rate, all VOP3", w, it);
+        step_row<10>("32-row blocks, full-rate only (C++)", w, it);
     }
     return 0;
 }
