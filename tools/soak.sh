@@ -14,4 +14,7 @@ QE_WINDOWED_QUAD=1 QE_WINDOWED_SYS=1 QE_FILL_SYS=1 QE_SCORE_SYS=1 QE_TRACE_SYS=1
 QE_WINDOWED_QUAD=1 QE_WINDOWED_SYS=1 QE_FILL_SYS=1 QE_SCORE_SYS=1 QE_TRACE_SYS=8 timeout 900 python tests/soak_long.py $(( $2 + 3000 )) $m > $out/soak_long_sys_forced.txt 2>&1
 QE_TRACE_SYS=4 QE_LANE_REL=2 timeout 900 python tests/soak_long.py $(( $2 + 4000 )) $m > $out/soak_long_trace4.txt 2>&1
 QE_WINDOWED_QUAD=0 QE_WINDOWED_SYS=0 QE_FILL_SYS=0 QE_SCORE_SYS=0 QE_TRACE_SYS=0 QE_STAGE3_DEVICE=0 QE_FORMAT_WAVE=0 QE_WAVE_PRIO=0 timeout 900 python tests/soak_fuzz.py $(( $2 + 5000 )) $n > $out/soak_fuzz_sys_off.txt 2>&1
+# round 6's wave formatter (64 consecutive runs per step, segmented scan) on every alignment, however few its runs
+QE_FORMAT_WAVE=1 timeout 900 python tests/soak_fuzz.py $(( $2 + 6000 )) $n > $out/soak_fuzz_format_wave.txt 2>&1
+QE_FORMAT_WAVE=1 timeout 900 python tests/soak_long.py $(( $2 + 6000 )) $m > $out/soak_long_format_wave.txt 2>&1
 grep -h "MISMATCH\|^soak" $out/soak_*.txt | tail -30
