@@ -68,14 +68,13 @@ struct Chip {
 };
 inline const Chip& chip(int device) {
     static Chip table[16];
-    static std::atomic<int> known[16];
+    static std::once_flag once[16];
     const int d = (device >= 0 && device < 16) ? device : 0;
-    if (!known[d].load(std::memory_order_acquire)) {
+    std::call_once(once[d], [d] {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && cus > 0) { table[d].cus = cus; table[d].simds = cus * 4; }
         else (void)hipGetLastError();
-        known[d].store(1, std::memory_order_release);
-    }
+    });
     return table[d];
 }
 

@@ -201,6 +201,12 @@ def test_newest_committed_bench_line_follows_the_contract():
               "value_definition", "kernel_value", "e2e_value", "e2e_ascii_link_value", "single_batch_value"):
         assert k in d, (f, k)
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    # round 6: which collective backend reduced the line's figures ("none" for a plain N = 1 run), config 5's share of one GPU,
+    # the loop's measured rate next to the nominal instruction-mix bound
+    assert d["collective"]["backend"] in ("none", "nccl", "gloo")
+    c5 = d["workloads"]["cfg5_shard"]
+    assert c5["pairs_per_gpu"] == 125000 and c5["value"] > 0 and "configs[4]" in c5["data"]
+    assert 0 < d["valu"]["aggregate_frac_of_measured_loop"] < 1.05
     assert "workload" in d["config"] and "model" not in d["config"] and "DEVICE-RESIDENT" in d["config"]["workload"]
     assert abs(d["value"] - d["config"]["pairs_per_gpu"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-6
     assert d["kernel_value"] == d["value"] and d["e2e_value"] == d["e2e"]["ascii_hostpacked"]["value"]
