@@ -892,8 +892,7 @@ def main():
         # rank, no data-path collective, the totals through one all-reduce).  N > 1: the whole job, `cfg5_pairs` in total
         # (125 k pairs per GPU at 8; at most CFG5_MAX_PER_GPU per GPU, so N = 2 / 3 run a smaller total and say so).  N = 1: the
         # shard one GPU of eight gets, as `cfg5_shard`.
-        per_gpu = min(args.cfg5_pairs // max(world, 8 if world == 1 else 1), CFG5_MAX_PER_GPU)
-        total = per_gpu * world
+        per_gpu, total = shard.config5_plan(args.cfg5_pairs, world, CFG5_MAX_PER_GPU)
         B._cache = None
         B.capi.pool_trim()
         o = B.workload_object("quicked", per_gpu, min(args.steps, 10), 2, with_e2e=False, with_cpu=False)

@@ -26,6 +26,14 @@ def plan(pairs, rank, world, scaling):
     raise ValueError(scaling)
 
 
+def config5_plan(total_pairs, world, max_per_gpu=250000, node_gpus=8):
+    """BASELINE.json configs[4] -- QuickEd score + CIGAR on `total_pairs` (1 M) pairs sharded over the node's GPUs -- for a
+    run on `world` GPUs: -> (pairs per GPU, pairs of the whole job).  world > 1: the job split evenly, at most `max_per_gpu`
+    per GPU (so 2 or 3 GPUs run a smaller total and say so); world == 1: the shard one GPU of `node_gpus` gets."""
+    per_gpu = min(total_pairs // (world if world > 1 else node_gpus), max_per_gpu)
+    return per_gpu, per_gpu * world
+
+
 def reduce_totals(dist, torch, device, pairs, cells, checksum, elapsed, extra_sum=()):
     """SUM of (pairs, cells, checksum, *extra_sum) and MAX of elapsed over the ranks; identity without a process group.
     -> (pairs, cells, checksum, elapsed, [extra sums])"""

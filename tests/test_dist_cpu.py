@@ -130,3 +130,18 @@ def test_launch_ranks_relays_the_json_line(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     last = out.stdout.strip().splitlines()[-1]
     assert json.loads(last) == {"n_gpus": 2, "argv": ["--gpus", "2"]}
+
+
+def test_config_5_plan():
+    """BASELINE.json configs[4] (1 M pairs over 8 GPUs) per world size: 125 k pairs per GPU at 8 and as the N = 1 shard, an even
+    split capped at 250 k per GPU below that, contiguous ranges that tile the job (what bench.py's cfg5 leg runs)"""
+    from quicked_amd import shard
+    assert shard.config5_plan(1000000, 8) == (125000, 1000000)
+    assert shard.config5_plan(1000000, 1) == (125000, 125000)
+    assert shard.config5_plan(1000000, 4) == (250000, 1000000)
+    assert shard.config5_plan(1000000, 2) == (250000, 500000)
+    assert shard.config5_plan(8000, 1) == (1000, 1000) and shard.config5_plan(5000, 2) == (2500, 5000)
+    per_gpu, total = shard.config5_plan(1000000, 8)
+    ranges = [shard.plan(per_gpu, r, 8, "weak")[:2] for r in range(8)]
+    assert ranges[0] == (0, 125000) and all(ranges[r][0] == ranges[r - 1][0] + ranges[r - 1][1] for r in range(1, 8))
+    assert ranges[-1][0] + ranges[-1][1] == total
