@@ -50,3 +50,31 @@ t_res = (time.perf_counter() - t0) / 20
 rb.close()
 print(f"config 1 (1000 x 1 kb, BandEd score-only): per-pair loop {t_loop*1e3:.1f} ms ({1000/t_loop:,.0f} pairs/s), "
       f"one quicked_align_batch call {t_batch*1e3:.2f} ms ({1000/t_batch:,.0f} pairs/s), resident batch run {t_res*1e3:.3f} ms ({1000/t_res:,.0f} pairs/s)")
+
+# The reference's parallel mode over the per-pair ABI (align_benchmark.c:246-284: N OpenMP threads, an aligner per thread and
+# pair): T host threads, each with its own quicked_new / quicked_align / quicked_free per pair.  Every thread has its own
+# context (streams, pools), so the calls of different threads are on the device at the same time.
+import threading
+for length, algo, only, label in ((1000, capi.BANDED, True, "1 kb BandEd score-only"), (10000, capi.QUICKED, False, "10 kb QuickEd + CIGAR")):
+    pairs = list(datagen.generate(400, length, 0.05, seed=5).pairs())
+    p = capi.make_params(algo=algo, only_score=only)
+    want = [once(p, pt) for pt in pairs[:64]]
+    for T in (1, 2, 4, 8, 16):
+        got = [None] * T
+        go = threading.Barrier(T + 1)
+
+        def work(i):
+            for pt in pairs[:8]:
+                once(p, pt)                               # this thread's context: streams, pinned block
+            go.wait()
+            got[i] = [once(p, pt) for pt in pairs]
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+        [t.start() for t in ths]
+        go.wait()
+        t0 = time.perf_counter()
+        [t.join() for t in ths]
+        dt = time.perf_counter() - t0
+        assert all(g[:64] == want for g in got)
+        print(f"{label}, {T:2d} host threads x {len(pairs)} new+align+free each: {T * len(pairs) / dt:9,.0f} calls/s ({dt / len(pairs) * 1e3:.3f} ms per call and thread)", flush=True)
+    capi.pool_trim()
