@@ -941,7 +941,11 @@ static quicked_status_t fetch_pending(quicked_batch& B, FastLeft* left = nullptr
 // caller's fetch then finds the work done.  Runs without deferred pairs are left alone (one 4-byte-per-pair read).
 // QE_FINISHERS = 0 switches it off; default 3 threads, started on demand, detached (they sleep on the queue).
 // ---------------------------------------------------------------------------
-struct FinishJob { quicked_batch* B; std::shared_ptr<void> pf; };
+// device / cigar_style / check: the batch's as they were when the run was queued (under its fin_mu).  A finisher looks at
+// them BEFORE it takes the batch's fin_mu -- it waits for the run's event and picks the queued jobs that fit its flow first --
+// while the batch's owner may be inside quicked_batch_reload / _configure, which write those fields: found by the
+// ThreadSanitizer build under load (one run in ~100; tests/test_host_sanitizers.py)
+struct FinishJob { quicked_batch* B; std::shared_ptr<void> pf; int device = 0, cigar_style = 0; bool check = false; };
 static std::mutex& g_fin_mu = *new std::mutex;                      // never destroyed: detached threads wait on them at exit
 static std::condition_variable& g_fin_cv = *new std::condition_variable;
 static std::deque<FinishJob>& g_fin_q = *new std::deque<FinishJob>;
@@ -1087,8 +1091,8 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
     PendingFetch& F0 = *static_cast<PendingFetch*>(job.pf.get());
     // the run is over (the batch is alive: destroy waits for fin_jobs).  Polled with short sleeps: hipEventSynchronize spins,
     // and these threads wait for every queued QuickEd run of the process.  No context is held meanwhile.
-    HIP_CHECK(hipSetDevice(B0.device));
-    tl_bound_device = B0.device;
+    HIP_CHECK(hipSetDevice(job.device));
+    tl_bound_device = job.device;
     for (;;) {
         const hipError_t e = B0.done_query(F0.parity);
         if (e == hipSuccess) break;
@@ -1103,8 +1107,8 @@ static void finisher_work(const FinishJob& job, std::vector<FinishJob>& taken) {
         std::lock_guard<std::mutex> lk(g_fin_mu);
         for (auto it = g_fin_q.begin(); it != g_fin_q.end() && (int)group.size() < merge_max;) {
             const PendingFetch& F = *static_cast<const PendingFetch*>(it->pf.get());
-            const bool fits = it->B->device == B0.device && it->B != &B0 && same_flow(F0, F) && it->B->cigar_style == B0.cigar_style &&
-                              !it->B->check && !B0.check && it->B->done_query(F.parity) == hipSuccess;
+            const bool fits = it->device == job.device && it->B != &B0 && same_flow(F0, F) && it->cigar_style == job.cigar_style &&
+                              !it->check && !job.check && it->B->done_query(F.parity) == hipSuccess;
             if (fits) { group.push_back(*it); taken.push_back(*it); it = g_fin_q.erase(it); }
             else ++it;
         }
@@ -1299,7 +1303,7 @@ static void finisher_submit(quicked_batch& B, const std::shared_ptr<void>& pf) {
     std::lock_guard<std::mutex> pl(g_fin_pool_mu);                // (order: a batch's fin_mu, the pool, the queue)
     std::lock_guard<std::mutex> lk(g_fin_mu);
     g_fin_limit = max_threads;
-    g_fin_q.push_back(FinishJob{&B, pf});
+    g_fin_q.push_back(FinishJob{&B, pf, B.device, B.cigar_style, B.check});
     if (g_fin_idle == 0 && g_fin_threads < max_threads) { g_fin_pool.emplace_back(finisher_main, g_fin_threads); ++g_fin_threads; }
     g_fin_cv.notify_all();
 }
@@ -1378,7 +1382,8 @@ void batch_load(quicked_batch* B, Context& C, int64_t n,
                        const char* pattern_pool, const int64_t* pattern_off, const int32_t* pattern_len,
                        const char* text_pool, const int64_t* text_off, const int32_t* text_len) {
     batch_reset_state(B);
-    B->n = n; B->device = C.device; B->packed = false; B->wire = 0;
+    B->n = n; B->packed = false; B->wire = 0;
+    if (B->device != C.device) B->device = C.device;      // (a batch stays on its device: no write for a finisher's unlocked reads to race with)
     B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
     // A pool whose pairs lie (nearly) back to back is uploaded as the byte span it is, offsets kept;
     // a sparse one is compacted first.
@@ -1497,7 +1502,8 @@ void batch_load_packed(quicked_batch* B, Context& C, int64_t n, int wire,
                               const uint64_t* pattern_words, const int64_t* pattern_word_off, const int32_t* pattern_len,
                               const uint64_t* text_words, const int64_t* text_word_off, const int32_t* text_len) {
     batch_reset_state(B);
-    B->n = n; B->device = C.device; B->packed = true; B->wire = wire;
+    B->n = n; B->packed = true; B->wire = wire;
+    if (B->device != C.device) B->device = C.device;
     B->p_len.assign(pattern_len, pattern_len + n); B->t_len.assign(text_len, text_len + n);
     B->p_off.assign((size_t)n, 0); B->t_off.assign((size_t)n, 0);
     B->plp_off.resize((size_t)n); B->plt_off.resize((size_t)n);
