@@ -136,6 +136,29 @@ static void scenario_trim_race(int rounds) {
     unsetenv("QE_STUB_SKIP_EVERY");
 }
 
+// 2c. reload right behind a fetch: the caller's own fetch has done a queued run's deferred pairs, the early-finish thread that
+// was handed the same run gets to its job late -- it looks the job over (which device, which flow) before it takes the batch's
+// fin_mu and finds the run superseded -- while the caller is already inside quicked_batch_reload / quicked_batch_configure,
+// which write the batch.  (Round 6's loaded ThreadSanitizer rounds found the finisher reading B.device there, one run in ~100
+// of scenario 1; this scenario is that window, over and over.)
+static void scenario_reload_race(int rounds) {
+    setenv("QE_STUB_SKIP_EVERY", "3", 1);
+    const Pairs P = make_pairs(128, 200, 7), Q = make_pairs(128, 200, 8);
+    const quicked_params_t pq = params(QUICKED, false);
+    std::vector<quicked_batch_t*> bs;
+    for (int k = 0; k < 3; ++k) { bs.push_back(create(P)); CHECK(bs.back()); CHECK(quicked_batch_run(bs[k], &pq, 1) >= 0); }
+    for (int r = 0; r < rounds; ++r)
+        for (size_t k = 0; k < bs.size(); ++k) {
+            CHECK(quicked_batch_run(bs[k], &pq, 0) >= 0);
+            fetch_all(bs[k], P.n);
+            const Pairs& N = ((r + (int)k) & 1) ? Q : P;
+            CHECK(quicked_batch_reload(bs[k], N.n, N.pp.data(), N.po.data(), N.pl.data(), N.tp.data(), N.to.data(), N.tl.data()) >= 0);
+            CHECK(quicked_batch_configure(bs[k], (r + (int)k) % 2, 0) >= 0);
+        }
+    for (quicked_batch_t* b : bs) quicked_batch_destroy(b);
+    unsetenv("QE_STUB_SKIP_EVERY");
+}
+
 // 3. thread churn: short-lived threads with a batch each take over the contexts the ones before them left
 static void scenario_churn(int threads, int alive) {
     std::atomic<int> done{0};
@@ -208,6 +231,7 @@ int main(int argc, char** argv) {
     if (which == "all" || which == "rotation") scenario_rotation();
     if (which == "all" || which == "early") { scenario_early_finish(5, 3, 6); scenario_early_finish(16, 8, 4); }
     if (which == "all" || which == "trim") scenario_trim_race(12);
+    if (which == "all" || which == "reload") scenario_reload_race(40);
     if (which == "all" || which == "churn") scenario_churn(18, 3);
     if (which == "all" || which == "perpair") scenario_per_pair(4, 40);
     if (which == "all" || which == "budget") scenario_budget();
