@@ -686,8 +686,9 @@ class Bench:
                 "instruction_mix_bound_block_columns_per_s": SIMDS * PEAK_CLOCK_HZ * 64 / ISSUE_CYCLES_PER_BLOCK_COLUMN,
                 "aggregate_block_columns_per_s": work_blocks / step_s,
                 # what the pass's own instruction stream does on registers, no memory, two waves per SIMD (the occupancy the
-                # kernel runs at): profiles/r06_b_skew_asm_bench.txt / r06_b_issue_classes.md -- a quarter-rate instruction costs
-                # ~6.8 cycles in a mixed stream, not the nominal 4, so this, not instruction_mix_bound, is the loop's real bound
+                # kernel runs at): profiles/r06_b_skew_asm_bench.txt / r06_b_issue_classes.md -- every variant of the pass issues
+                # at 3.2-3.6 cycles per instruction there whatever its class mix, not at the nominal 2 / 4, so this, not
+                # instruction_mix_bound, is the loop's real bound
                 "measured_loop_block_columns_per_s": MEASURED_LOOP_BLOCK_COLUMNS_PER_S,
                 "aggregate_frac_of_measured_loop": work_blocks / step_s / MEASURED_LOOP_BLOCK_COLUMNS_PER_S,
                 "note": "aggregate = per-step work / step time; peak assumes the 2.4 GHz peak clock (the chip holds less under this "
