@@ -353,6 +353,32 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
         }
     }
     QE_TRACE_POINT("stage 2/3 decisions");
+    // only_score, a run the caller waits for: the score is the end value of the fill's cells; nothing is stored, walked or
+    // formatted (run_fill_score).  Not where a pair holds symbols whose raw bytes differ from their codes (lower case, IUPAC:
+    // the reference's traceback compares the raw bytes, bpm_banded.c:1012, so its edit count is not the matrix's end
+    // value there) -- the pack flags say so; they are this run's (stage 1 has been fetched: the pack is over).
+    auto all_canonical = [&]() {
+        std::vector<u32> fl;
+        d2h(fl, (const u32*)B.d_flags[B.parity], (size_t)B.n, C.stream);
+        HIP_CHECK(hipStreamSynchronize(C.stream));
+        for (u32 f : fl) if (f & FLAG_NONCANON) return false;
+        return true;
+    };
+    if (p.algo == QUICKED && p.only_score && whole_batch && fetch && quicked_score_pass_wanted(L) && all_canonical()) {
+        TaskList LS;
+        for (size_t t = 0; t < L.pair.size(); ++t)
+            if (L.pair[t] >= 0) LS.push(L.pair[t], 0, L.m[t], 0, L.n[t], bound[t], L.n[t]);
+        LS.pad();
+        enter_a();
+        qe_timer_start(tl_timers.align);
+        StageResult RS;
+        run_fill_score(B, C, LS, &RS, &B.d_score);
+        qe_timer_stop(tl_timers.align);
+        scatter_scores(B, LS, RS.score, QUICKED_WIP);
+        B.counters[1] += (int64_t)sum_u32(RS.adv);
+        QE_TRACE_POINT("score pass + fetch");
+        return;
+    }
     // align step: bpm_compute_matrix_hirschberg with the bound (quicked.c:283-294)
     TaskList LA;
     // sized like the fast flow's align step where that is possible (no task may split): buffers for the estimate, the
@@ -412,8 +438,9 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
 // those of the classic flow bit for bit: the bound IS the stage-1 score, sizes never enter a result.
 // ---------------------------------------------------------------------------
 static bool quicked_fast_wanted(const quicked_batch& B, const Context& C, const quicked_params_t& p, const TaskList& L,
-                                std::vector<int32_t>& est) {
+                                std::vector<int32_t>& est, bool fetch) {
     if (p.algo != QUICKED || !quicked_fast_enabled(C) || B.est_bound <= 0) return false;   // the first run of a batch is a classic one
+    if (p.only_score && fetch && quicked_score_pass_wanted(L)) return false;                // the classic flow ends in the score pass
     if (tl_timers.align) return false;          // quicked_align: the aligner's stage timers bracket host-synchronous stages
     const int forced = env_int("QE_QUICKED_EST", 0);                   // tests: a small estimate sends pairs through the overflow path
     const uint64_t split = split_threshold();
@@ -777,7 +804,7 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
     case QUICKED:                                                   // run_quicked, quicked.c:163-306
     case HIRSCHBERG: {                                              // run_hirschberg, quicked.c:125-161
         std::vector<int32_t> est;
-        if (quicked_fast_wanted(B, C, p, L, est)) {
+        if (quicked_fast_wanted(B, C, p, L, est, fetch)) {
             TaskOut W1; DevTasks T1;
             qe_timer_start(tl_timers.windowed_s);
             run_windowed(B, C, L, false, QUICKED_FAST_WINDOW_SIZE, QUICKED_FAST_WINDOW_OVERLAP, (int)p.hew_threshold[0], true, sse,

@@ -910,9 +910,10 @@ __global__ __launch_bounds__(512) void k_banded(BandedArgs A) {
     const bool hasN = (fl & FLAG_HAS_N) != 0;
     const Geom G = band_geometry(m, n, cut_in);
     const int nw = (m + 63) >> 6;
-    // the score-only kernels use their own narrower band (bpm_banded.c:801-803)
-    const int nsl = FILL ? G.ebb : ((G.cutoff + 63) >> 6) + 1;
-    const int stop_row = FILL ? nw - 1 : nw;                       // bpm_banded.c:295 / 917
+    // the score-only kernels use their own narrower band (bpm_banded.c:801-803) -- unless the launch asks for the fill's
+    const bool fgeom = FILL || A.fill_geom != 0;
+    const int nsl = fgeom ? G.ebb : ((G.cutoff + 63) >> 6) + 1;
+    const int stop_row = fgeom ? nw - 1 : nw;                      // bpm_banded.c:295 / 917
     const int lvl_last = (m - 1) & 63;                             // level_mask of the last block
     int first = G.prolog, last = nsl - 1, pos_v = -G.prolog, pos_h = 0;
     int max_row_init = nsl - 1;

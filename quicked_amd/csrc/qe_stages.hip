@@ -241,10 +241,11 @@ static BandState band_state(const ScoreLaunch& S) {
     return b;
 }
 
-static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int timed) {
+static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int timed, bool fill_geom = false) {
     ScoreLaunch S;
     S.nt = L.pair.size();
-    const BandLayout lay = band_layout(L, false, false);
+    BandLayout lay = band_layout(L, fill_geom, false);
+    lay.mat_u4 = 0;                                   // (the fill's geometry, not its checkpoints)
     S.T = upload_tasks(L, C);
     S.D = upload_layout(lay, C);
     S.O = take_out(C, S.nt);
@@ -256,6 +257,7 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     a.o_maxrow = S.O.len;
     a.only_if = nullptr;
     a.lane_rel = env_int("QE_LANE_REL", 1);
+    a.fill_geom = fill_geom ? 1 : 0;
     auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;       // timed = kind + 1 (Context::kernel_events)
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
     // QE_SCORE_WAVES = 3: a 52 KB pin, three workgroups per CU = three waves per SIMD (the kernel's 158 VGPRs allow it)
@@ -554,6 +556,31 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
         fb.add(R->score, S.O.score, S.nt); fb.add(R->adv, S.O.adv, S.nt);
         fb.sync();
     }
+}
+
+// QuickEd with only_score (quicked.c:283-294 aligns and extract_results counts the alignment's edits, quicked.c:34-56): the
+// bound is an upper bound of the distance (it is the cost of a real path), so the banded alignment with that cutoff is an
+// optimal one and its edit count is the value of the fill's end cell -- which a pass over the FILL's cells (its band
+// geometry, its bookkeeping: BandedArgs::fill_geom) computes without storing a checkpoint, walking a path or formatting a
+// run.  No split either: the pass needs no matrix (bpm_hirschberg.c:63-65 splits for memory), and the children's distances
+// add up to the same end value.  One lane per alignment and a host-synchronous flow (the bounds come to the host first):
+// for the runs a caller waits for, of batches that fill the chip -- measured on 10 kb pairs, one run alone (align step /
+// score pass): 4 k pairs 4.9 / 6.0 ms, 8 k 6.2 / 6.2, 12.5 k 8.3 / 6.5, 25 k 13.8 / 9.3, 50 k 15.7 / 9.5, 100 k 24.4 / 16.2;
+// queued runs keep the fast flow, whose stream is faster than this flow's (7.1 against 6.8 M alignments/s at 100 k pairs:
+// profiles/r06_p_probe_score_pass.txt).  QE_QUICKED_SCORE_PASS = 0 / 1: never / wherever the results allow it (tests).
+static bool quicked_score_pass_wanted(const TaskList& L) {
+    const int env = env_int("QE_QUICKED_SCORE_PASS", -1);
+    if (env >= 0) return env != 0;
+    size_t live = 0;
+    for (int32_t pr : L.pair) live += pr >= 0;
+    return live >= (size_t)chip(tl_device).simds * 12;     // 12 288 pairs on an MI355X
+}
+static void run_fill_score(quicked_batch& B, Context& C, const TaskList& L, StageResult* R, int32_t** d_score_out) {
+    const ScoreLaunch S = launch_banded_score(B, C, L, false, 2 /* timed as a fill */, true);
+    if (d_score_out) *d_score_out = S.O.score;
+    FetchBatch fb(C);
+    fb.add(R->score, S.O.score, S.nt); fb.add(R->adv, S.O.adv, S.nt);
+    fb.sync();
 }
 
 // One wave per alignment wherever the strings are more than a few runs long, else one lane per alignment.  Decided before the

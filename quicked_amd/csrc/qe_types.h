@@ -87,6 +87,9 @@ struct BandedArgs {
     int32_t doubling = 0;         // k_banded_sys<.., false>: QuickEd's stage-3 band doubling in the launch (quicked.c:248-278)
     int32_t* o_cutoff = nullptr;  // ... the cutoff of every task's last pass (or, flagged, of the pass it was handed back before)
     int32_t prio = 0;             // the cooperative forms: s_setprio 3 (few waves on a serial chain, next to chip-filling launches)
+    int32_t fill_geom = 0;        // k_banded<false>: the FILL's band geometry (a6's ebb, stop rule nw - 1: bpm_banded.c:121-135, 295) instead of
+                                  // the score-only kernel's narrower one (801-803, 917): the cells, hence the end value, of the fill -- QuickEd with
+                                  // only_score takes its score from such a pass instead of filling, tracing back and counting edits
 };
 
 // BandEd score-only, G lanes per alignment (cooperative form of k_banded<false>)

@@ -521,6 +521,73 @@ def test_randomised_shapes_and_params(seed, monkeypatch):
                 assert out[i][2] == ecg, (kw, i)
 
 
+def test_quicked_only_score_pass(monkeypatch):
+    """QuickEd with only_score, a run the caller waits for: one score-only pass over the FILL's cells (run_fill_score,
+    BandedArgs::fill_geom) instead of fill + traceback + edit count.  Forced wherever the results allow it and switched
+    off: the oracle's scores and statuses on 10 kb reads, indel-heavy pairs (stages 2 / 3), ragged lengths with N; a batch
+    with lower-case / IUPAC symbols (the reference's traceback compares raw bytes, bpm_banded.c:1012: the library must keep
+    the align step there); queued runs (they keep the fast flow); and, above the size where the library takes the pass by
+    itself, the same array as the align step's with the same block-advance count and no traceback step."""
+    sets = [("10 kb", list(datagen.generate(192, 10000, 0.05, seed=611).pairs())),
+            ("indels", list(datagen.generate(160, 3000, 0.1, seed=612, indels_num=2, indels_len=300).pairs())),
+            ("mixed", mixed_batch())]
+    rng = np.random.default_rng(613)
+    ragged = []
+    for i in range(128):
+        L = int(rng.choice([1, 2, 63, 64, 65, 129, 500, 1000, 2500, 4000]))
+        e = float(rng.choice([0.0, 0.02, 0.1, 0.3]))
+        pt, tx = next(datagen.generate(1, L, e if e * L >= 1 or e == 0 else 1, seed=61300 + i).pairs())
+        if rng.random() < 0.2:
+            tx = tx[: max(1, len(tx) - int(rng.integers(0, max(1, len(tx) // 3))))]
+        if rng.random() < 0.15:
+            pt = pt.replace(b"A", b"N", 2)
+        ragged.append((pt, tx))
+    sets.append(("ragged", ragged))
+    kws = (dict(algo=0, only_score=True), dict(algo=0, only_score=True, force_scalar=True),
+           dict(algo=0, only_score=True, window_size=5, overlap_size=2, hew_threshold=(10, 40), hew_percentage=(1, 15)))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("QE_QUICKED_SCORE_PASS", mode)
+        for name, pairs in sets:
+            for kw in kws:
+                al = capi.QuickedAligner()
+                for k, v in kw.items():
+                    if k in ("hew_threshold", "hew_percentage"):
+                        getattr(al._params, k)[0], getattr(al._params, k)[1] = v
+                    else:
+                        setattr(al._params, k, v)
+                for rep in range(2):                          # the second run of an aligner knows its batch's estimate
+                    st, out = al.alignBatch(pairs)
+                    want = oracle_many(pairs, **kw)
+                    assert out == want, (mode, name, kw, rep, [i for i in range(len(pairs)) if out[i] != want[i]][:5])
+    # the library's own choice: >= 12 288 pairs (4 per SIMD ... chip(): simds * 12), synchronous runs only
+    monkeypatch.delenv("QE_QUICKED_SCORE_PASS", raising=False)
+    capi.reload_env()
+    b = datagen.generate(12800, 1000, 0.05, seed=614)
+    rb = capi.ResidentBatch(b)
+    p = capi.make_params(algo=0, only_score=True)
+    got = []
+    for rep in range(2):
+        assert rb.run(p, sync=True) >= 0
+        got.append((rb.scores()[0].copy(), rb.scores()[1].copy(), rb.counters().copy()))
+    assert rb.run(p, sync=False) >= 0                          # queued: the fast flow, fill + traceback
+    rb.fetch()
+    queued = (rb.scores()[0].copy(), rb.scores()[1].copy(), rb.counters().copy())
+    monkeypatch.setenv("QE_QUICKED_SCORE_PASS", "0")
+    assert rb.run(p, sync=True) >= 0
+    off = (rb.scores()[0].copy(), rb.scores()[1].copy(), rb.counters().copy())
+    rb.close()
+    for sc, stt, cnt in got + [queued]:
+        assert np.array_equal(sc, off[0]) and np.array_equal(stt, off[1])
+    for sc, stt, cnt in got:
+        assert cnt[3] == 0 and cnt[4] == 0, cnt                # no traceback step: the pass ran
+        assert cnt[1] == off[2][1] and cnt[0] == off[2][0] and cnt[2] == off[2][2], (cnt, off[2])
+    assert off[2][3] > 0 and queued[2][3] > 0
+    idx = list(range(0, len(b), 61))
+    pl = list(b.pairs())
+    want = oracle_many([pl[i] for i in idx], algo=0, only_score=True)
+    assert [(int(off[1][i]), int(off[0][i]), None) for i in idx] == want
+
+
 @pytest.mark.parametrize("cp", ["1", "0"])
 def test_windowed_checkpoint_and_history_paths(cp, monkeypatch):
     """WindowEd for any window shape but (2, 1): k_windowed_cp keeps checkpoints + carry words and recomputes the tile the

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""QuickEd with only_score: the align step (fill, traceback, edit count) against one score pass over the fill's cells
+(QE_QUICKED_SCORE_PASS = 0 / 1), a stream of queued runs and one run alone, at several batch sizes.  The scores of the two
+must be the same array."""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from quicked_amd import capi, datagen
+
+sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4096, 8192, 12500, 25000, 50000, 100000]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+for n in sizes:
+    b = datagen.generate(n, 10000, 0.05, seed=datagen.DEFAULT_SEED)
+    rb = capi.ResidentBatch(b)
+    ref = None
+    for mode in ("0", "1"):
+        os.environ["QE_QUICKED_SCORE_PASS"] = mode
+        capi.reload_env()
+        p = capi.make_params(algo=capi.QUICKED, only_score=True)
+        for _ in range(2):
+            assert rb.run(p, sync=True) >= 0
+        sc = rb.scores()[0].copy()
+        if ref is None: ref = sc
+        same = bool(np.array_equal(ref, sc))
+        ctr = [int(x) for x in rb.counters()] if hasattr(rb, "counters") else None
+        lat = []
+        for _ in range(5):
+            t0 = time.perf_counter(); assert rb.run(p, sync=True) >= 0; lat.append(time.perf_counter() - t0)
+        for _ in range(6):
+            assert rb.run(p, sync=False) >= 0
+        rb.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            assert rb.run(p, sync=False) >= 0
+        rb.sync()
+        dt = time.perf_counter() - t0
+        print(f"{n:7d} pairs, score pass {mode}: stream {n * steps / dt / 1e6:.3f} M alignments/s, alone {min(lat) * 1e3:.2f} ms; "
+              f"scores identical to the align step's: {same}; counters {ctr}", flush=True)
+    rb.close()
+    capi.pool_trim()
