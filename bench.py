@@ -7,6 +7,7 @@ HBM: pack -> kernels -> results in HBM.  The headline (`value`) is configs[1] of
 
   workloads.quicked  configs[2]: QuickEd bound-and-align + CIGAR on the same pairs, with its own roofline / e2e /
                      cpu_baseline objects (this is the HBM-relevant workload of the path)
+  workloads.quicked_score  (N = 1) the same pairs with only_score: bound, then one score-only pass over the fill's cells
   strong_share       (N = 1) both workloads at 12 500 pairs per step: the per-GPU share of BASELINE.json's "100 k pairs
                      at 8 GPUs", i.e. the rate one GPU of the 8-GPU strong-scaling target sees
   strong             (N > 1) both workloads with `--pairs` pairs IN TOTAL split over the ranks
@@ -760,6 +761,45 @@ class Bench:
         return obj
 
 
+def quicked_score_leg(B, args, expect_checksum):
+    """QuickEd with only_score on the line's pairs (still cached from workloads.quicked): queued runs as the headline loop
+    queues them, one batch alone; the scores must be workloads.quicked's"""
+    capi = B.capi
+    batch = B._cache[1]
+    rb = capi.ResidentBatch(batch)
+    try:
+        params = capi.make_params(algo=capi.QUICKED, only_score=True, bandwidth=args.bandwidth)
+
+        def run(sync):
+            st = rb.run(params, sync=sync)
+            if st < 0:
+                raise RuntimeError(f"quicked_batch_run failed: {capi.lib().quicked_status_msg(st).decode().strip()}")
+        for _ in range(2):
+            run(True)
+        checksum = int(rb.scores()[0].astype(np.int64).sum())
+        lat = []
+        for _ in range(3):
+            t0 = time.perf_counter(); run(True); lat.append(time.perf_counter() - t0)
+        for _ in range(6):
+            run(False)
+        rb.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run(False)
+        rb.sync()
+        dt = time.perf_counter() - t0
+        rb.fetch()
+        cnt = rb.counters()
+        return {"value": len(batch) * args.steps / dt, "unit": "alignments/s", "ms_per_step": dt / args.steps * 1e3,
+                "gcups": batch.cells() * args.steps / dt / 1e9, "pairs_per_gpu": len(batch), "steps": args.steps,
+                "single_batch_latency_ms": min(lat) * 1e3, "score_checksum": checksum,
+                "scores_equal_workloads_quicked": (checksum == expect_checksum) if expect_checksum is not None else None,
+                "traceback_steps": int(cnt[3]), "pairs_finished_outside_the_fast_flow": int(rb.deferred_pairs()),
+                "data": "QuickEd, only_score: WindowEd bound, then one score-only BandEd pass over the fill's cells at that cutoff"}
+    finally:
+        rb.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -850,6 +890,13 @@ def main():
         args.cpu_budget = min(args.cpu_budget, 6.0)
         others["quicked"] = B.workload_object("quicked", args.pairs, args.steps, args.warmup, with_e2e=not args.no_e2e,
                                               with_cpu=not args.no_cpu_baseline)
+    if default_shape and world == 1:
+        # the same pairs once more with only_score: the reference aligns all the same and counts the CIGAR's edits
+        # (quicked.c:283-294); here the scores come from one score-only pass over the fill's cells
+        try:
+            others["quicked_score"] = quicked_score_leg(B, args, others["quicked"].get("score_checksum"))
+        except Exception as e:      # noqa: BLE001  (a leg of its own: the line survives it)
+            others["quicked_score"] = {"error": repr(e)}
     if default_shape and args.indel_pairs > 0 and args.indels_num == 0 and world == 1:
         # QuickEd's stages 2 / 3 (quicked.c:204-280): pairs with large indels leave stage 1, go through WindowEd(L) forward
         # and reverse and, most of them, through score-only BandEd with band doubling before the align step.  Host-driven
@@ -1009,10 +1056,10 @@ def main():
             line["roofline"]["frac_of_measured_copy"] = line["roofline"]["achieved"] / mc
         if others:
             line["workloads"] = {wl: dict(o, config={"workload": f"{wl}, DEVICE-RESIDENT inputs, " +
-                                                                 (f"the same {args.pairs}" if wl == "quicked" else str(o.get("pairs_per_gpu"))) +
+                                                                 (f"the same {args.pairs}" if wl in ("quicked", "quicked_score") else str(o.get("pairs_per_gpu"))) +
                                                                  (" pairs/GPU x 100000 bp @ 0.1 error" if wl == "cfg4" else f" pairs/GPU x {args.length} bp @ {args.error:g} error") +
-                                                                 "; CIGAR strings left in HBM "
-                                                                 "(end-to-end: e2e, strings on the host)"})
+                                                                 ("; scores left in HBM" if wl == "quicked_score" else
+                                                                  "; CIGAR strings left in HBM (end-to-end: e2e, strings on the host)")})
                                  for wl, o in others.items()}
         if strong is not None:
             line["strong"] = strong

@@ -372,7 +372,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
         enter_a();
         qe_timer_start(tl_timers.align);
         StageResult RS;
-        run_fill_score(B, C, LS, &RS, &B.d_score);
+        run_fill_score(B, C, LS, &RS, true, &B.d_score);
         qe_timer_stop(tl_timers.align);
         scatter_scores(B, LS, RS.score, QUICKED_WIP);
         B.counters[1] += (int64_t)sum_u32(RS.adv);
@@ -440,7 +440,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
 static bool quicked_fast_wanted(const quicked_batch& B, const Context& C, const quicked_params_t& p, const TaskList& L,
                                 std::vector<int32_t>& est, bool fetch) {
     if (p.algo != QUICKED || !quicked_fast_enabled(C) || B.est_bound <= 0) return false;   // the first run of a batch is a classic one
-    if (p.only_score && fetch && quicked_score_pass_wanted(L)) return false;                // the classic flow ends in the score pass
+    if (p.only_score && fetch && env_int("QE_QUICKED_SCORE_PASS_FAST", 1) == 0 && quicked_score_pass_wanted(L)) return false;   // the classic flow ends in the score pass
     if (tl_timers.align) return false;          // quicked_align: the aligner's stage timers bracket host-synchronous stages
     const int forced = env_int("QE_QUICKED_EST", 0);                   // tests: a small estimate sends pairs through the overflow path
     const uint64_t split = split_threshold();
@@ -544,8 +544,8 @@ static void stash_results(quicked_batch& B, Context& C, PendingFetch& F) {
         stash_add(items, F.AO.len, nr * 4); stash_add(items, F.AO.edits, nr * 4); stash_add(items, F.AO.nops, nr * 4);
         stash_add(items, F.AO.ok, nr * 4); stash_add(items, F.AO.str_off, nr * 8);
         stash_add(items, F.d_leaf_adv, nl * 4); stash_add(items, F.d_leaf_steps, nl * 4);
-        stash_add(items, F.d_cut, nq * 4); stash_add(items, F.d_skip, nq * 4); stash_add(items, F.d_stage_steps, nq * 4);
     }
+    if (F.fast) { stash_add(items, F.d_cut, nq * 4); stash_add(items, F.d_skip, nq * 4); stash_add(items, F.d_stage_steps, nq * 4); }
     const bool strings = F.kind == 2 && F.want_strings && F.AO.pool && F.AO.total;
     size_t need = 256;
     for (const StashItem& it : items) need += (it.bytes + 255) & ~(size_t)255;
@@ -822,6 +822,9 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
             Stage1Args sa;
             sa.nt = (int32_t)nt; sa.pair = T1.pair; sa.m = T1.m; sa.n = T1.n; sa.score = W1.score; sa.hew = W1.hew; sa.steps = W1.steps;
             sa.est = d_est; sa.hew_percentage = p.hew_percentage[0]; sa.o_cut = d_cut; sa.o_skip = d_skip; sa.o_steps = d_steps;
+            // only_score: the fill's end value from a score-only pass instead of fill + traceback + edit count (run_fill_score)
+            const bool score_pass = p.only_score && quicked_score_pass_wanted(L, !fetch);
+            sa.flags = score_pass ? B.d_flags[B.parity] : nullptr;
             hipLaunchKernelGGL(k_stage1_decide, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, C.stream, sa);
             HIP_CHECK(hipEventRecord(C.ev_decided[C.ai], C.stream));    // the stage's outputs live in the set's W pool, which the set's next run recycles
             C.decided_set[C.ai] = true;
@@ -834,7 +837,13 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
             QE_TRACE_POINT("fast: stage 1 + align list queued");
             qe_timer_start(tl_timers.align);
             AlignStats AS;
-            run_align(B, C, LA, fetch, want_cigar, matrix_budget, split_threshold(), QUICKED_WIP, &B.d_score, &AS, pf, true, d_cut, d_skip);
+            if (score_pass) {
+                LA.pad();
+                StageResult RS;
+                run_fill_score(B, C, LA, &RS, fetch, &B.d_score, pf, d_cut, d_skip);
+                if (fetch) { scatter_scores(B, LA, RS.score, QUICKED_WIP); AS.fill_adv = sum_u32(RS.adv); }      // (the tasks that left the list: -1, 0 -- the classic flow below)
+            } else
+                run_align(B, C, LA, fetch, want_cigar, matrix_budget, split_threshold(), QUICKED_WIP, &B.d_score, &AS, pf, true, d_cut, d_skip);
             qe_timer_stop(tl_timers.align);
             B.counters[1] += (int64_t)AS.fill_adv; B.counters[3] += (int64_t)AS.tb_steps;
             if (pf) {
@@ -949,11 +958,11 @@ static quicked_status_t fetch_pending(quicked_batch& B, FastLeft* left = nullptr
             B.counters[2] += (int64_t)sum_u32(steps);
         }
         fetch_alignments(B, C, F.SL, F.AO, F.want_strings, F.ok_status, F.root_status.empty() ? nullptr : &F.root_status);
-        if (F.fast && left) {
-            if (fast_finish_collect(B, C, F.L, F.d_cut, F.d_skip, F.d_stage_steps, *left)) return QUICKED_OK;      // the caller goes on
-        } else if (F.fast) quicked_fast_finish(B, C, F.params, F.L, F.d_cut, F.d_skip, F.d_stage_steps, F.matrix_budget, F.parity);
     }
-    fetch_finalize(B, F.kind != 1 && F.quicked);
+    if (F.fast && left) {
+        if (fast_finish_collect(B, C, F.L, F.d_cut, F.d_skip, F.d_stage_steps, *left)) return QUICKED_OK;      // the caller goes on
+    } else if (F.fast) quicked_fast_finish(B, C, F.params, F.L, F.d_cut, F.d_skip, F.d_stage_steps, F.matrix_budget, F.parity);
+    fetch_finalize(B, F.quicked && (F.kind != 1 || F.fast));
     return QUICKED_OK;
 }
 

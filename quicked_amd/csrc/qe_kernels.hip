@@ -4077,6 +4077,7 @@ __global__ __launch_bounds__(256) void k_stage1_decide(Stage1Args A) {
         const bool stage2 = (u64)(u32)A.hew[t] * 64u > (u64)(mx * A.hew_percentage / 100u);     // unsigned arithmetic as in quicked.c:201
         cut = A.score[t];
         skip = (stage2 ? 1 : 0) | ((cut > A.est[t]) ? 2 : 0);
+        if (A.flags != nullptr && (A.flags[A.pair[t]] & FLAG_NONCANON)) skip |= 4;
         steps = A.steps[t];
     }
     A.o_cut[t] = cut; A.o_skip[t] = skip; A.o_steps[t] = steps;

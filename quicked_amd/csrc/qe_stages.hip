@@ -241,7 +241,10 @@ static BandState band_state(const ScoreLaunch& S) {
     return b;
 }
 
-static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int timed, bool fill_geom = false) {
+// d_cut / d_skip: the cutoffs are still being computed on the device (QuickEd's fast flow): the list's are the estimates the
+// buffers are sized for; k_apply_cutoffs puts the real ones in and takes the tasks out that the host finishes afterwards
+static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int timed, bool fill_geom = false,
+                                       const int32_t* d_cut = nullptr, const int32_t* d_skip = nullptr) {
     ScoreLaunch S;
     S.nt = L.pair.size();
     BandLayout lay = band_layout(L, fill_geom, false);
@@ -249,6 +252,10 @@ static ScoreLaunch launch_banded_score(quicked_batch& B, Context& C, const TaskL
     S.T = upload_tasks(L, C);
     S.D = upload_layout(lay, C);
     S.O = take_out(C, S.nt);
+    if (d_cut) {
+        HIP_CHECK(hipMemsetAsync(S.O.score, 0xFF, S.nt * sizeof(int32_t), C.stream));      // a task taken out of the list has no score (-1)
+        hipLaunchKernelGGL(k_apply_cutoffs, dim3((unsigned)((S.nt + 255) / 256)), dim3(256), 0, C.stream, (int)S.nt, S.T.cutoff, S.T.pair, d_cut, d_skip);
+    }
     BandedArgs a;
     a.P = pair_view(B, reversed); a.T = S.T.v;
     a.ws = S.D.ws; a.g_ws_off = S.D.ws_off; a.g_nslots = S.D.nslots; a.g_nrows = S.D.nrows; a.g_nch = S.D.nch;
@@ -563,24 +570,36 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
 // optimal one and its edit count is the value of the fill's end cell -- which a pass over the FILL's cells (its band
 // geometry, its bookkeeping: BandedArgs::fill_geom) computes without storing a checkpoint, walking a path or formatting a
 // run.  No split either: the pass needs no matrix (bpm_hirschberg.c:63-65 splits for memory), and the children's distances
-// add up to the same end value.  One lane per alignment and a host-synchronous flow (the bounds come to the host first):
-// for the runs a caller waits for, of batches that fill the chip -- measured on 10 kb pairs, one run alone (align step /
-// score pass): 4 k pairs 4.9 / 6.0 ms, 8 k 6.2 / 6.2, 12.5 k 8.3 / 6.5, 25 k 13.8 / 9.3, 50 k 15.7 / 9.5, 100 k 24.4 / 16.2;
-// queued runs keep the fast flow, whose stream is faster than this flow's (7.1 against 6.8 M alignments/s at 100 k pairs:
-// profiles/r06_p_probe_score_pass.txt).  QE_QUICKED_SCORE_PASS = 0 / 1: never / wherever the results allow it (tests).
-static bool quicked_score_pass_wanted(const TaskList& L) {
+// add up to the same end value.  One lane per alignment.  Measured on 10 kb pairs (align step / score pass,
+// profiles/r06_q_probe_score_pass.txt): one run alone 4 k pairs 4.8 / 5.9 ms, 8 k 6.1 / 6.1, 12.5 k 8.0 / 6.2, 25 k 13.5 / 8.5,
+// 100 k 21.9 / 14.3 -- synchronous runs take the pass from 12 per SIMD (12 288 pairs) on, smaller ones keep the cooperative
+// align step; a stream of queued runs 1 k pairs 0.33 / 1.45 M alignments/s, 4 k 2.8 / 4.6, 12.5 k 5.4 / 8.6, 100 k 7.05 / 11.15
+// -- queued runs take it from one pair per SIMD on.  In the fast flow the pass reads its cutoffs from the device like the
+// align step does (k_apply_cutoffs); pairs with lower-case / IUPAC symbols leave the flow there (Stage1Args::flags) and in the
+// host-driven flow keep the whole batch on the align step.  QE_QUICKED_SCORE_PASS = 0 / 1: never / wherever the results allow
+// it (tests); QE_QUICKED_SCORE_PASS_FAST = 0: synchronous runs take it at the end of the host-driven flow only.
+enum : int { QE_SCORE_PASS_QUEUED_PER_SIMD = 1 };
+static bool quicked_score_pass_wanted(const TaskList& L, bool queued = false) {
     const int env = env_int("QE_QUICKED_SCORE_PASS", -1);
     if (env >= 0) return env != 0;
     size_t live = 0;
     for (int32_t pr : L.pair) live += pr >= 0;
-    return live >= (size_t)chip(tl_device).simds * 12;     // 12 288 pairs on an MI355X
+    return live >= (size_t)chip(tl_device).simds * (queued ? QE_SCORE_PASS_QUEUED_PER_SIMD : 12);     // 12 288 pairs on an MI355X
 }
-static void run_fill_score(quicked_batch& B, Context& C, const TaskList& L, StageResult* R, int32_t** d_score_out) {
-    const ScoreLaunch S = launch_banded_score(B, C, L, false, 2 /* timed as a fill */, true);
+// fetch: the scores and block-advance counts to the host (R).  pf: a queued run's (kind 1; the fast flow's fields are the caller's)
+static void run_fill_score(quicked_batch& B, Context& C, const TaskList& L, StageResult* R, bool fetch, int32_t** d_score_out,
+                           PendingFetch* pf = nullptr, const int32_t* d_cut = nullptr, const int32_t* d_skip = nullptr) {
+    const ScoreLaunch S = launch_banded_score(B, C, L, false, 2 /* timed as a fill */, true, d_cut, d_skip);
     if (d_score_out) *d_score_out = S.O.score;
-    FetchBatch fb(C);
-    fb.add(R->score, S.O.score, S.nt); fb.add(R->adv, S.O.adv, S.nt);
-    fb.sync();
+    if (pf && !fetch) {
+        pf->kind = 1; pf->task_pair = L.pair; pf->d_score = S.O.score; pf->d_adv = S.O.adv; pf->counter_slot = 1;
+        pf->ok_status = QUICKED_WIP;
+    }
+    if (fetch && R) {
+        FetchBatch fb(C);
+        fb.add(R->score, S.O.score, S.nt); fb.add(R->adv, S.O.adv, S.nt);
+        fb.sync();
+    }
 }
 
 // One wave per alignment wherever the strings are more than a few runs long, else one lane per alignment.  Decided before the

@@ -166,8 +166,10 @@ struct Stage1Args {
     const int32_t* est;
     u32 hew_percentage;
     int32_t* o_cut;      // the bound = the align step's cutoff
-    int32_t* o_skip;     // bit 0: the pair goes on to stage 2; bit 1: its bound exceeds the estimate the buffers were sized for
+    int32_t* o_skip;     // bit 0: the pair goes on to stage 2; bit 1: its bound exceeds the estimate the buffers were sized for; bit 2: see flags
     u32* o_steps;        // copy of steps (the stage's buffers are recycled before the run is fetched)
+    const u32* flags = nullptr;   // the pack flags by pair, where a score pass follows instead of the align step (only_score): a pair with
+                                  // FLAG_NONCANON leaves the list too (bit 2 of o_skip) -- its edit count is not the matrix's end value
 };
 
 // Where a stopped score-only BandEd launch left its band (what the Hirschberg join reads)

@@ -224,6 +224,9 @@ def test_newest_committed_bench_line_follows_the_contract():
     for wl in ("quicked", "cfg4", "quicked_indels", "quicked_mixed"):
         assert w[wl]["value"] > 0 and w[wl]["cpu_baseline"]["value"] > 0, (f, wl)
     assert w["quicked"]["score_checksum"] == d["score_checksum"]            # BandEd (bandwidth 15) and QuickEd agree on every distance
+    # round 6, late: QuickEd with only_score takes its scores from one score-only pass over the fill's cells
+    qs = w["quicked_score"]
+    assert qs["scores_equal_workloads_quicked"] is True and qs["traceback_steps"] == 0 and qs["value"] > w["quicked"]["value"]
     assert w["quicked_indels"]["quicked_flow"]["stage2_pairs"] > 0 and w["quicked_indels"]["quicked_flow"]["stage3_pairs"] > 0
     s = d["strong_share"]
     assert s["pairs_per_gpu"] == 12500

@@ -526,8 +526,9 @@ def test_quicked_only_score_pass(monkeypatch):
     BandedArgs::fill_geom) instead of fill + traceback + edit count.  Forced wherever the results allow it and switched
     off: the oracle's scores and statuses on 10 kb reads, indel-heavy pairs (stages 2 / 3), ragged lengths with N; a batch
     with lower-case / IUPAC symbols (the reference's traceback compares raw bytes, bpm_banded.c:1012: the library must keep
-    the align step there); queued runs (they keep the fast flow); and, above the size where the library takes the pass by
-    itself, the same array as the align step's with the same block-advance count and no traceback step."""
+    the align step there); queued runs, where the pass sits inside the fast flow with its cutoffs still on the device and
+    the pairs that leave the flow are finished afterwards; and, above the size where the library takes the pass by itself, the
+    same array as the align step's with the same block-advance count and no traceback step."""
     sets = [("10 kb", list(datagen.generate(192, 10000, 0.05, seed=611).pairs())),
             ("indels", list(datagen.generate(160, 3000, 0.1, seed=612, indels_num=2, indels_len=300).pairs())),
             ("mixed", mixed_batch())]
@@ -555,11 +556,28 @@ def test_quicked_only_score_pass(monkeypatch):
                         getattr(al._params, k)[0], getattr(al._params, k)[1] = v
                     else:
                         setattr(al._params, k, v)
-                for rep in range(2):                          # the second run of an aligner knows its batch's estimate
+                want = oracle_many(pairs, **kw)
+                for rep in range(2):                          # the second run of an aligner knows its batch's estimate: the fast flow
                     st, out = al.alignBatch(pairs)
-                    want = oracle_many(pairs, **kw)
                     assert out == want, (mode, name, kw, rep, [i for i in range(len(pairs)) if out[i] != want[i]][:5])
-    # the library's own choice: >= 12 288 pairs (4 per SIMD ... chip(): simds * 12), synchronous runs only
+            # queued runs (the fast flow from the second on; pairs that leave it -- stage 2, bounds above the estimate, raw
+            # symbols -- finished by the library's threads or the fetch), a small forced estimate once
+            kw = kws[0]
+            want = oracle_many(pairs, **kw)
+            rb = capi.ResidentBatch(datagen.PairBatch(*_pools(pairs)))
+            p = capi.make_params(**kw)
+            for rep in range(4):
+                if rep == 3:
+                    monkeypatch.setenv("QE_QUICKED_EST", "40")
+                assert rb.run(p, sync=False) >= 0
+                rb.fetch()
+                sc, stt = rb.scores()
+                out = [(int(stt[i]), int(sc[i])) for i in range(len(pairs))]
+                assert out == [w[:2] for w in want], (mode, name, rep, [i for i in range(len(pairs)) if out[i] != want[i][:2]][:5])
+            monkeypatch.delenv("QE_QUICKED_EST", raising=False)
+            capi.reload_env()
+            rb.close()
+    # the library's own choice: synchronous runs of >= 12 288 pairs (chip(): simds * 12), queued runs of >= 1 024
     monkeypatch.delenv("QE_QUICKED_SCORE_PASS", raising=False)
     capi.reload_env()
     b = datagen.generate(12800, 1000, 0.05, seed=614)
@@ -569,7 +587,7 @@ def test_quicked_only_score_pass(monkeypatch):
     for rep in range(2):
         assert rb.run(p, sync=True) >= 0
         got.append((rb.scores()[0].copy(), rb.scores()[1].copy(), rb.counters().copy()))
-    assert rb.run(p, sync=False) >= 0                          # queued: the fast flow, fill + traceback
+    assert rb.run(p, sync=False) >= 0                          # queued: the pass inside the fast flow, cutoffs from the device
     rb.fetch()
     queued = (rb.scores()[0].copy(), rb.scores()[1].copy(), rb.counters().copy())
     monkeypatch.setenv("QE_QUICKED_SCORE_PASS", "0")
@@ -578,10 +596,10 @@ def test_quicked_only_score_pass(monkeypatch):
     rb.close()
     for sc, stt, cnt in got + [queued]:
         assert np.array_equal(sc, off[0]) and np.array_equal(stt, off[1])
-    for sc, stt, cnt in got:
+    for sc, stt, cnt in got + [queued]:
         assert cnt[3] == 0 and cnt[4] == 0, cnt                # no traceback step: the pass ran
         assert cnt[1] == off[2][1] and cnt[0] == off[2][0] and cnt[2] == off[2][2], (cnt, off[2])
-    assert off[2][3] > 0 and queued[2][3] > 0
+    assert off[2][3] > 0
     idx = list(range(0, len(b), 61))
     pl = list(b.pairs())
     want = oracle_many([pl[i] for i in idx], algo=0, only_score=True)

@@ -8,14 +8,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from quicked_amd import capi, datagen
 
-sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4096, 8192, 12500, 25000, 50000, 100000]
+sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1024, 2048, 4096, 8192, 12500, 25000, 50000, 100000]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for n in sizes:
     b = datagen.generate(n, 10000, 0.05, seed=datagen.DEFAULT_SEED)
     rb = capi.ResidentBatch(b)
     ref = None
-    for mode in ("0", "1"):
+    for mode, fast in (("0", "1"), ("1", "0"), ("1", "1")):
         os.environ["QE_QUICKED_SCORE_PASS"] = mode
+        os.environ["QE_QUICKED_SCORE_PASS_FAST"] = fast      # 0: synchronous runs take the pass at the end of the host-driven flow
         capi.reload_env()
         p = capi.make_params(algo=capi.QUICKED, only_score=True)
         for _ in range(2):
@@ -35,7 +36,7 @@ for n in sizes:
             assert rb.run(p, sync=False) >= 0
         rb.sync()
         dt = time.perf_counter() - t0
-        print(f"{n:7d} pairs, score pass {mode}: stream {n * steps / dt / 1e6:.3f} M alignments/s, alone {min(lat) * 1e3:.2f} ms; "
+        print(f"{n:7d} pairs, score pass {mode} (sync runs in the fast flow {fast}): stream {n * steps / dt / 1e6:.3f} M alignments/s, alone {min(lat) * 1e3:.2f} ms; "
               f"scores identical to the align step's: {same}; counters {ctr}", flush=True)
     rb.close()
     capi.pool_trim()

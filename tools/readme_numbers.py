@@ -44,7 +44,10 @@ def paragraph(tag=None):
         f"`{tag}_bench_cfg4.json`; this paragraph is generated from them by `tools/readme_numbers.py`), "
         f"{cfg['pairs_per_gpu'] // 1000} k pairs of {cfg['length'] // 1000} kb at {cfg['error'] * 100:.0f} % error per batch: "
         f"BandEd score-only **{m(d['value'], 2)} alignments/s** device-resident ({d['gcups'] / 1e3:.0f} k GCUPS); "
-        f"QuickEd + CIGAR **{m(q['value'], 2)} alignments/s**; end to end with the results on the host "
+        f"QuickEd + CIGAR **{m(q['value'], 2)} alignments/s**"
+        + (f" (scores only: {m(d['workloads']['quicked_score']['value'], 1)}, one batch alone in "
+           f"{d['workloads']['quicked_score']['single_batch_latency_ms']:.1f} ms)" if "value" in d["workloads"].get("quicked_score", {}) else "")
+        + f"; end to end with the results on the host "
         f"{m(e['2bit_pinned']['value'])} / {m(eq['2bit_pinned']['value'])} from pinned 2-bit words, "
         f"**{m(e['ascii_hostpacked']['value'])} / {m(eq['ascii_hostpacked']['value'])} from ASCII packed on the host inside the clock**, "
         f"{m(e['ascii_pinned']['value'])} / {m(eq['ascii_pinned']['value'])} from ASCII over the link (PCIe-bound); "
