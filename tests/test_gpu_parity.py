@@ -519,6 +519,25 @@ def test_randomised_shapes_and_params(seed, monkeypatch):
             if est >= 0 and in_domain:
                 assert out[i][1] == esc, (kw, i, len(p), len(t))
                 assert out[i][2] == ecg, (kw, i)
+        if algo == 0:
+            # the same through a resident batch: its first run is a host-driven one (and sets the bound estimate), the second
+            # -- synchronous -- and the third -- queued, then fetched -- go through the fast flow (the aligner's calls above
+            # never do: its stage timers bracket host-synchronous stages)
+            rb = capi.ResidentBatch(datagen.PairBatch(*_pools(pairs)))
+            pp = capi.make_params(**kw)
+            for rep in range(3):
+                st = rb.run(pp, sync=rep < 2)
+                assert st >= 0 or st == capi.QUICKED_EMPTY_SEQUENCE, st
+                if rep == 2:
+                    rb.fetch()
+                sc, stt = rb.scores()
+                cg = None if kw["only_score"] else rb.cigars()
+                for i, (p, t) in enumerate(pairs):
+                    est, esc, ecg = oracle_cached(p, t, **kw)
+                    assert stt[i] == est, (kw, i, rep)
+                    if est >= 0:
+                        assert sc[i] == esc and (cg is None or cg[i] == ecg), (kw, i, rep, len(p), len(t))
+            rb.close()
 
 
 def test_quicked_only_score_pass(monkeypatch):
@@ -557,9 +576,8 @@ def test_quicked_only_score_pass(monkeypatch):
                     else:
                         setattr(al._params, k, v)
                 want = oracle_many(pairs, **kw)
-                for rep in range(2):                          # the second run of an aligner knows its batch's estimate: the fast flow
-                    st, out = al.alignBatch(pairs)
-                    assert out == want, (mode, name, kw, rep, [i for i in range(len(pairs)) if out[i] != want[i]][:5])
+                st, out = al.alignBatch(pairs)                # (the host-driven flow: an aligner's stage timers keep it there)
+                assert out == want, (mode, name, kw, [i for i in range(len(pairs)) if out[i] != want[i]][:5])
             # queued runs (the fast flow from the second on; pairs that leave it -- stage 2, bounds above the estimate, raw
             # symbols -- finished by the library's threads or the fetch), a small forced estimate once
             kw = kws[0]
