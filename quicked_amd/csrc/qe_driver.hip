@@ -364,7 +364,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
         for (u32 f : fl) if (f & FLAG_NONCANON) return false;
         return true;
     };
-    if (p.algo == QUICKED && p.only_score && whole_batch && fetch && quicked_score_pass_wanted(L) && all_canonical()) {
+    if (p.algo == QUICKED && p.only_score && whole_batch && fetch && quicked_score_pass_wanted() && all_canonical()) {
         TaskList LS;
         for (size_t t = 0; t < L.pair.size(); ++t)
             if (L.pair[t] >= 0) LS.push(L.pair[t], 0, L.m[t], 0, L.n[t], bound[t], L.n[t]);
@@ -440,7 +440,7 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
 static bool quicked_fast_wanted(const quicked_batch& B, const Context& C, const quicked_params_t& p, const TaskList& L,
                                 std::vector<int32_t>& est, bool fetch) {
     if (p.algo != QUICKED || !quicked_fast_enabled(C) || B.est_bound <= 0) return false;   // the first run of a batch is a classic one
-    if (p.only_score && fetch && env_int("QE_QUICKED_SCORE_PASS_FAST", 1) == 0 && quicked_score_pass_wanted(L)) return false;   // the classic flow ends in the score pass
+    if (p.only_score && fetch && env_int("QE_QUICKED_SCORE_PASS_FAST", 1) == 0 && quicked_score_pass_wanted()) return false;   // the classic flow ends in the score pass
     if (tl_timers.align) return false;          // quicked_align: the aligner's stage timers bracket host-synchronous stages
     const int forced = env_int("QE_QUICKED_EST", 0);                   // tests: a small estimate sends pairs through the overflow path
     const uint64_t split = split_threshold();
@@ -823,7 +823,7 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
             sa.nt = (int32_t)nt; sa.pair = T1.pair; sa.m = T1.m; sa.n = T1.n; sa.score = W1.score; sa.hew = W1.hew; sa.steps = W1.steps;
             sa.est = d_est; sa.hew_percentage = p.hew_percentage[0]; sa.o_cut = d_cut; sa.o_skip = d_skip; sa.o_steps = d_steps;
             // only_score: the fill's end value from a score-only pass instead of fill + traceback + edit count (run_fill_score)
-            const bool score_pass = p.only_score && quicked_score_pass_wanted(L, !fetch);
+            const bool score_pass = p.only_score && quicked_score_pass_wanted();
             sa.flags = score_pass ? B.d_flags[B.parity] : nullptr;
             hipLaunchKernelGGL(k_stage1_decide, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, C.stream, sa);
             HIP_CHECK(hipEventRecord(C.ev_decided[C.ai], C.stream));    // the stage's outputs live in the set's W pool, which the set's next run recycles

@@ -2064,7 +2064,8 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
         fl = A.P.flags[pair];
     }
     const int nw = (m + 63) >> 6;
-    const int stop_row = FILL ? nw - 1 : nw;                       // bpm_banded.c:295 / 917
+    const bool fgeom = FILL || A.fill_geom != 0;                   // score-only over the fill's cells (BandedArgs::fill_geom)
+    const int stop_row = fgeom ? nw - 1 : nw;                      // bpm_banded.c:295 / 917
     const u64 lvl_mask = (m & 63) ? (((u64)1 << (m & 63)) - 1) : QE_ONES;     // rows of the last block up to the pattern's end
     u32 adv = 0;
     // A.doubling (score-only): QuickEd's stage-3 loop (quicked.c:248-278) on the device -- while the pass's score says the
@@ -2075,7 +2076,7 @@ __global__ __launch_bounds__(256) void k_banded_sys(BandedArgs A) {
     bool want = valid;
     for (;;) {
     const Geom G = band_geometry(m, n, cut_cur);
-    const int nsl = FILL ? G.ebb : ((G.cutoff + 63) >> 6) + 1;    // the score-only kernels' own band (bpm_banded.c:801-803)
+    const int nsl = fgeom ? G.ebb : ((G.cutoff + 63) >> 6) + 1;   // the score-only kernels' own band (bpm_banded.c:801-803)
     const bool elig = (fl & FLAG_HAS_N) == 0 && nsl <= GM && tfin == n;
     const bool ok = want && elig;
     if (want && !elig) {
@@ -2347,11 +2348,12 @@ __global__ __launch_bounds__(256) void k_banded_sys2(BandedArgs A) {
     const u32 fl = A.P.flags[pair];
     const Geom G = band_geometry(m, n, cut_in);
     const int nw = (m + 63) >> 6;
-    const int nsl = FILL ? G.ebb : ((G.cutoff + 63) >> 6) + 1;
+    const bool fgeom = FILL || A.fill_geom != 0;
+    const int nsl = fgeom ? G.ebb : ((G.cutoff + 63) >> 6) + 1;
     const bool ok = (fl & FLAG_HAS_N) == 0 && nsl <= 2 * GL - 1 && tfin == n;
     if (j == 0) A.o_abort[t] = ok ? 0 : 1;
     if (!ok) return;
-    const int stop_row = FILL ? nw - 1 : nw;
+    const int stop_row = fgeom ? nw - 1 : nw;
     const u64 lvl_mask = (m & 63) ? (((u64)1 << (m & 63)) - 1) : QE_ONES;
     int first = G.prolog, last = nsl - 1, pos_v = -G.prolog, pos_h = 0;
     int max_row_init = nsl - 1;

@@ -465,16 +465,23 @@ static ScoreLaunch launch_banded_wave(quicked_batch& B, Context& C, const TaskLi
 
 // k_banded_sys<.., false> over the list (16 lanes per task for bands of <= 15 slots, else a wave per task), then
 // k_banded<false> over the tasks it flagged (N, a taller band)
-static ScoreLaunch launch_banded_sys(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int lg, int timed) {
+static ScoreLaunch launch_banded_sys(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int lg, int timed, bool fill_geom = false,
+                                     const int32_t* d_cut = nullptr, const int32_t* d_skip = nullptr) {
     ScoreLaunch S;
     S.nt = L.pair.size();
-    const BandLayout lay = band_layout(L, false, false);
+    BandLayout lay = band_layout(L, fill_geom, false);
+    lay.mat_u4 = 0;
     int max_nsl = 0;
     for (int32_t v : lay.nslots) max_nsl = std::max(max_nsl, (int)v);
     S.T = upload_tasks(L, C);
     S.D = upload_layout(lay, C);
     S.O = take_out(C, S.nt);
+    if (d_cut) {       // as launch_banded_score
+        HIP_CHECK(hipMemsetAsync(S.O.score, 0xFF, S.nt * sizeof(int32_t), C.stream));
+        hipLaunchKernelGGL(k_apply_cutoffs, dim3((unsigned)((S.nt + 255) / 256)), dim3(256), 0, C.stream, (int)S.nt, S.T.cutoff, S.T.pair, d_cut, d_skip);
+    }
     BandedArgs a;
+    a.fill_geom = fill_geom ? 1 : 0;
     a.P = pair_view(B, reversed); a.T = S.T.v;
     a.ws = S.D.ws; a.g_ws_off = S.D.ws_off; a.g_nslots = S.D.nslots; a.g_nrows = S.D.nrows; a.g_nch = S.D.nch;
     a.mat = nullptr; a.g_mat_off = S.D.mat_off;
@@ -494,7 +501,7 @@ static ScoreLaunch launch_banded_sys(quicked_batch& B, Context& C, const TaskLis
 }
 // whole-text passes on few tasks (QuickEd's stage-3 doubling rounds on the pairs a run left, a BandEd score-only call on one
 // pair or a few hundred): 0 = no, else log2 of the lanes per task.  QE_SCORE_SYS = 0 / 1: never / wherever eligible (tests)
-static int sys_score_lanes(const TaskList& L, int in_flight) {
+static int sys_score_lanes(const TaskList& L, int in_flight, bool fill_geom = false) {
     const int env = env_int("QE_SCORE_SYS", -1);
     if (env == 0) return 0;
     size_t live = 0;
@@ -503,12 +510,14 @@ static int sys_score_lanes(const TaskList& L, int in_flight) {
         if (L.pair[t] < 0) continue;
         ++live;
         if (L.tfin[t] != L.n[t]) return 0;                  // a stopped band is exported in k_banded's layout (Hirschberg half passes)
-        max_nsl = std::max(max_nsl, host_geometry(L.m[t], L.n[t], L.cutoff[t]).ebb_local);
+        const HGeom hg = host_geometry(L.m[t], L.n[t], L.cutoff[t]);
+        max_nsl = std::max(max_nsl, fill_geom ? hg.ebb : hg.ebb_local);
     }
     if (live == 0 || max_nsl > 127) return 0;
     const size_t nt = L.pair.size(), fl = (size_t)std::max(1, in_flight);
     const Chip& chp = chip(tl_device);
-    if (max_nsl <= 15) return (env == 1 || nt / 4 * fl <= chp.slots2()) ? 4 : 0;      // one round of waves
+    // one round of waves; two for the pass over the fill's cells, as for the fill itself (run_align's sys_fill: 12.5 k tasks, 3 125 waves)
+    if (max_nsl <= 15) return (env == 1 || nt / 4 * fl <= (fill_geom ? 2 : 1) * chp.slots2()) ? 4 : 0;
     return (env == 1 || nt * fl <= chp.frac2(0.54)) ? 6 : 0;                            // a wave per task: about a wave per SIMD
 }
 
@@ -570,26 +579,22 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
 // optimal one and its edit count is the value of the fill's end cell -- which a pass over the FILL's cells (its band
 // geometry, its bookkeeping: BandedArgs::fill_geom) computes without storing a checkpoint, walking a path or formatting a
 // run.  No split either: the pass needs no matrix (bpm_hirschberg.c:63-65 splits for memory), and the children's distances
-// add up to the same end value.  One lane per alignment.  Measured on 10 kb pairs (align step / score pass,
-// profiles/r06_q_probe_score_pass.txt): one run alone 4 k pairs 4.8 / 5.9 ms, 8 k 6.1 / 6.1, 12.5 k 8.0 / 6.2, 25 k 13.5 / 8.5,
-// 100 k 21.9 / 14.3 -- synchronous runs take the pass from 12 per SIMD (12 288 pairs) on, smaller ones keep the cooperative
-// align step; a stream of queued runs 1 k pairs 0.33 / 1.45 M alignments/s, 4 k 2.8 / 4.6, 12.5 k 5.4 / 8.6, 100 k 7.05 / 11.15
-// -- queued runs take it from one pair per SIMD on.  In the fast flow the pass reads its cutoffs from the device like the
-// align step does (k_apply_cutoffs); pairs with lower-case / IUPAC symbols leave the flow there (Stage1Args::flags) and in the
-// host-driven flow keep the whole batch on the align step.  QE_QUICKED_SCORE_PASS = 0 / 1: never / wherever the results allow
-// it (tests); QE_QUICKED_SCORE_PASS_FAST = 0: synchronous runs take it at the end of the host-driven flow only.
-enum : int { QE_SCORE_PASS_QUEUED_PER_SIMD = 1 };
-static bool quicked_score_pass_wanted(const TaskList& L, bool queued = false) {
-    const int env = env_int("QE_QUICKED_SCORE_PASS", -1);
-    if (env >= 0) return env != 0;
-    size_t live = 0;
-    for (int32_t pr : L.pair) live += pr >= 0;
-    return live >= (size_t)chip(tl_device).simds * (queued ? QE_SCORE_PASS_QUEUED_PER_SIMD : 12);     // 12 288 pairs on an MI355X
-}
+// add up to the same end value.  One lane per alignment, or the systolic forms where the launch is short of waves (run_fill_score).
+// Measured on 10 kb pairs (align step / score pass, profiles/r06_t_probe_score_pass*.txt): one run alone 1 pair 3.9 / 2.9 ms,
+// 1 k pairs 4.7 / 3.2, 4 k 4.8 / 3.2, 8 k 6.1 / 3.8, 12.5 k 8.2 / 5.0, 25 k 13.5 / 8.6, 100 k 21.9 / 14.3; a stream of queued runs
+// 1 k pairs 0.44 / 1.5 M alignments/s, 4 k 2.9 / 4.8, 12.5 k 5.6 / 9.1, 25 k 6.3 / 10.4, 100 k 7.05 / 11.5 -- every size, so always.
+// In the fast flow the pass reads its cutoffs from the device like the align step does (k_apply_cutoffs); pairs with lower-case /
+// IUPAC symbols leave the flow there (Stage1Args::flags) and in the host-driven flow keep the whole batch on the align step.
+// QE_QUICKED_SCORE_PASS = 0: never (the align step: tests); QE_QUICKED_SCORE_PASS_FAST = 0: synchronous runs take the pass at the
+// end of the host-driven flow only.
+static bool quicked_score_pass_wanted() { return env_int("QE_QUICKED_SCORE_PASS", 1) != 0; }
 // fetch: the scores and block-advance counts to the host (R).  pf: a queued run's (kind 1; the fast flow's fields are the caller's)
 static void run_fill_score(quicked_batch& B, Context& C, const TaskList& L, StageResult* R, bool fetch, int32_t** d_score_out,
                            PendingFetch* pf = nullptr, const int32_t* d_cut = nullptr, const int32_t* d_skip = nullptr) {
-    const ScoreLaunch S = launch_banded_score(B, C, L, false, 2 /* timed as a fill */, true, d_cut, d_skip);
+    // launches of few waves: the systolic forms (16 lanes or a wave per task), as the score-only passes and the fills take them
+    const int lg = sys_score_lanes(L, fetch ? 1 : C.in_flight, true);
+    const ScoreLaunch S = lg ? launch_banded_sys(B, C, L, false, lg, 2 /* timed as a fill */, true, d_cut, d_skip)
+                             : launch_banded_score(B, C, L, false, 2, true, d_cut, d_skip);
     if (d_score_out) *d_score_out = S.O.score;
     if (pf && !fetch) {
         pf->kind = 1; pf->task_pair = L.pair; pf->d_score = S.O.score; pf->d_adv = S.O.adv; pf->counter_slot = 1;

@@ -541,13 +541,13 @@ def test_randomised_shapes_and_params(seed, monkeypatch):
 
 
 def test_quicked_only_score_pass(monkeypatch):
-    """QuickEd with only_score, a run the caller waits for: one score-only pass over the FILL's cells (run_fill_score,
-    BandedArgs::fill_geom) instead of fill + traceback + edit count.  Forced wherever the results allow it and switched
-    off: the oracle's scores and statuses on 10 kb reads, indel-heavy pairs (stages 2 / 3), ragged lengths with N; a batch
+    """QuickEd with only_score: one score-only pass over the FILL's cells (run_fill_score, BandedArgs::fill_geom; one lane, 16
+    lanes or a wave per alignment by the launch's size) instead of fill + traceback + edit count.  On (the default) and
+    switched off: the oracle's scores and statuses on 10 kb reads, indel-heavy pairs (stages 2 / 3), ragged lengths with N; a batch
     with lower-case / IUPAC symbols (the reference's traceback compares raw bytes, bpm_banded.c:1012: the library must keep
     the align step there); queued runs, where the pass sits inside the fast flow with its cutoffs still on the device and
-    the pairs that leave the flow are finished afterwards; and, above the size where the library takes the pass by itself, the
-    same array as the align step's with the same block-advance count and no traceback step."""
+    the pairs that leave the flow are finished afterwards; and the same array as the align step's with the same block-advance
+    count and no traceback step."""
     sets = [("10 kb", list(datagen.generate(192, 10000, 0.05, seed=611).pairs())),
             ("indels", list(datagen.generate(160, 3000, 0.1, seed=612, indels_num=2, indels_len=300).pairs())),
             ("mixed", mixed_batch())]
@@ -595,10 +595,10 @@ def test_quicked_only_score_pass(monkeypatch):
             monkeypatch.delenv("QE_QUICKED_EST", raising=False)
             capi.reload_env()
             rb.close()
-    # the library's own choice: synchronous runs of >= 12 288 pairs (chip(): simds * 12), queued runs of >= 1 024
+    # the library's own choice (always the pass), one lane per alignment at this size
     monkeypatch.delenv("QE_QUICKED_SCORE_PASS", raising=False)
     capi.reload_env()
-    b = datagen.generate(12800, 1000, 0.05, seed=614)
+    b = datagen.generate(20000, 1000, 0.05, seed=614)
     rb = capi.ResidentBatch(b)
     p = capi.make_params(algo=0, only_score=True)
     got = []

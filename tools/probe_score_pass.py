@@ -14,9 +14,12 @@ for n in sizes:
     b = datagen.generate(n, 10000, 0.05, seed=datagen.DEFAULT_SEED)
     rb = capi.ResidentBatch(b)
     ref = None
-    for mode, fast in (("0", "1"), ("1", "0"), ("1", "1")):
+    for mode, fast, sys_ in (("0", "1", None), ("1", "0", None), ("1", "1", None), ("1", "1", "0")):
         os.environ["QE_QUICKED_SCORE_PASS"] = mode
         os.environ["QE_QUICKED_SCORE_PASS_FAST"] = fast      # 0: synchronous runs take the pass at the end of the host-driven flow
+        os.environ.pop("QE_SCORE_SYS", None)
+        if sys_ is not None:
+            os.environ["QE_SCORE_SYS"] = sys_                # 0: one lane per alignment whatever the launch's size
         capi.reload_env()
         p = capi.make_params(algo=capi.QUICKED, only_score=True)
         for _ in range(2):
@@ -36,7 +39,7 @@ for n in sizes:
             assert rb.run(p, sync=False) >= 0
         rb.sync()
         dt = time.perf_counter() - t0
-        print(f"{n:7d} pairs, score pass {mode} (sync runs in the fast flow {fast}): stream {n * steps / dt / 1e6:.3f} M alignments/s, alone {min(lat) * 1e3:.2f} ms; "
+        print(f"{n:7d} pairs, score pass {mode} (sync runs in the fast flow {fast}, QE_SCORE_SYS {sys_}): stream {n * steps / dt / 1e6:.3f} M alignments/s, alone {min(lat) * 1e3:.2f} ms; "
               f"scores identical to the align step's: {same}; counters {ctr}", flush=True)
     rb.close()
     capi.pool_trim()

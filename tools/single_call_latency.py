@@ -17,7 +17,8 @@ def once(p, pt):
     return s
 
 
-for length, algo, only in ((1000, capi.BANDED, True), (1000, capi.QUICKED, False), (10000, capi.BANDED, True), (10000, capi.QUICKED, False)):
+for length, algo, only in ((1000, capi.BANDED, True), (1000, capi.QUICKED, False), (10000, capi.BANDED, True), (10000, capi.QUICKED, False),
+                           (1000, capi.QUICKED, True), (10000, capi.QUICKED, True)):
     pairs = list(datagen.generate(300, length, 0.05, seed=3).pairs())
     p = capi.make_params(algo=algo, only_score=only)
     for pt in pairs[:40]:
@@ -25,7 +26,7 @@ for length, algo, only in ((1000, capi.BANDED, True), (1000, capi.QUICKED, False
     ts = []
     for pt in pairs[40:]:
         t0 = time.perf_counter(); once(p, pt); ts.append(time.perf_counter() - t0)
-    print(f"len {length:6d} {'BandEd score-only' if only else 'QuickEd + CIGAR  '}: median {statistics.median(ts)*1e3:7.3f} ms  min {min(ts)*1e3:7.3f} ms per new+align+free")
+    print(f"len {length:6d} {('BandEd score-only' if algo == capi.BANDED else 'QuickEd score-only') if only else 'QuickEd + CIGAR  '}: median {statistics.median(ts)*1e3:7.3f} ms  min {min(ts)*1e3:7.3f} ms per new+align+free")
 
 # BASELINE config 1: 1000 pairs of 1 kb at 5 %, BandEd score-only
 b = datagen.generate(1000, 1000, 0.05)

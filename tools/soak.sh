@@ -17,8 +17,8 @@ QE_WINDOWED_QUAD=0 QE_WINDOWED_SYS=0 QE_FILL_SYS=0 QE_SCORE_SYS=0 QE_TRACE_SYS=0
 # round 6's wave formatter (64 consecutive runs per step, segmented scan) on every alignment, however few its runs
 QE_FORMAT_WAVE=1 timeout 900 python tests/soak_fuzz.py $(( $2 + 6000 )) $n > $out/soak_fuzz_format_wave.txt 2>&1
 QE_FORMAT_WAVE=1 timeout 900 python tests/soak_long.py $(( $2 + 6000 )) $m > $out/soak_long_format_wave.txt 2>&1
-# round 6, late: QuickEd with only_score from one score pass over the fill's cells, forced at every size (inside the fast flow
-# from an aligner's second batch on; at the end of the host-driven flow with _FAST=0)
-QE_QUICKED_SCORE_PASS=1 timeout 900 python tests/soak_fuzz.py $(( $2 + 7000 )) $n > $out/soak_fuzz_score_pass.txt 2>&1
-QE_QUICKED_SCORE_PASS=1 QE_QUICKED_SCORE_PASS_FAST=0 QE_QUICKED_EST=40 timeout 900 python tests/soak_fuzz.py $(( $2 + 8000 )) $n > $out/soak_fuzz_score_pass_classic.txt 2>&1
+# round 6, late: QuickEd with only_score from one score pass over the fill's cells (the default): at the end of the host-driven
+# flow only, with a small forced estimate; and switched off (the align step)
+QE_QUICKED_SCORE_PASS_FAST=0 QE_QUICKED_EST=40 timeout 900 python tests/soak_fuzz.py $(( $2 + 7000 )) $n > $out/soak_fuzz_score_pass_classic.txt 2>&1
+QE_QUICKED_SCORE_PASS=0 timeout 900 python tests/soak_fuzz.py $(( $2 + 8000 )) $n > $out/soak_fuzz_score_pass_off.txt 2>&1
 grep -h "MISMATCH\|^soak" $out/soak_*.txt | tail -30
