@@ -364,11 +364,23 @@ static void quicked_classic(quicked_batch& B, Context& C, const quicked_params_t
         for (u32 f : fl) if (f & FLAG_NONCANON) return false;
         return true;
     };
-    if (p.algo == QUICKED && p.only_score && whole_batch && fetch && quicked_score_pass_wanted() && all_canonical()) {
-        TaskList LS;
+    // Not where a pair's align step would split either (bpm_hirschberg.c:63-65): the levels' half passes are two launches of
+    // half the chain each, side by side, and one pass over a 100 kb read's band is one wave's chain of 0.4 s -- 64 / 1 000 /
+    // 10 000 pairs of 100 kb alone: 54 / 77 / 262 ms through the levels, 417 / 422 / 413-518 ms in one pass
+    // (profiles/r06_y_probe_long_reads.txt)
+    auto none_splits = [&]() {
+        const uint64_t split = split_threshold();
+        for (size_t t = 0; t < L.pair.size(); ++t)
+            if (L.pair[t] >= 0 && (uint64_t)host_geometry(L.m[t], L.n[t], bound[t]).ebb * (uint64_t)L.n[t] * 16u > split) return false;
+        return true;
+    };
+    TaskList LS;
+    if (p.algo == QUICKED && p.only_score && whole_batch && fetch && quicked_score_pass_wanted() && none_splits()) {
         for (size_t t = 0; t < L.pair.size(); ++t)
             if (L.pair[t] >= 0) LS.push(L.pair[t], 0, L.m[t], 0, L.n[t], bound[t], L.n[t]);
         LS.pad();
+    }
+    if (!LS.pair.empty() && quicked_score_pass_fits(LS, fetch) && all_canonical()) {
         enter_a();
         qe_timer_start(tl_timers.align);
         StageResult RS;
@@ -822,23 +834,22 @@ quicked_status_t run_batch(quicked_batch& B, const quicked_params_t& p, bool fet
             Stage1Args sa;
             sa.nt = (int32_t)nt; sa.pair = T1.pair; sa.m = T1.m; sa.n = T1.n; sa.score = W1.score; sa.hew = W1.hew; sa.steps = W1.steps;
             sa.est = d_est; sa.hew_percentage = p.hew_percentage[0]; sa.o_cut = d_cut; sa.o_skip = d_skip; sa.o_steps = d_steps;
-            // only_score: the fill's end value from a score-only pass instead of fill + traceback + edit count (run_fill_score)
-            const bool score_pass = p.only_score && quicked_score_pass_wanted();
-            sa.flags = score_pass ? B.d_flags[B.parity] : nullptr;
-            hipLaunchKernelGGL(k_stage1_decide, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, C.stream, sa);
-            HIP_CHECK(hipEventRecord(C.ev_decided[C.ai], C.stream));    // the stage's outputs live in the set's W pool, which the set's next run recycles
-            C.decided_set[C.ai] = true;
-            QE_TRACE_POINT("fast: decide queued");
             TaskList LA;
             for (size_t t = 0; t < nt; ++t) {
                 if (L.pair[t] < 0) continue;
                 LA.push(L.pair[t], 0, L.m[t], 0, L.n[t], est[t], L.n[t]);
             }
-            QE_TRACE_POINT("fast: stage 1 + align list queued");
+            // only_score: the fill's end value from a score-only pass instead of fill + traceback + edit count (run_fill_score)
+            bool score_pass = p.only_score && quicked_score_pass_wanted();
+            if (score_pass && (score_pass = quicked_score_pass_fits(LA, fetch))) LA.pad();      // (run_align takes its roots unpadded)
+            sa.flags = score_pass ? B.d_flags[B.parity] : nullptr;
+            hipLaunchKernelGGL(k_stage1_decide, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, C.stream, sa);
+            HIP_CHECK(hipEventRecord(C.ev_decided[C.ai], C.stream));    // the stage's outputs live in the set's W pool, which the set's next run recycles
+            C.decided_set[C.ai] = true;
+            QE_TRACE_POINT("fast: decide queued");
             qe_timer_start(tl_timers.align);
             AlignStats AS;
             if (score_pass) {
-                LA.pad();
                 StageResult RS;
                 run_fill_score(B, C, LA, &RS, fetch, &B.d_score, pf, d_cut, d_skip);
                 if (fetch) { scatter_scores(B, LA, RS.score, QUICKED_WIP); AS.fill_adv = sum_u32(RS.adv); }      // (the tasks that left the list: -1, 0 -- the classic flow below)

@@ -1503,8 +1503,9 @@ __global__ __launch_bounds__(512) void k_banded_coop_lds(CoopLdsArgs X) {
     const bool hasN = (fl & FLAG_HAS_N) != 0;
     const Geom GE = band_geometry(m, n, cut_in);
     const int nw = (m + 63) >> 6;
-    const int nsl = FILL ? GE.ebb : ((GE.cutoff + 63) >> 6) + 1;        // the score-only passes use their own narrower band (bpm_banded.c:801-803)
-    const int stop_row = FILL ? nw - 1 : nw;                            // bpm_banded.c:295 / 917
+    const bool fgeom = FILL || A.fill_geom != 0;                        // score-only over the fill's cells (BandedArgs::fill_geom)
+    const int nsl = fgeom ? GE.ebb : ((GE.cutoff + 63) >> 6) + 1;       // the score-only passes use their own narrower band (bpm_banded.c:801-803)
+    const int stop_row = fgeom ? nw - 1 : nw;                           // bpm_banded.c:295 / 917
     const int lvl_last = (m - 1) & 63;
     const int prolog = GE.prolog;
     // my slots, and the passes every lane of the wave walks them in

@@ -308,7 +308,15 @@ static int coop_lanes(const TaskList& L, int in_flight = 1, bool fill = false) {
 }
 
 // k_banded_coop over the list, then k_banded<false> over the tasks it flagged
-static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int G, int timed) {
+// the band state of a wave's 64 / G tasks in LDS (k_banded_coop_lds): bytes per wave for bands of ns slots
+static size_t coop_lds_bytes(int ns, int G) {
+    const int NA = 64 / G, rr = ns + G + 4, cr = std::max(16, 4 * G);
+    const size_t bytes = (size_t)2 * (ns + 1) * NA * 8 + (size_t)2 * rr * NA * 4 + (size_t)2 * cr * NA * 2 + (size_t)2 * NA * 4;
+    return (bytes + 63) & ~(size_t)63;
+}
+// fill_geom: score-only over the FILL's cells (BandedArgs::fill_geom) -- the LDS form only; d_cut / d_skip as launch_banded_score
+static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskList& L, bool reversed, int G, int timed, bool fill_geom = false,
+                                      const int32_t* d_cut = nullptr, const int32_t* d_skip = nullptr) {
     ScoreLaunch S;
     S.nt = L.pair.size();
     const int NA = 64 / G;
@@ -316,23 +324,32 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     std::vector<int64_t> w_off(nwaves);
     std::vector<int32_t> w_ns(nwaves), w_nr(nwaves), w_nch(nwaves);
     size_t ws_bytes = 0;
+    int ns_max = 3;
     for (size_t w = 0; w < nwaves; ++w) {
         int ns = 3, nr = 4, nch = 2;
         for (int q = 0; q < NA; ++q) {
             const size_t t = w * NA + q;
             if (L.pair[t] < 0) continue;
             const HGeom Gm = host_geometry(L.m[t], L.n[t], L.cutoff[t]);
-            ns = std::max(ns, Gm.ebb_local);
-            nr = std::max(nr, (L.m[t] + 63) / 64 + Gm.ebb_local + 4);
+            const int nsl = fill_geom ? Gm.ebb : Gm.ebb_local;
+            ns = std::max(ns, nsl);
+            nr = std::max(nr, (L.m[t] + 63) / 64 + nsl + 4);
             nch = std::max(nch, L.n[t] / 64 + 3);
         }
         w_ns[w] = ns; w_nr[w] = nr; w_nch[w] = nch;
+        ns_max = std::max(ns_max, ns);
         w_off[w] = (int64_t)ws_bytes;
         const size_t bytes = (size_t)2 * (ns + 1) * NA * 8 + (size_t)2 * nr * NA * 4 + (size_t)2 * nch * NA * 2 + (size_t)2 * NA * 4;
         ws_bytes += (bytes + 255) & ~(size_t)255;
     }
+    if (fill_geom && (env_int("QE_COOP_LDS", 1) == 0 || coop_lds_bytes(ns_max, G) > (size_t)38 * 1024))
+        return launch_banded_score(B, C, L, reversed, timed, true, d_cut, d_skip);      // no room on chip: one lane per task
     S.T = upload_tasks(L, C);
     S.O = take_out(C, S.nt);
+    if (d_cut) {
+        HIP_CHECK(hipMemsetAsync(S.O.score, 0xFF, S.nt * sizeof(int32_t), C.stream));
+        hipLaunchKernelGGL(k_apply_cutoffs, dim3((unsigned)((S.nt + 255) / 256)), dim3(256), 0, C.stream, (int)S.nt, S.T.cutoff, S.T.pair, d_cut, d_skip);
+    }
     uint8_t* ws = C.scratch_p->take<uint8_t>(ws_bytes + 256);
     int64_t* d_off = C.scratch_p->take<int64_t>(nwaves); int32_t* d_ns = C.scratch_p->take<int32_t>(nwaves);
     int32_t* d_nr = C.scratch_p->take<int32_t>(nwaves); int32_t* d_nch = C.scratch_p->take<int32_t>(nwaves);
@@ -343,6 +360,7 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     a.ws = ws; a.w_ws_off = d_off; a.w_nslots = d_ns; a.w_nrows = d_nr; a.w_nch = d_nch;
     a.o_score = S.O.score; a.o_first = S.O.first; a.o_last = S.O.last; a.o_posv = S.O.posv; a.o_adv = S.O.adv;
     a.o_maxrow = S.O.len; a.o_abort = S.O.hew;
+    a.fill_geom = fill_geom ? 1 : 0;
     HIP_CHECK(hipMemsetAsync(S.O.hew, 0, S.nt * sizeof(int32_t), C.stream));
     auto* ke = timed ? C.kernel_events(timed - 1) : nullptr;       // timed = kind + 1 (Context::kernel_events)
     if (ke) HIP_CHECK(hipEventRecord(ke->first, C.stream));
@@ -364,9 +382,11 @@ static ScoreLaunch launch_banded_coop(quicked_batch& B, Context& C, const TaskLi
     else
         launch_groups(C, k_banded_coop, a, (size_t)nwaves, 8, 0);
     // fallback pass: one lane per task, only where a band-edge decision could not be resolved in time
-    const BandLayout lay = band_layout(L, false, false);
+    BandLayout lay = band_layout(L, fill_geom, false);
+    lay.mat_u4 = 0;
     S.D = upload_layout(lay, C);
     BandedArgs b;
+    b.fill_geom = fill_geom ? 1 : 0;
     b.P = a.P; b.T = S.T.v;
     b.ws = S.D.ws; b.g_ws_off = S.D.ws_off; b.g_nslots = S.D.nslots; b.g_nrows = S.D.nrows; b.g_nch = S.D.nch;
     b.mat = nullptr; b.g_mat_off = S.D.mat_off;
@@ -588,10 +608,24 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
 // QE_QUICKED_SCORE_PASS = 0: never (the align step: tests); QE_QUICKED_SCORE_PASS_FAST = 0: synchronous runs take the pass at the
 // end of the host-driven flow only.
 static bool quicked_score_pass_wanted() { return env_int("QE_QUICKED_SCORE_PASS", 1) != 0; }
+// ... and for THIS list (cutoffs: the bounds, or the fast flow's estimates): a run the caller waits for, of a few thousand
+// tasks whose bands are too tall for the systolic forms, is a handful of one-lane waves with one wave's chain each, and the
+// align step's cooperative fill is ahead there (2 000 pairs of 20 kb at 5 %: 11 ms against 15; of 10 kb at 10 %: 7.8 / 7.8;
+// from 8 000 pairs on the pass wins: 20 / 16 and 12.6 / 7.9 ms).  Queued runs fill the chip together: always.
+static bool quicked_score_pass_fits(const TaskList& L, bool fetch) {
+    if (env_int("QE_QUICKED_SCORE_PASS", -1) == 1 || !fetch) return true;
+    if (sys_score_lanes(L, 1, true) != 0) return true;
+    size_t live = 0;
+    for (int32_t pr : L.pair) live += pr >= 0;
+    return live >= (size_t)chip(tl_device).simds * 4;
+}
 // fetch: the scores and block-advance counts to the host (R).  pf: a queued run's (kind 1; the fast flow's fields are the caller's)
 static void run_fill_score(quicked_batch& B, Context& C, const TaskList& L, StageResult* R, bool fetch, int32_t** d_score_out,
                            PendingFetch* pf = nullptr, const int32_t* d_cut = nullptr, const int32_t* d_skip = nullptr) {
     // launches of few waves: the systolic forms (16 lanes or a wave per task), as the score-only passes and the fills take them
+    // (the cooperative LDS form can run the pass too -- launch_banded_coop(.., fill_geom) -- but loses to the one-lane kernel
+    // wherever it was tried: 2 000 / 8 000 / 30 000 pairs of 20 kb alone 21 / 21 / 30 ms against 15 / 16 / 21, its bands of ~20
+    // slots leave G = 8 lanes 2 G + 4 slots and most tasks to the fallback pass: profiles/r06_y_probe_coop_form.txt)
     const int lg = sys_score_lanes(L, fetch ? 1 : C.in_flight, true);
     const ScoreLaunch S = lg ? launch_banded_sys(B, C, L, false, lg, 2 /* timed as a fill */, true, d_cut, d_skip)
                              : launch_banded_score(B, C, L, false, 2, true, d_cut, d_skip);

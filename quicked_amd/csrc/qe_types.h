@@ -102,6 +102,7 @@ struct CoopArgs {
     uint8_t* ws;  const int64_t* w_ws_off;  const int32_t* w_nslots;  const int32_t* w_nrows;  const int32_t* w_nch;
     int32_t* o_score;  int32_t* o_first;  int32_t* o_last;  int32_t* o_posv;  u32* o_adv;  int32_t* o_maxrow;
     int32_t* o_abort;                        // 1: a band-edge decision could not be resolved in time; rerun with k_banded<false>
+    int32_t fill_geom = 0;                   // k_banded_coop_lds<false>: the fill's band geometry (BandedArgs::fill_geom)
 };
 
 // the same with the band state of a wave's tasks in LDS (k_banded_coop_lds): what the whole launch is sized for

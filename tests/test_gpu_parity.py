@@ -595,7 +595,20 @@ def test_quicked_only_score_pass(monkeypatch):
             monkeypatch.delenv("QE_QUICKED_EST", raising=False)
             capi.reload_env()
             rb.close()
-    # the library's own choice (always the pass), one lane per alignment at this size
+    # reads whose align step splits (bpm_hirschberg.c:63-65) keep it, forced or not: the levels' half passes beat one pass
+    b = datagen.generate(48, 30000, 0.08, seed=615)
+    want = oracle_many(list(b.pairs()), algo=0, only_score=True)
+    for mode in ("1", None):
+        if mode is None:
+            monkeypatch.delenv("QE_QUICKED_SCORE_PASS", raising=False)
+            capi.reload_env()
+        else:
+            monkeypatch.setenv("QE_QUICKED_SCORE_PASS", mode)
+        sc, stt, _, cnt = gpu_batch(b, algo=0, only_score=True)
+        assert [(int(stt[i]), int(sc[i]), None) for i in range(len(b))] == want, mode
+        assert cnt[3] > 0, (mode, cnt)                         # traceback steps: the align step ran
+    # the library's own choice (the pass: 20 000 pairs are past the size below which a waited-for run of tall bands keeps
+    # the align step), one lane per alignment at this size
     monkeypatch.delenv("QE_QUICKED_SCORE_PASS", raising=False)
     capi.reload_env()
     b = datagen.generate(20000, 1000, 0.05, seed=614)

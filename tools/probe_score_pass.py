@@ -10,16 +10,21 @@ from quicked_amd import capi, datagen
 
 sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1024, 2048, 4096, 8192, 12500, 25000, 50000, 100000]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+length = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
+error = float(sys.argv[4]) if len(sys.argv) > 4 else 0.05
 for n in sizes:
-    b = datagen.generate(n, 10000, 0.05, seed=datagen.DEFAULT_SEED)
+    b = datagen.generate(n, length, error, seed=datagen.DEFAULT_SEED)
     rb = capi.ResidentBatch(b)
     ref = None
-    for mode, fast, sys_ in (("0", "1", None), ("1", "0", None), ("1", "1", None), ("1", "1", "0")):
-        os.environ["QE_QUICKED_SCORE_PASS"] = mode
+    for mode, fast, sys_ in (("0", "1", None), (None, "1", None), ("1", "0", None), ("1", "1", None), ("1", "1", "0")):      # (sys_ "0": also QE_COOP_FILL_G = 1, no cooperative form)
+        os.environ.pop("QE_QUICKED_SCORE_PASS", None)
+        if mode is not None:
+            os.environ["QE_QUICKED_SCORE_PASS"] = mode       # None: the library's own choice; 1: the pass wherever the results allow it
         os.environ["QE_QUICKED_SCORE_PASS_FAST"] = fast      # 0: synchronous runs take the pass at the end of the host-driven flow
-        os.environ.pop("QE_SCORE_SYS", None)
+        os.environ.pop("QE_SCORE_SYS", None); os.environ.pop("QE_COOP_FILL_G", None)
         if sys_ is not None:
             os.environ["QE_SCORE_SYS"] = sys_                # 0: one lane per alignment whatever the launch's size
+            os.environ["QE_COOP_FILL_G"] = "1"
         capi.reload_env()
         p = capi.make_params(algo=capi.QUICKED, only_score=True)
         for _ in range(2):
@@ -39,7 +44,7 @@ for n in sizes:
             assert rb.run(p, sync=False) >= 0
         rb.sync()
         dt = time.perf_counter() - t0
-        print(f"{n:7d} pairs, score pass {mode} (sync runs in the fast flow {fast}, QE_SCORE_SYS {sys_}): stream {n * steps / dt / 1e6:.3f} M alignments/s, alone {min(lat) * 1e3:.2f} ms; "
+        print(f"{n:7d} pairs of {length}, score pass {mode} (sync runs in the fast flow {fast}, QE_SCORE_SYS {sys_}): stream {n * steps / dt / 1e6:.3f} M alignments/s, alone {min(lat) * 1e3:.2f} ms; "
               f"scores identical to the align step's: {same}; counters {ctr}", flush=True)
     rb.close()
     capi.pool_trim()
