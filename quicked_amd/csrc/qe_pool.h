@@ -87,12 +87,12 @@ inline const Chip& chip(int device) {
 // runs) parses the environment again; it must not run concurrently with other calls into the library.
 // ---------------------------------------------------------------------------
 struct SwitchTable {
-    static constexpr int N = 28;
+    static constexpr int N = 29;
     static constexpr const char* names[N] = {
         "QE_QUICKED_FAST", "QE_QUICKED_EST", "QE_FINISH_MERGE", "QE_FINISH_MERGE_PAIRS", "QE_FINISHERS", "QE_WAVE_PRIO", "QE_LANE_REL",
         "QE_COOP_G", "QE_COOP_FILL_G", "QE_COOP_LDS", "QE_WAVE", "QE_SCORE_SYS", "QE_STAGE3_DEVICE", "QE_FORMAT_WAVE", "QE_WINDOWED_CP",
         "QE_WINDOWED_QUAD", "QE_WINDOWED_SYS", "QE_SPLIT_BYTES", "QE_FILL_SYS", "QE_COOP_TALL_FILL", "QE_FILL_MULTI", "QE_TRACE_SYS",
-        "QE_TRACE", "QE_TRACE_POOL", "QE_OOM_WAIT_MS", "QE_SCORE_WAVES", "QE_QUICKED_SCORE_PASS", "QE_QUICKED_SCORE_PASS_FAST"};
+        "QE_TRACE", "QE_TRACE_POOL", "QE_OOM_WAIT_MS", "QE_SCORE_WAVES", "QE_QUICKED_SCORE_PASS", "QE_QUICKED_SCORE_PASS_FAST", "QE_SCORE_PASS_COOP_G"};
     bool set[N];
     long long value[N];
     SwitchTable() {

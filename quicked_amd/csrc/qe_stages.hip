@@ -627,8 +627,10 @@ static void run_fill_score(quicked_batch& B, Context& C, const TaskList& L, Stag
     // wherever it was tried: 2 000 / 8 000 / 30 000 pairs of 20 kb alone 21 / 21 / 30 ms against 15 / 16 / 21, its bands of ~20
     // slots leave G = 8 lanes 2 G + 4 slots and most tasks to the fallback pass: profiles/r06_y_probe_coop_form.txt)
     const int lg = sys_score_lanes(L, fetch ? 1 : C.in_flight, true);
-    const ScoreLaunch S = lg ? launch_banded_sys(B, C, L, false, lg, 2 /* timed as a fill */, true, d_cut, d_skip)
-                             : launch_banded_score(B, C, L, false, 2, true, d_cut, d_skip);
+    const int Gc = lg ? 0 : env_int("QE_SCORE_PASS_COOP_G", 0);       // tests / probes: that many lanes per task in the cooperative LDS form
+    const ScoreLaunch S = lg ? launch_banded_sys(B, C, L, false, lg, 2 /* timed as a fill */, true, d_cut, d_skip) :
+                          Gc >= 2 ? launch_banded_coop(B, C, L, false, Gc, 2, true, d_cut, d_skip)
+                                  : launch_banded_score(B, C, L, false, 2, true, d_cut, d_skip);
     if (d_score_out) *d_score_out = S.O.score;
     if (pf && !fetch) {
         pf->kind = 1; pf->task_pair = L.pair; pf->d_score = S.O.score; pf->d_adv = S.O.adv; pf->counter_slot = 1;

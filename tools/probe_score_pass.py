@@ -16,13 +16,17 @@ for n in sizes:
     b = datagen.generate(n, length, error, seed=datagen.DEFAULT_SEED)
     rb = capi.ResidentBatch(b)
     ref = None
-    for mode, fast, sys_ in (("0", "1", None), (None, "1", None), ("1", "0", None), ("1", "1", None), ("1", "1", "0")):      # (sys_ "0": also QE_COOP_FILL_G = 1, no cooperative form)
+    coop = [("1", "1", "coop%d" % g) for g in (2, 4, 8)] if os.environ.get("PROBE_COOP") else []
+    for mode, fast, sys_ in [("0", "1", None), (None, "1", None), ("1", "0", None), ("1", "1", None), ("1", "1", "0")] + coop:      # (sys_ "0": also QE_COOP_FILL_G = 1, no cooperative form)
         os.environ.pop("QE_QUICKED_SCORE_PASS", None)
         if mode is not None:
             os.environ["QE_QUICKED_SCORE_PASS"] = mode       # None: the library's own choice; 1: the pass wherever the results allow it
         os.environ["QE_QUICKED_SCORE_PASS_FAST"] = fast      # 0: synchronous runs take the pass at the end of the host-driven flow
         os.environ.pop("QE_SCORE_SYS", None); os.environ.pop("QE_COOP_FILL_G", None)
-        if sys_ is not None:
+        os.environ.pop("QE_SCORE_PASS_COOP_G", None)
+        if sys_ is not None and sys_.startswith("coop"):
+            os.environ["QE_SCORE_SYS"] = "0"; os.environ["QE_SCORE_PASS_COOP_G"] = sys_[4:]      # the pass in the cooperative LDS form
+        elif sys_ is not None:
             os.environ["QE_SCORE_SYS"] = sys_                # 0: one lane per alignment whatever the launch's size
             os.environ["QE_COOP_FILL_G"] = "1"
         capi.reload_env()
