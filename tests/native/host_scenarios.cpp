@@ -62,9 +62,10 @@ static void scenario_rotation() {
     std::vector<quicked_batch_t*> bs;
     for (int k = 0; k < 5; ++k) { bs.push_back(create(P)); CHECK(bs.back()); }
     const quicked_params_t pb = params(BANDED, true), pq = params(QUICKED, false), pw = params(WINDOWED, true), ph = params(HIRSCHBERG, false);
+    const quicked_params_t pqs = params(QUICKED, true);                 // only_score: the score pass (one score per task + the fast flow's lists)
     for (int round = 0; round < 6; ++round) {
         for (size_t k = 0; k < bs.size(); ++k) {
-            const quicked_params_t* p = (round + k) % 4 == 0 ? &pb : ((round + k) % 4 == 1 ? &pq : ((round + k) % 4 == 2 ? &pw : &ph));
+            const quicked_params_t* p = (round + k) % 4 == 0 ? &pb : ((round + k) % 4 == 1 ? ((round & 1) ? &pqs : &pq) : ((round + k) % 4 == 2 ? &pw : &ph));
             CHECK(quicked_batch_run(bs[k], p, (round == 0) ? 1 : 0) >= 0);
         }
         for (size_t k = bs.size(); k-- > 0;) fetch_all(bs[k], P.n);
@@ -80,8 +81,11 @@ static void scenario_early_finish(int skip_every, int objects, int rounds) {
     setenv("QE_STUB_SKIP_EVERY", std::to_string(skip_every).c_str(), 1);
     const Pairs P = make_pairs(256, 300, 2);
     std::vector<quicked_batch_t*> bs;
-    const quicked_params_t pq = params(QUICKED, false);
-    for (int k = 0; k < objects; ++k) { bs.push_back(create(P)); CHECK(bs.back()); CHECK(quicked_batch_run(bs[k], &pq, 1) >= 0); }
+    // every third object runs with only_score: its queued runs are score passes inside the fast flow, whose left pairs go
+    // through the same early-finish threads (a flow of their own: merged flows take runs of equal parameters)
+    const quicked_params_t pq_cigar = params(QUICKED, false), pq_score = params(QUICKED, true);
+    auto pq_of = [&](int k) -> const quicked_params_t* { return (k % 3 == 2) ? &pq_score : &pq_cigar; };
+    for (int k = 0; k < objects; ++k) { bs.push_back(create(P)); CHECK(bs.back()); CHECK(quicked_batch_run(bs[k], pq_of(k), 1) >= 0); }
     std::atomic<int> next{0};
     std::thread fetcher([&] {                                          // fetches from another thread than the one that queues
         for (int i = 0; i < rounds * objects; ++i) {
@@ -94,7 +98,7 @@ static void scenario_early_finish(int skip_every, int objects, int rounds) {
             while (next.load() - (r * objects + k) < -objects + 1) std::this_thread::yield();
             // a batch object is queued again only after its last run was fetched
             while (r > 0 && next.load() < (r - 1) * objects + k + 1) std::this_thread::yield();
-            CHECK(quicked_batch_run(bs[k], &pq, 0) >= 0);
+            CHECK(quicked_batch_run(bs[k], pq_of(k), 0) >= 0);
             next.store(r * objects + k + 1);
         }
     fetcher.join();
