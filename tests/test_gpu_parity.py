@@ -274,6 +274,18 @@ def test_configs_2_and_3_at_full_size():
         assert 440 < int(s_q.min()) and int(s_q.max()) < 520                 # 460-493 on this generator
         assert bool(rb.check_results().all())
         cig = rb.cigars()
+        s_q = s_q.copy()
+        # QuickEd with only_score (one score-only pass over the fill's cells instead of the alignment): the same 100 k distances,
+        # a run the caller waits for and a queued one (the pass inside the fast flow, its cutoffs from the device)
+        rb.configure(check=False)
+        p_qs = capi.make_params(algo=0, only_score=True)
+        assert rb.run(p_qs, sync=True) == capi.QUICKED_WIP
+        s_s, st_s = rb.scores()
+        assert (st_s == capi.QUICKED_WIP).all() and (s_s == s_q).all() and rb.counters()[3] == 0
+        assert rb.run(p_qs, sync=False) >= 0
+        rb.fetch()
+        s_s, st_s = rb.scores()
+        assert (st_s == capi.QUICKED_WIP).all() and (s_s == s_q).all() and rb.counters()[3] == 0
     finally:
         rb.close()
         capi.pool_trim()                  # 100 k-pair QuickEd pools (five sets): not this test's to leave to the ones after it
