@@ -976,6 +976,18 @@ def main():
                 strong_share[wl] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "runs_in_flight", "single_batch_latency_ms",
                                                        "single_batch_value", "score_checksum")}
                 strong_share[wl]["aggregate_block_columns_per_s"] = o["valu"]["aggregate_block_columns_per_s"]
+            if "quicked" in wls and world == 1:
+                # the share with only_score (the 12.5 k pairs are still cached): two chains per batch instead of three
+                saved_steps = args.steps
+                try:
+                    args.steps = 4 * max(saved_steps, 40)
+                    o = quicked_score_leg(B, args, strong_share["quicked"]["score_checksum"])
+                    strong_share["quicked_score"] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "single_batch_latency_ms",
+                                                                         "score_checksum", "scores_equal_workloads_quicked", "traceback_steps")}
+                except Exception as e:      # noqa: BLE001
+                    strong_share["quicked_score"] = {"error": repr(e)}
+                finally:
+                    args.steps = saved_steps
             if "quicked" in wls and args.mixed_share > 0 and args.indels_num == 0:
                 # the same share with realistic data: 1 % of every 12.5 k-pair batch leaves the fast flow.  A flow for a hundred
                 # pairs lasts as long as one for thousands (launch latency), so the early-finish threads serve the pairs of

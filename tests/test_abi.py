@@ -233,6 +233,8 @@ def test_newest_committed_bench_line_follows_the_contract():
     for wl in ("banded_score", "quicked"):
         assert s[wl]["value"] > s[wl]["single_batch_value"] > 0 and s[wl]["runs_in_flight"] >= 3
     assert s["quicked_mixed"]["value"] > 0 and s["quicked_mixed"]["early_finish_flows"]["merged_flows"] >= 0
+    assert s["quicked_score"]["scores_equal_workloads_quicked"] is True and s["quicked_score"]["value"] > s["quicked"]["value"]
+    assert s["quicked_score"]["single_batch_latency_ms"] < s["quicked"]["single_batch_latency_ms"]
 
 
 def test_readme_numbers_are_generated_from_the_committed_bench_line():
