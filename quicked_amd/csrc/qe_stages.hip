@@ -598,14 +598,15 @@ static void run_banded_score(quicked_batch& B, Context& C, const TaskList& L, bo
 // bound is an upper bound of the distance (it is the cost of a real path), so the banded alignment with that cutoff is an
 // optimal one and its edit count is the value of the fill's end cell -- which a pass over the FILL's cells (its band
 // geometry, its bookkeeping: BandedArgs::fill_geom) computes without storing a checkpoint, walking a path or formatting a
-// run.  No split either: the pass needs no matrix (bpm_hirschberg.c:63-65 splits for memory), and the children's distances
-// add up to the same end value.  One lane per alignment, or the systolic forms where the launch is short of waves (run_fill_score).
+// run.  A read whose align step would split (bpm_hirschberg.c:63-65) keeps it -- the children's distances add up to the same
+// end value, but the levels' half passes are the faster way through a band that long (quicked_classic).  One lane per alignment,
+// or the systolic forms where the launch is short of waves (run_fill_score).
 // Measured on 10 kb pairs (align step / score pass, profiles/r06_t_probe_score_pass*.txt): one run alone 1 pair 3.9 / 2.9 ms,
 // 1 k pairs 4.7 / 3.2, 4 k 4.8 / 3.2, 8 k 6.1 / 3.8, 12.5 k 8.2 / 5.0, 25 k 13.5 / 8.6, 100 k 21.9 / 14.3; a stream of queued runs
-// 1 k pairs 0.44 / 1.5 M alignments/s, 4 k 2.9 / 4.8, 12.5 k 5.6 / 9.1, 25 k 6.3 / 10.4, 100 k 7.05 / 11.5 -- every size, so always.
+// 1 k pairs 0.44 / 1.5 M alignments/s, 4 k 2.9 / 4.8, 12.5 k 5.6 / 9.1, 25 k 6.3 / 10.4, 100 k 7.05 / 11.5 -- every size of such reads (taller bands: quicked_score_pass_fits).
 // In the fast flow the pass reads its cutoffs from the device like the align step does (k_apply_cutoffs); pairs with lower-case /
 // IUPAC symbols leave the flow there (Stage1Args::flags) and in the host-driven flow keep the whole batch on the align step.
-// QE_QUICKED_SCORE_PASS = 0: never (the align step: tests); QE_QUICKED_SCORE_PASS_FAST = 0: synchronous runs take the pass at the
+// QE_QUICKED_SCORE_PASS = 0: never (the align step: tests), 1: wherever the results allow it and no read splits; QE_QUICKED_SCORE_PASS_FAST = 0: synchronous runs take the pass at the
 // end of the host-driven flow only.
 static bool quicked_score_pass_wanted() { return env_int("QE_QUICKED_SCORE_PASS", 1) != 0; }
 // ... and for THIS list (cutoffs: the bounds, or the fast flow's estimates): a run the caller waits for, of a few thousand
